@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT, os.path.join(ROOT, "m17-cxx-demod_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+
+    import numpy as np
+
+    g = dict(np.load(os.path.join(HERE, "golden", "ref_vectors.npz")))
+    g["kat"] = json.load(open(os.path.join(HERE, "golden", "kat_vectors.json")))
+    return g

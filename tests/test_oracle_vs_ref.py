@@ -1,0 +1,95 @@
+"""Live comparison of the oracle with the reference's own headers (oracle/_ref/libm17ref.so, built in the
+build container by oracle/Makefile from /root/reference where it lies).  Skipped where _ref is absent; the
+same comparison is frozen into tests/golden/ for everywhere else.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+R = ol.ref()
+pytestmark = pytest.mark.skipif(R is None, reason="oracle/_ref not built (reference not present)")
+
+
+@pytest.mark.parametrize("seed,kind,sigma", [(1, 0, 0), (2, 1, 800), (3, 2, 2500), (4, 3, 0), (5, 0, 4000)])
+def test_front_end_bit_exact(seed, kind, sigma):
+    p = ol.gen_params(seed=seed, kind=kind, n_frames=3, lead_in=2500, noise_sigma=sigma, tail=2000, tail_sigma=max(sigma, 30),
+                      lead_sigma=40000.0, dc_offset=(-1000 if seed == 3 else 0), total=12000)
+    s = ol.generate(p)
+    x = ol.scale(s)
+    taps = ol.taps()
+    y = np.zeros_like(x)
+    R.ref_fir_f32(ol._p(taps), ol._p(x), C.c_size_t(x.size), ol._p(y))
+    assert np.array_equal(ol.fir_f32(x), y)
+    for a, b in zip(ol.correlator(y), ol.correlator(y, lib=R, prefix="ref_")):
+        assert np.array_equal(a, b)
+    for w in range(4):
+        for a, b in zip(ol.syncword(y, w), ol.syncword(y, w, lib=R, prefix="ref_")):
+            assert np.array_equal(a, b)
+    for period in (384, 960):
+        for a, b in zip(ol.dcd_trace(x, period), ol.dcd_trace(x, period, lib=R, prefix="ref_")):
+            assert np.array_equal(a, b)
+    for n, si in ((100, 7), (5000, 2), (11999, 5)):
+        assert ol.outer_levels(y[:n], si) == ol.outer_levels(y[:n], si, lib=R, prefix="ref_")
+    assert ol.dcd_sums(x, 1920, 960) == ol.dcd_sums(x, 1920, 960, lib=R, prefix="ref_")
+
+
+def test_dcd_nan_poisoning_matches_reference():
+    # an all-zero update window gives 0/0 = NaN and the level never recovers.
+    x = np.zeros(3000, dtype=np.float32)
+    x[1200:] = np.sin(np.arange(1800) * 2 * np.pi * 2400 / 48000).astype(np.float32)
+    a = ol.dcd_trace(x, 384)
+    b = ol.dcd_trace(x, 384, lib=R, prefix="ref_")
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])
+    assert np.isnan(a[0]).all()
+
+
+def test_slicer_evm_fec_bit_exact():
+    rng = np.random.default_rng(9)
+    sym = rng.normal(0, 2.2, 20000).astype(np.float32)
+    assert np.array_equal(ol.llr(sym), ol.llr(sym, lib=R, prefix="ref_"))
+    assert np.array_equal(ol.evm_trace(sym, 1), ol.evm_trace(sym, 1, lib=R, prefix="ref_"))
+    assert np.array_equal(ol.evm_trace(sym[:500], 0), ol.evm_trace(sym[:500], 0, lib=R, prefix="ref_"))
+    for _ in range(50):
+        d = rng.integers(0, 256, rng.integers(0, 40)).astype(np.uint8)
+        assert ol.crc16(d.tobytes()) == ol.crc16(d.tobytes(), lib=R, prefix="ref_")
+    for v in rng.integers(0, 1 << 24, 3000):
+        assert ol.golay_decode(int(v)) == ol.golay_decode(int(v), lib=R, prefix="ref_") or not ol.golay_decode(int(v))[0]
+        assert ol.golay_decode(int(v))[0] == ol.golay_decode(int(v), lib=R, prefix="ref_")[0]
+    for v in range(0, 4096, 37):
+        assert ol.golay_encode24(v) == ol.golay_encode24(v, lib=R, prefix="ref_")
+    f = rng.integers(-7, 8, 368).astype(np.int8)
+    for op in ("interleave", "deinterleave", "derandomize"):
+        assert np.array_equal(ol.frame_op(op, f), ol.frame_op(op, f, lib=R, prefix="ref_"))
+    b = rng.integers(0, 2, 368).astype(np.int8)
+    assert np.array_equal(ol.frame_op("randomize_bits", b), ol.frame_op("randomize_bits", b, lib=R, prefix="ref_"))
+    for (IN, OUT) in ((488, 240), (296, 144), (420, 206), (402, 197)):
+        for _ in range(40):
+            soft = rng.integers(-7, 8, IN).astype(np.int8)          # incl. zeros = erasures, pure noise
+            assert ol.viterbi(soft, OUT)[0] == ol.viterbi(soft, OUT, lib=R, prefix="ref_")[0]
+            assert np.array_equal(ol.viterbi(soft, OUT)[1], ol.viterbi(soft, OUT, lib=R, prefix="ref_")[1])
+    bits, st = ol.prbs9(1000)
+    rb, rs = ol.prbs9(1000, lib=R, prefix="ref_")
+    assert np.array_equal(bits, rb) and st == rs
+
+
+def test_frame_decoder_random_walk_bit_exact():
+    rng = np.random.default_rng(17)
+    so = (0, 0, np.zeros(30, np.uint8), 0, 0)
+    sr = (0, 0, np.zeros(30, np.uint8), 0, 0)
+    frames = []
+    for kind in (0, 1, 2):
+        fb, st = ol.make_frames(kind, 100 + kind, 6)
+        frames += [(int(t), b) for t, b in zip(st, fb)]
+    for step in range(400):
+        t, b = frames[rng.integers(len(frames))]
+        if rng.random() < 0.15:
+            t = int(rng.integers(0, 4))                    # wrong sync type for the content
+        fr = (b.astype(np.int16) * 2 - 1) * rng.integers(1, 8, 368)
+        fr = np.where(rng.random(368) < rng.choice([0.0, 0.03, 0.3]), -fr, fr).astype(np.int8)
+        ro = ol.decode_frame(t, fr, *so)
+        rr = ol.decode_frame(t, fr, *sr, lib=R, prefix="ref_")
+        so, sr = ro[1:], rr[1:]
+        assert (ro[1], ro[2], ro[3].tolist(), ro[4], ro[5]) == (rr[1], rr[2], rr[3].tolist(), rr[4], rr[5]), step
+        assert ro[0].tobytes() == rr[0].tobytes(), step
