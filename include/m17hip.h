@@ -1,0 +1,138 @@
+/* m17hip.h — C ABI of the MI355X-native M17 4-FSK demodulation hot path.
+ *
+ * The reference (mobilinkd/m17-cxx-demod) has no FFI layer: its hot path is the header-only
+ * operator surface in include/m17cxx driven one sample at a time by apps/m17-demod.cpp:484-490.
+ * This library is what a batched replacement of that path binds to: plain pointers and sizes,
+ * no C++ or torch types, every function returns 0 on success or a negative M17HIP_E* code
+ * (m17hip_strerror), no exceptions cross the boundary.  One context per (host thread, GPU).
+ * All channels of a context advance together: a "run" consumes T new samples of each of C
+ * independent 48 kSPS int16 baseband channels and continues from the state the previous run left
+ * (m17hip_demod_reset starts over), exactly as C fresh reference processes would.
+ *
+ * Each entry point names the reference interface it replaces (file:line in /root/reference).
+ */
+#ifndef M17HIP_H
+#define M17HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M17HIP_OK 0
+#define M17HIP_EINVAL (-1)   /* bad argument / size beyond what the context was created for */
+#define M17HIP_EHIP (-2)     /* a HIP runtime call failed (m17hip_last_hip_error) */
+#define M17HIP_ENOMEM (-3)
+#define M17HIP_ESTATE (-4)   /* call sequence error (e.g. fetch before run) */
+#define M17HIP_EOVERFLOW (-5) /* a per-channel frame-record buffer overflowed */
+
+/* Frame-type / sync-type codes = the reference enums M17FrameDecoder.h:52-55. */
+enum { M17_FRAME_LSF = 0, M17_FRAME_LICH = 1, M17_FRAME_STREAM = 2, M17_FRAME_BASIC_PACKET = 3, M17_FRAME_FULL_PACKET = 4, M17_FRAME_BERT = 5 };
+enum { M17_SYNC_LSF = 0, M17_SYNC_STREAM = 1, M17_SYNC_PACKET = 2, M17_SYNC_BERT = 3 };
+
+/* One record per invocation of the reference's frame callback
+ * `bool(const output_buffer_t&, int viterbi_cost)` (M17FrameDecoder.h:98, called at :171,221,253,271,286,306).
+ * payload = lsf[30] | lich[6] | stream[18] | packet[26] | bert[25] according to frame_type. */
+typedef struct m17_frame_rec {
+    uint32_t channel;
+    uint32_t seq;        /* per-channel callback counter since the last reset */
+    uint64_t sample_pos; /* 0-based index (since reset) of the input sample whose processing fired the callback */
+    int32_t cost;        /* the callback's viterbi_cost argument */
+    uint8_t frame_type;  /* M17_FRAME_* */
+    uint8_t sync_type;   /* M17_SYNC_* that selected the decode */
+    uint8_t len;         /* valid payload bytes */
+    uint8_t flags;
+    uint8_t payload[32];
+    uint8_t pad[8];
+} m17_frame_rec; /* 64 bytes */
+
+/* Arguments of the most recent diagnostic callback (M17Demodulator.h:144, fired at :681-685 and :746-750),
+ * plus the demodulator state at the end of the run. */
+typedef struct m17_diag {
+    int32_t dcd;
+    float evm, deviation, offset;
+    int32_t locked;
+    float clock;
+    int32_t sample_index, sync_index, clock_index, viterbi_cost;
+    float dcd_level;
+    uint32_t n_diag;
+    uint32_t demod_state; /* M17Demodulator.h:146 DemodState */
+    uint32_t n_frames;    /* frame callbacks since reset */
+    uint32_t pad[2];
+} m17_diag; /* 64 bytes */
+
+typedef struct m17hip_ctx m17hip_ctx;
+
+#define M17HIP_FLAG_INVERT 1u /* apps/m17-demod.cpp:488 `if (invert_input) sample *= -1` */
+
+const char* m17hip_strerror(int code);
+int m17hip_last_hip_error(const m17hip_ctx* ctx);
+int m17hip_version(void);
+
+/* Context: device slabs for `max_channels` x `max_samples` (per run).  Replaces constructing one
+ * M17Demodulator<float> per channel (apps/m17-demod.cpp:455, M17Demodulator.h:180-182). */
+int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out);
+void m17hip_ctx_destroy(m17hip_ctx* ctx);
+/* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = the default stream). */
+int m17hip_set_stream(m17hip_ctx* ctx, void* hip_stream);
+
+/* Input: [C][T] int16, row pitch in samples.  Replaces the stdin read loop apps/m17-demod.cpp:484-488. */
+int m17hip_upload_i16(m17hip_ctx* ctx, const int16_t* host, uint32_t channels, uint32_t samples, size_t pitch);
+/* Same, from a DEVICE pointer (e.g. a tensor that already lives in HBM). */
+int m17hip_upload_i16_device(m17hip_ctx* ctx, const int16_t* dev, uint32_t channels, uint32_t samples, size_t pitch);
+
+/* ---- per-operator batched entry points (config 2 parity) ---------------------------------------- */
+/* K1: sample scaling + BaseFirFilter<float,150> with the RRC taps, ungated, over the uploaded slab
+ * (apps/m17-demod.cpp:489 scaling; FirFilter.h:28-43; taps M17Demodulator.h:79-118).
+ * out_host may be NULL (result stays on the device for the next operator). out: [C][T] float. */
+int m17hip_fir_rrc150(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint32_t flags, float* out_host);
+/* K2: Correlator::sample (limit_ = IIR LPF of |y|) and Correlator::correlate against the four M17 sync words
+ * (preamble, LSF, packet, EOT — M17Demodulator.h:154-157) for every sample of the FIR output left on the
+ * device by m17hip_fir_rrc150 (Correlator.h:43-64, IirFilter.h:26-42).  limit: [C][T]; corr: [4][C][T]. */
+int m17hip_correlator(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, float* limit_host, float* corr_host);
+/* K3: NSlidingDFT<float,48000,120,2> + DataCarrierDetect accumulation (SlidingDFT.h:118-132,
+ * DataCarrierDetect.h:53-58) over the uploaded slab.  For every 192-sample tick k the table holds the
+ * sequential sums of norm(X0), norm(X1) for segments that started 1..5 ticks ago (index a%5, a = start
+ * tick) and since the stream start (index 5): sums[C][ticks][6][2]. */
+int m17hip_dcd(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint32_t flags, float* sums_host, uint32_t* ticks_out);
+/* K4: Viterbi<Trellis<4,2>,4>::decode (Viterbi.h:162-239) on n depunctured soft-bit frames.
+ * kind: 0 = LSF 488->240, 1 = stream 296->144, 2 = packet 420->206, 3 = BERT 402->197.
+ * soft: [n][IN] int8 (0 = erasure); bits: [n][OUT] uint8; cost: [n]. */
+int m17hip_viterbi(m17hip_ctx* ctx, const int8_t* soft_host, uint32_t n_frames, int kind, uint8_t* bits_host, int32_t* cost_host);
+/* K4': M17FrameDecoder::operator() (M17FrameDecoder.h:353-392: derandomize, deinterleave, depuncture,
+ * Viterbi / Golay, CRC, frame-type state machine) on n independent 368-LLR frames, each with its own decoder
+ * state in/out.  sync_type[n]; state_io[n] (State enum), lich_io[n], lsf_io[n][30], dep401_io[n], cost_io[n];
+ * recs: [n][2] records, nrec[n] callbacks per frame. */
+int m17hip_decode_frames(m17hip_ctx* ctx, const int8_t* llr368_host, uint32_t n_frames, const uint8_t* sync_type,
+                         uint8_t* state_io, uint8_t* lich_io, uint8_t* lsf_io, int8_t* dep401_io, int64_t* cost_io,
+                         m17_frame_rec* recs, uint8_t* nrec);
+
+/* ---- the full chain ------------------------------------------------------------------------------- */
+/* Fresh demodulators for every channel (M17Demodulator ctor + zero-initialised storage). */
+int m17hip_demod_reset(m17hip_ctx* ctx);
+/* M17Demodulator<float>::operator() (M17Demodulator.h:657-753) for `samples` new samples of each channel of
+ * the uploaded slab; frame callbacks become records, the last diagnostic callback becomes m17_diag. */
+int m17hip_demod_run(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint32_t flags);
+/* Number of records produced by the last run (all channels). */
+int m17hip_frames_count(m17hip_ctx* ctx, uint64_t* total);
+/* Records of the last run, ordered by (channel, seq).  Host destination. */
+int m17hip_frames_fetch(m17hip_ctx* ctx, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* count);
+/* Same, compacted into caller-provided DEVICE memory (so a collective can ship it without a host hop). */
+int m17hip_frames_compact_device(m17hip_ctx* ctx, m17_frame_rec* recs_dev, uint64_t capacity, uint64_t* count);
+/* Per-channel diagnostics after the last run: diag_host[C]. */
+int m17hip_diag_fetch(m17hip_ctx* ctx, m17_diag* diag_host, uint32_t channels);
+
+/* ---- measurement ----------------------------------------------------------------------------------- */
+/* When enabled, every kernel launch of the context is bracketed by HIP events on the context's stream. */
+int m17hip_timing_enable(m17hip_ctx* ctx, int on);
+/* Accumulated device time (ms) and launch count per kernel since the last m17hip_timing_reset:
+ * which: 0 = fir_rrc150, 1 = dcd, 2 = demod_seq, 3 = viterbi/decode_frames, 4 = correlator, 5 = compaction. */
+int m17hip_timing_get(m17hip_ctx* ctx, int which, double* total_ms, uint64_t* launches);
+int m17hip_timing_reset(m17hip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M17HIP_H */

@@ -1,0 +1,316 @@
+// K4: per-frame FEC back end on the device — derandomise, deinterleave, depuncture, soft Viterbi
+// (K = 5, polys 031/027, LLR = 4), CRC-16, Golay(24,12) LICH recovery and the frame-type state machine.
+// Reference: M17FrameDecoder.h:40-395, Viterbi.h:94-240, Util.h:169-190,300-318, CRC16.h, Golay24.h.
+//
+// Mapping: ONE LANE PER FRAME.  The 16 path metrics live in registers (the 8 ACS butterflies are fully
+// unrolled), the 16 decision bits of each trellis step go to an LDS column private to the lane, the frame's
+// 368 LLRs are read from an LDS column private to the lane.  64 frames decode in lock step per wave; there
+// is no cross-lane traffic at all, so the only LDS cost is conflict-free column access ([word][lane] layout).
+// Integer work throughout: bit-exact by construction.
+#pragma once
+
+#include "m17_common.hpp"
+
+namespace m17 {
+
+// ---- host-built constant tables (uploaded once per context) ------------------------------------------------
+// soft-bit source map for the four depunctured layouts: entry for trellis input position i
+//   0x8000            erasure (puncture matrix 0)                      Util.h:176-180
+//   0x4000            never written by depuncture: keeps the previous frame's value (BERT [401])
+//   else bits 0..8    index into the received 368-LLR frame (after the QPP interleaver, PolynomialInterleaver.h:21-24)
+//        bit 9        multiply by -1 (decorrelator bit, M17Randomizer.h:43-49)
+struct DecodeTables {
+    uint16_t src[8][488];    // kind 0 LSF(488) 1 stream(296) 2 packet(420) 3 BERT(402); 4..7: identity (already depunctured input)
+    uint16_t lich_src[96];   // first 96 deinterleaved positions (hard bits for Golay)
+    uint32_t golay_fix[2048];  // 11-bit syndrome -> 23-bit error pattern (Golay24.h:131-177: every syndrome occurs once)
+};
+
+__device__ __constant__ const int DEC_IN[4] = {488, 296, 420, 402};
+__device__ __constant__ const int DEC_OUT[4] = {240, 144, 206, 197};
+
+// LDS columns: element k of lane l lives at base[k * 64 + l]
+struct DecodeLds {
+    uint32_t* llr;    // [92][64]   368 int8 LLRs packed little-endian
+    uint32_t* hist;   // [122][64]  16 decision bits per step, two steps per word
+    uint32_t* outb;   // [8][64]    decoded bytes (<= 30), little-endian packed
+    uint32_t* lsf;    // [8][64]    M17FrameDecoder::output_buffer.lsf (persistent across frames)
+};
+
+__device__ __forceinline__ int llr_at(const uint32_t* llr, int lane, int idx)
+{
+    const uint32_t w = llr[(idx >> 2) * 64 + lane];
+    return (int)(int8_t)(w >> (8 * (idx & 3)));
+}
+__device__ __forceinline__ int soft_at(const DecodeTables* tb, const uint32_t* llr, int lane, int kind, int i, int stale)
+{
+    const uint32_t e = tb->src[kind][i];
+    if (e & 0x8000u) return 0;
+    if (e & 0x4000u) return stale;
+    const int v = llr_at(llr, lane, (int)(e & 0x1FFu));
+    return (e & 0x200u) ? -v : v;
+}
+__device__ __forceinline__ uint32_t byte_at(const uint32_t* col, int lane, int b)
+{
+    return (col[(b >> 2) * 64 + lane] >> (8 * (b & 3))) & 0xFFu;
+}
+
+// CRC16<0x5935,0xFFFF> over n bytes of an LDS column (CRC16.h:12-70).
+__device__ __forceinline__ uint32_t crc16_col(const uint32_t* col, int lane, int n)
+{
+    uint32_t reg = 0xFFFFu;
+    for (int i = 0; i != 16; ++i) {  // reset()
+        const uint32_t bit = reg & 1u;
+        if (bit) reg ^= 0x5935u;
+        reg >>= 1;
+        if (bit) reg |= 0x8000u;
+    }
+    for (int k = 0; k < n; ++k) {
+        const uint32_t byte = byte_at(col, lane, k);
+        for (int i = 0; i != 8; ++i) {
+            const uint32_t msb = reg & 0x8000u;
+            reg = ((reg << 1) & 0xFFFFu) | ((byte >> (7 - i)) & 1u);
+            if (msb) reg ^= 0x5935u;
+        }
+    }
+    for (int i = 0; i != 16; ++i) {  // get()
+        const uint32_t msb = reg & 0x8000u;
+        reg = (reg << 1) & 0xFFFFu;
+        if (msb) reg ^= 0x5935u;
+    }
+    return reg;
+}
+
+__device__ __forceinline__ uint32_t golay_syndrome(uint32_t cw)  // Golay24.h:88-98
+{
+    cw &= 0xFFFFFFu;
+    for (int i = 0; i != 12; ++i) {
+        if (cw & 1u) cw ^= 0xC75u;
+        cw >>= 1;
+    }
+    return cw;  // 11 bits (the reference returns this << 12)
+}
+__device__ __forceinline__ bool golay_decode(const DecodeTables* tb, uint32_t input, uint32_t& output)  // Golay24.h:203-222
+{
+    const uint32_t syn = golay_syndrome(input >> 1);
+    const uint32_t correction = tb->golay_fix[syn & 0x7FFu] << 1;
+    output = input ^ correction;
+    return __popc(syn) < 3 || !(__popc(output) & 1);
+}
+
+// Viterbi<Trellis<4,2>,4>::decode (Viterbi.h:162-239).  Returns cost; decoded bytes (to_byte_array, Util.h:300-318)
+// are left in L.outb.  `stale_io`: value of depunctured position 401 left by the previous frame (Q4); updated to this
+// frame's position-401 value when the layout writes it (LSF, packet).
+__device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const DecodeLds& L, int lane, int kind, int& stale_io)
+{
+    const int IN = DEC_IN[kind & 3], OUT = DEC_OUT[kind & 3];
+    const int steps = IN >> 1;
+    constexpr int32_t MAXM = 0x7FFFFFFF / 2;
+    int32_t m[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) m[s] = MAXM;
+    m[0] = 0;
+    uint32_t prev_bits = 0;
+    for (int h = 0; h < steps; ++h) {
+        const int s0 = soft_at(tb, L.llr, lane, kind, 2 * h, stale_io);
+        const int s1 = soft_at(tb, L.llr, lane, kind, 2 * h + 1, stale_io);
+        if (2 * h == 400 && (kind & 3) != 3) stale_io = s1;  // this layout writes position 401
+        // branch metrics (Viterbi.h:181-200): an erased bit contributes 0
+        const int a = s0 ? abs(-7 - s0) : 0, b = s0 ? abs(7 - s0) : 0;  // |c - s0| for c = -7 / +7
+        const int d = s1 ? abs(-7 - s1) : 0, e = s1 ? abs(7 - s1) : 0;
+        // |c + s| = |(-c) - s| : the complement costs swap a<->b, d<->e
+        const int nn0 = a + d, nn1 = b + e;  // cost_[j] = (-7,-7): cost0, cost1
+        const int np0 = a + e, np1 = b + d;  // (-7,+7)
+        const int pn0 = b + d, pn1 = a + e;  // (+7,-7)
+        const int pp0 = b + e, pp1 = a + d;  // (+7,+7)
+        // cost_[0..7] = (-7,-7)(-7,7)(-7,7)(-7,-7)(7,-7)(7,7)(7,7)(7,-7)   (polys 031/027)
+        const int c0[8] = {nn0, np0, np0, nn0, pn0, pp0, pp0, pn0};
+        const int c1[8] = {nn1, np1, np1, nn1, pn1, pp1, pp1, pn1};
+        int32_t n[16];
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int32_t m0 = m[j] + c0[j], m1 = m[j] + c1[j];
+            const int32_t m2 = m[j + 8] + c1[j], m3 = m[j + 8] + c0[j];
+            const bool d0 = m0 > m2, d1 = m1 > m3;
+            bits |= (d0 ? 1u : 0u) << (2 * j);
+            bits |= (d1 ? 1u : 0u) << (2 * j + 1);
+            n[2 * j] = d0 ? m2 : m0;
+            n[2 * j + 1] = d1 ? m3 : m1;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) m[s] = n[s];
+        if (h & 1) L.hist[(h >> 1) * 64 + lane] = prev_bits | (bits << 16);
+        else prev_bits = bits;
+    }
+    if (steps & 1) L.hist[(steps >> 1) * 64 + lane] = prev_bits;
+    // end state: first strict minimum scanning 0 -> 15 (Viterbi.h:211-221)
+    int best = 0;
+    int32_t best_cost = m[0];
+#pragma unroll
+    for (int s = 1; s < 16; ++s)
+        if (m[s] < best_cost) { best_cost = m[s]; best = s; }
+    const uint32_t cost = (uint32_t)roundf((float)best_cost / 7.0f);
+    // chainback (Viterbi.h:226-236) fused with to_byte_array: bit n of the message -> byte n>>3, bit 7-(n&7)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) L.outb[q * 64 + lane] = 0;
+    uint32_t state = (uint32_t)best;
+    uint32_t word = 0;
+    int o = OUT;
+    int index = steps;
+    for (int hi = steps; hi > 0 && o > 0;) {
+        --hi;
+        const uint32_t hw = L.hist[(hi >> 1) * 64 + lane];
+        const uint32_t hb = (hi & 1) ? (hw >> 16) : (hw & 0xFFFFu);
+        const uint32_t v = (hb >> state) & 1u;
+        if (index-- <= OUT) {
+            --o;
+            const int byte = o >> 3;
+            word |= (state & 1u) << (8 * (byte & 3) + (7 - (o & 7)));
+            if ((o & 31) == 0) { L.outb[(byte >> 2) * 64 + lane] = word; word = 0; }
+        }
+        state = (state >> 1) + (v ? 8u : 0u);  // prevState_[s] = (s>>1, (s>>1)+8)
+    }
+    return cost;
+}
+
+// Per-lane frame-decoder state (M17FrameDecoder members that persist between frames).
+struct DecoderRegs {
+    uint32_t state;          // State enum: 0 LSF 1 STREAM 2 BASIC_PACKET 3 FULL_PACKET 4 BERT
+    uint32_t lich_segments;
+    int stale401;            // depuncture_buffer[401]
+};
+
+struct RecSink {  // where callbacks go
+    FrameRec* base;   // this channel's record slots for this run
+    uint32_t cap;
+    uint32_t* n_run;  // records written this run (register copy owned by caller)
+    uint32_t* seq;    // records since reset
+    uint32_t channel;
+    uint64_t sample_pos;
+    uint32_t sync_type;
+    uint32_t* overflow;
+};
+
+__device__ __forceinline__ void emit_record(const RecSink& S, uint32_t& n_run, uint32_t& seq, uint32_t frame_type, int32_t cost,
+                                            const uint32_t* col, int lane, uint32_t len)
+{
+    if (n_run < S.cap) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(S.base + n_run);
+        w[0] = S.channel;
+        w[1] = seq;
+        w[2] = (uint32_t)S.sample_pos;
+        w[3] = (uint32_t)(S.sample_pos >> 32);
+        w[4] = (uint32_t)cost;
+        w[5] = frame_type | (S.sync_type << 8) | (len << 16);
+        for (int q = 0; q < 8; ++q) {
+            uint32_t v = col[q * 64 + lane];
+            const int lo = 4 * q;  // zero bytes at and beyond len
+            if (lo + 4 > (int)len) v = (lo >= (int)len) ? 0u : (v & (0xFFFFFFFFu >> (8 * (lo + 4 - (int)len))));
+            w[6 + q] = v;
+        }
+        w[14] = 0;
+        w[15] = 0;
+    } else {
+        *S.overflow = 1;
+    }
+    ++n_run;
+    ++seq;
+}
+
+// M17FrameDecoder::operator() (M17FrameDecoder.h:353-392).  Returns the new viterbi_cost (unchanged when the
+// reference leaves its by-reference argument untouched).  0xFFFFFFFF stands for size_t(-1).
+__device__ __forceinline__ uint32_t decode_frame(const DecodeTables* tb, const DecodeLds& L, int lane, uint32_t sync_type,
+                                                 DecoderRegs& D, uint32_t cost_in, const RecSink& S, uint32_t& n_run, uint32_t& seq)
+{
+    uint32_t cost = cost_in;
+    auto run_viterbi = [&](int kind) { return viterbi_decode(tb, L, lane, kind, D.stale401); };
+    switch (sync_type) {
+    case 0: {  // LSF: decode_lsf :154-178
+        D.state = 0;
+        cost = run_viterbi(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) L.lsf[q * 64 + lane] = L.outb[q * 64 + lane];
+        if (crc16_col(L.lsf, lane, 30) == 0) {
+            const uint32_t b13 = byte_at(L.lsf, lane, 13);  // update_state :113-136 on bits 109..111
+            const uint32_t bit109 = (b13 >> 2) & 1u, bit110 = (b13 >> 1) & 1u, bit111 = b13 & 1u;
+            if (bit111) { if (bit109) D.state = 1; }
+            else D.state = (((bit109 << 1) | bit110) == 1u) ? 2u : 3u;
+            emit_record(S, n_run, seq, 0 /*LSF*/, (int32_t)cost, L.lsf, lane, 30);
+        } else {
+            D.lich_segments = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) L.lsf[q * 64 + lane] = 0;
+        }
+        break;
+    }
+    case 1:  // STREAM
+        if (D.state == 0) {  // decode_lich :214-262
+            uint32_t lich[6] = {0, 0, 0, 0, 0, 0};
+            bool ok = true;
+            for (int i = 0; i < 4 && ok; ++i) {
+                uint32_t cw = 0;
+                for (int j = 0; j < 24; ++j) {
+                    const uint32_t e = tb->lich_src[i * 24 + j];
+                    int v = llr_at(L.llr, lane, (int)(e & 0x1FFu));
+                    if (e & 0x200u) v = -v;
+                    cw = (cw << 1) | (v > 0 ? 1u : 0u);
+                }
+                uint32_t dec = 0;
+                if (!golay_decode(tb, cw, dec)) { ok = false; break; }
+                dec >>= 12;
+                // unpack_lich :181-212 — i = 0: bytes 0,1hi; 1: 1lo,2; 2: 3,4hi; 3: 4lo,5
+                if (i == 0) { lich[0] |= (dec >> 4) & 0xFFu; lich[1] = (dec & 0xFu) << 4; }
+                else if (i == 1) { lich[1] |= (dec >> 8) & 0xFFu; lich[2] = dec & 0xFFu; }
+                else if (i == 2) { lich[3] |= (dec >> 4) & 0xFFu; lich[4] = (dec & 0xFu) << 4; }
+                else { lich[4] |= (dec >> 8) & 0xFFu; lich[5] = dec & 0xFFu; }
+            }
+            if (!ok) break;  // FAIL, cost untouched
+            L.outb[0 * 64 + lane] = lich[0] | (lich[1] << 8) | (lich[2] << 16) | (lich[3] << 24);
+            L.outb[1 * 64 + lane] = lich[4] | (lich[5] << 8);
+            emit_record(S, n_run, seq, 1 /*LICH*/, 0, L.outb, lane, 6);
+            const uint32_t frag = (lich[5] >> 5) & 7u;
+            if (frag > 5) { cost = 0xFFFFFFFFu; break; }
+            {  // copy 5 bytes into lsf[frag*5 ..]
+                for (int k = 0; k < 5; ++k) {
+                    const int b = (int)frag * 5 + k;
+                    uint32_t w = L.lsf[(b >> 2) * 64 + lane];
+                    w = (w & ~(0xFFu << (8 * (b & 3)))) | (lich[k] << (8 * (b & 3)));
+                    L.lsf[(b >> 2) * 64 + lane] = w;
+                }
+            }
+            D.lich_segments |= (1u << frag);
+            if ((D.lich_segments & 0x3Fu) != 0x3Fu) { cost = 0xFFFFFFFFu; break; }
+            if (crc16_col(L.lsf, lane, 30) == 0) {
+                D.lich_segments = 0;
+                D.state = 1;
+                cost = 0;
+                emit_record(S, n_run, seq, 0 /*LSF*/, 0, L.lsf, lane, 30);
+            } else {
+                cost = 128;
+            }
+        } else if (D.state == 1) {  // decode_stream :276-289
+            cost = run_viterbi(1);
+            emit_record(S, n_run, seq, 2 /*STREAM*/, (int32_t)cost, L.outb, lane, 18);
+        } else {
+            D.state = 0;
+        }
+        break;
+    case 2:  // PACKET: decode_packet :299-315
+        if (D.state == 2 || D.state == 3) {
+            cost = run_viterbi(2);
+            emit_record(S, n_run, seq, D.state == 2 ? 3u : 4u, (int32_t)cost, L.outb, lane, 26);
+            if (byte_at(L.outb, lane, 25) & 0x80u) D.state = 0;
+        } else {
+            D.state = 0;
+        }
+        break;
+    default:  // BERT: decode_bert :264-274
+        D.state = 4;
+        cost = run_viterbi(3);
+        emit_record(S, n_run, seq, 5 /*BERT*/, (int32_t)cost, L.outb, lane, 25);
+        break;
+    }
+    return cost;
+}
+
+}  // namespace m17

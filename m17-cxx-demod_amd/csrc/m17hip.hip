@@ -1,0 +1,647 @@
+// C-ABI implementation (include/m17hip.h) over the HIP kernels.  Host side: context, device slabs,
+// constant tables, launches, record compaction, per-kernel HIP-event timing.  gfx950 only.
+// Product code: no fallback path of any kind — if a HIP call fails the entry point returns M17HIP_EHIP.
+#include "../../include/m17hip.h"
+
+#include "m17_common.hpp"
+#include "m17_decode_device.hpp"
+#include "m17_frontend_kernels.hpp"
+#include "m17_seq_kernel.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace m17;
+
+namespace {
+
+enum { KT_FIR = 0, KT_DCD, KT_SEQ, KT_DEC, KT_CORR, KT_COMPACT, KT_N };
+
+struct TimedLaunch { hipEvent_t a, b; int which; };
+
+}  // namespace
+
+struct m17hip_ctx {
+    int device = 0;
+    int last_hip = 0;
+    hipStream_t stream = nullptr;
+    uint32_t maxC = 0, maxT = 0;
+    size_t xpitch = 0, ypitch = 0;
+    uint32_t ticks_cap = 0, rec_cap = 0;
+    int16_t* xbuf = nullptr;
+    float* ybuf = nullptr;
+    float* dcd_table = nullptr;
+    DcdState* dcd_state = nullptr;
+    SeqState* seq_state = nullptr;
+    FrameRec* recs = nullptr;
+    uint32_t* rec_count = nullptr;
+    uint32_t* overflow = nullptr;
+    uint64_t* rec_offsets = nullptr;  // exclusive prefix of rec_count (+ total at [C])
+    FrameRec* compact = nullptr;      // lazily sized
+    uint64_t compact_cap = 0;
+    DecodeTables* tables = nullptr;
+    float* taps = nullptr;
+    float* llr_edges = nullptr;
+    void* scratch = nullptr;          // per-operator staging (correlator outputs, viterbi io)
+    size_t scratch_bytes = 0;
+    DcdCoef coef{};
+    uint64_t pos = 0;          // samples consumed since reset
+    uint32_t lastC = 0, lastT = 0;
+    bool have_run = false;
+    bool uploaded = false;
+    bool timing = false;
+    std::vector<TimedLaunch> pending;
+    std::vector<hipEvent_t> pool;
+    double acc_ms[KT_N] = {0};
+    uint64_t acc_n[KT_N] = {0};
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                   \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) {                             \
+            (ctx)->last_hip = (int)e_;                      \
+            return M17HIP_EHIP;                             \
+        }                                                   \
+    } while (0)
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// ---- constant tables ------------------------------------------------------------------------------------------
+const uint8_t DC_SEQ[46] = {0xd6, 0xb5, 0xe2, 0x30, 0x82, 0xFF, 0x84, 0x62, 0xba, 0x4e, 0x96, 0x90, 0xd8, 0x98, 0xdd, 0x5d,
+                            0x0c, 0xc8, 0x52, 0x43, 0x91, 0x1d, 0xf8, 0x6e, 0x68, 0x2F, 0x35, 0xda, 0x14, 0xea, 0xcd, 0x76,
+                            0x19, 0x8d, 0xd5, 0x80, 0xd1, 0x33, 0x87, 0x13, 0x57, 0x18, 0x2d, 0x29, 0x78, 0xc3};  // M17 spec / M17Randomizer.h:16-22
+
+uint16_t frame_source(size_t deinterleaved_index)
+{
+    const size_t i = deinterleaved_index;
+    const size_t src = (45 * i + 92 * i * i) % 368;                       // PolynomialInterleaver.h:21-24
+    const bool neg = (DC_SEQ[src >> 3] >> (7 - (src & 7))) & 1;           // M17Randomizer.h:30-49
+    return (uint16_t)(src | (neg ? 0x200u : 0u));
+}
+
+void build_tables(DecodeTables& t)
+{
+    std::memset(&t, 0, sizeof(t));
+    // puncture matrices Trellis.h:17-40
+    std::vector<int> p1(61), p2(12, 1), p3(8, 1);
+    for (size_t i = 0, j = 2; i != 61; ++i) { if (i == j) { p1[i] = 0; j += 4; } else p1[i] = 1; }
+    p2[11] = 0;
+    p3[7] = 0;
+    struct Lay { int out, in, first; const std::vector<int>* p; };
+    const Lay lay[4] = {{488, 368, 0, &p1}, {296, 272, 96, &p2}, {420, 368, 0, &p3}, {402, 368, 0, &p2}};
+    for (int k = 0; k < 4; ++k) {
+        size_t index = 0, pindex = 0;
+        for (int i = 0; i < 488; ++i) t.src[k][i] = 0x8000;
+        int i = 0;
+        for (; i != lay[k].out && index < (size_t)lay[k].in; ++i) {     // depuncture, Util.h:169-190
+            if (!(*lay[k].p)[pindex++]) t.src[k][i] = 0x8000;
+            else t.src[k][i] = frame_source(lay[k].first + index++);
+            if (pindex == lay[k].p->size()) pindex = 0;
+        }
+        for (; i < lay[k].out; ++i) t.src[k][i] = 0x4000;               // never written (BERT position 401)
+        for (int q = 0; q < 488; ++q) t.src[4 + k][q] = (uint16_t)q;    // identity maps for already depunctured input
+    }
+    for (int i = 0; i < 96; ++i) t.lich_src[i] = frame_source(i);
+    // Golay syndrome -> error pattern (weight <= 3 over 23 bits): Golay24.h:131-177
+    auto syndrome = [](uint32_t cw) { cw &= 0xFFFFFFu; for (int i = 0; i != 12; ++i) { if (cw & 1u) cw ^= 0xC75u; cw >>= 1; } return cw; };
+    std::vector<int> seen(2048, 0);
+    auto put = [&](uint32_t v) { const uint32_t s = syndrome(v) & 0x7FF; t.golay_fix[s] = v; seen[s]++; };
+    put(0);
+    for (int i = 0; i < 23; ++i) put(1u << i);
+    for (int i = 0; i < 22; ++i) for (int j = i + 1; j < 23; ++j) put((1u << i) | (1u << j));
+    for (int i = 0; i < 21; ++i) for (int j = i + 1; j < 22; ++j) for (int k = j + 1; k < 23; ++k) put((1u << i) | (1u << j) | (1u << k));
+}
+
+void build_llr_edges(float* e)  // Util.h:63-104: edges accumulated in fp32
+{
+    const float inc = (float)(1.0 / (double)7.0f);
+    float k = (float)(-3.0 + (double)inc);
+    for (int n = 0; n < 43; ++n) { e[n] = k; k = k + inc; }
+}
+
+DcdCoef build_coef()  // SlidingDFT.h:85-95
+{
+    const std::complex<float> j{0, 1};
+    const float pi2 = (float)(M_PI * 2.0);
+    auto coeff = [&](size_t f) { const float k = float(f) / float(48000); return std::exp(-j * pi2 * k); };
+    const auto c0 = coeff(2400), c1 = coeff(3600);
+    return DcdCoef{c0.real(), c0.imag(), c1.real(), c1.imag()};
+}
+
+// ---- timing ---------------------------------------------------------------------------------------------------
+hipEvent_t get_event(m17hip_ctx* c)
+{
+    if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+struct Timed {
+    m17hip_ctx* c; int which; hipEvent_t a = nullptr, b = nullptr;
+    Timed(m17hip_ctx* ctx, int w) : c(ctx), which(w)
+    {
+        if (c->timing) { a = get_event(c); b = get_event(c); hipEventRecord(a, c->stream); }
+    }
+    ~Timed()
+    {
+        if (c->timing) { hipEventRecord(b, c->stream); c->pending.push_back({a, b, which}); }
+    }
+};
+void drain_timing(m17hip_ctx* c)
+{
+    for (auto& t : c->pending) {
+        hipEventSynchronize(t.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { c->acc_ms[t.which] += ms; c->acc_n[t.which]++; }
+        c->pool.push_back(t.a);
+        c->pool.push_back(t.b);
+    }
+    c->pending.clear();
+}
+
+int ensure_scratch(m17hip_ctx* c, size_t bytes)
+{
+    if (bytes <= c->scratch_bytes) return M17HIP_OK;
+    if (c->scratch) { hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    HIPCHK(c, hipMalloc(&c->scratch, bytes));
+    c->scratch_bytes = bytes;
+    return M17HIP_OK;
+}
+
+// ---- small device kernels owned by the host layer ----------------------------------------------------------------
+__global__ void seq_reset_kernel(SeqState* st, DcdState* ds, uint32_t C)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    // zero-initialised object + the constructors' values
+    uint32_t* w = reinterpret_cast<uint32_t*>(st + c);
+    for (size_t k = 0; k < sizeof(SeqState) / 4; ++k) w[k] = 0;
+    uint32_t* d = reinterpret_cast<uint32_t*>(ds + c);
+    for (size_t k = 0; k < sizeof(DcdState) / 4; ++k) d[k] = 0;
+    SeqScalars& s = st[c].sc;
+    s.run_pos = 148;              // the stream start is exact in ybuf (zero history)
+    kal_reset(s.ck, 0.f);         // KalmanFilter() : reset(0.)
+    kal_reset(s.kmin, 0.f);
+    kal_reset(s.kmax, 0.f);
+    s.dev_reset = 1;              // FreqDevEstimator::reset_ = true
+    s.evm_S = 1.0f;               // RunningStandardDeviation::S{1.0}
+    s.initializing = 1920;        // M17Demodulator.h:659 (per channel)
+    s.st = ST_UNLOCKED;
+}
+
+__global__ void zero_prefix_kernel(int16_t* x, size_t xpitch, float* y, size_t ypitch, uint32_t C)
+{
+    const uint32_t c = blockIdx.x;
+    for (int k = threadIdx.x; k < XPRE; k += blockDim.x) x[(size_t)c * xpitch + k] = 0;
+    for (int k = threadIdx.x; k < YPRE; k += blockDim.x) y[(size_t)c * ypitch + k] = 0.f;
+}
+
+// carry the last XPRE / YPRE samples of a run into the prefix of the next one
+__global__ void carry_tail_kernel(int16_t* x, size_t xpitch, float* y, size_t ypitch, uint32_t C, uint32_t T)
+{
+    const uint32_t c = blockIdx.x;
+    __shared__ int16_t xs[XPRE];
+    __shared__ float ys[YPRE];
+    int16_t* xr = x + (size_t)c * xpitch;
+    float* yr = y + (size_t)c * ypitch;
+    for (int k = threadIdx.x; k < XPRE; k += blockDim.x) xs[k] = xr[(size_t)T + k];   // = row[XPRE + T - XPRE + k]
+    for (int k = threadIdx.x; k < YPRE; k += blockDim.x) ys[k] = yr[(size_t)T + k];
+    __syncthreads();
+    for (int k = threadIdx.x; k < XPRE; k += blockDim.x) xr[k] = xs[k];
+    for (int k = threadIdx.x; k < YPRE; k += blockDim.x) yr[k] = ys[k];
+}
+
+__global__ void copy_rows_i16_kernel(const int16_t* src, size_t spitch, int16_t* dst, size_t dpitch, uint32_t T)
+{
+    const uint32_t c = blockIdx.y;
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (t >= T) return;
+    const int16_t* s = src + (size_t)c * spitch + t;
+    int16_t* d = dst + (size_t)c * dpitch + XPRE + t;
+    if (t + 8 <= T && (((uintptr_t)s) & 15) == 0) {
+        *reinterpret_cast<int4*>(d) = *reinterpret_cast<const int4*>(s);
+    } else {
+        for (uint32_t q = 0; q < 8 && t + q < T; ++q) d[q] = s[q];
+    }
+}
+
+// exclusive prefix sum of the per-channel record counts (single block; C <= a few 100k)
+__global__ void rec_offsets_kernel(const uint32_t* counts, uint32_t rec_cap, uint64_t* offsets, uint32_t C)
+{
+    __shared__ uint64_t partial[256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (C + 255) / 256;
+    const uint32_t lo = tid * per, hi = min(C, lo + per);
+    uint64_t sum = 0;
+    for (uint32_t c = lo; c < hi; ++c) sum += min(counts[c], rec_cap);
+    partial[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t run = 0;
+        for (int k = 0; k < 256; ++k) { const uint64_t v = partial[k]; partial[k] = run; run += v; }
+        offsets[C] = run;
+    }
+    __syncthreads();
+    uint64_t run = partial[tid];
+    for (uint32_t c = lo; c < hi; ++c) { offsets[c] = run; run += min(counts[c], rec_cap); }
+}
+
+__global__ void compact_kernel(const FrameRec* recs, uint32_t rec_cap, const uint32_t* counts, const uint64_t* offsets,
+                               FrameRec* out, uint64_t out_cap, uint32_t C)
+{
+    const uint32_t c = blockIdx.x;
+    const uint32_t n = min(counts[c], rec_cap);
+    const uint4* src = reinterpret_cast<const uint4*>(recs + (size_t)c * rec_cap);
+    uint4* dst = reinterpret_cast<uint4*>(out + offsets[c]);
+    for (uint32_t k = threadIdx.x; k < n * 4; k += blockDim.x)
+        if (offsets[c] + k / 4 < out_cap) dst[k] = src[k];
+}
+
+int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
+{
+    Timed tm(c, KT_FIR);
+    dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C);
+    hipLaunchKernelGGL(fir_rrc150_kernel, grid, dim3(FIR_THREADS), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, T, flags);
+    HIPCHK(c, hipGetLastError());
+    return M17HIP_OK;
+}
+int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
+{
+    Timed tm(c, KT_DCD);
+    hipLaunchKernelGGL(dcd_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->dcd_state, c->dcd_table,
+                       c->ticks_cap, C, T, c->pos, c->coef, flags);
+    HIPCHK(c, hipGetLastError());
+    return M17HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* m17hip_strerror(int code)
+{
+    switch (code) {
+    case M17HIP_OK: return "ok";
+    case M17HIP_EINVAL: return "invalid argument";
+    case M17HIP_EHIP: return "HIP runtime error";
+    case M17HIP_ENOMEM: return "out of memory";
+    case M17HIP_ESTATE: return "call sequence error";
+    case M17HIP_EOVERFLOW: return "frame record buffer overflow";
+    default: return "unknown error";
+    }
+}
+int m17hip_last_hip_error(const m17hip_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+int m17hip_version(void) { return 100; }
+
+int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out)
+{
+    if (!out || max_channels == 0 || max_samples == 0) return M17HIP_EINVAL;
+    m17hip_ctx* c = new (std::nothrow) m17hip_ctx();
+    if (!c) return M17HIP_ENOMEM;
+    c->device = device;
+    c->maxC = max_channels;
+    c->maxT = max_samples;
+    auto fail = [&](int code) { m17hip_ctx_destroy(c); return code; };
+    if (hipSetDevice(device) != hipSuccess) return fail(M17HIP_EHIP);
+    c->xpitch = round_up((size_t)XPRE + max_samples + 8, 8);
+    c->ypitch = round_up((size_t)YPRE + max_samples + 4, 4);
+    c->ticks_cap = max_samples / TICK + 2;
+    c->rec_cap = 2 * (max_samples / 1920 + 2) + 4;  // <= 2 callbacks per 1920-sample frame
+    const size_t C = max_channels;
+#define ALLOC(ptr, bytes)                                                            \
+    do {                                                                             \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                          \
+        if (e_ != hipSuccess) { c->last_hip = (int)e_; return fail(e_ == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP); } \
+    } while (0)
+    ALLOC(c->xbuf, C * c->xpitch * sizeof(int16_t));
+    ALLOC(c->ybuf, C * c->ypitch * sizeof(float));
+    ALLOC(c->dcd_table, C * c->ticks_cap * 12 * sizeof(float));
+    ALLOC(c->dcd_state, C * sizeof(DcdState));
+    ALLOC(c->seq_state, C * sizeof(SeqState));
+    ALLOC(c->recs, C * c->rec_cap * sizeof(FrameRec));
+    ALLOC(c->rec_count, C * sizeof(uint32_t));
+    ALLOC(c->rec_offsets, (C + 1) * sizeof(uint64_t));
+    ALLOC(c->overflow, sizeof(uint32_t));
+    ALLOC(c->tables, sizeof(DecodeTables));
+    ALLOC(c->taps, 160 * sizeof(float));
+    ALLOC(c->llr_edges, 64 * sizeof(float));
+#undef ALLOC
+    {
+        DecodeTables* t = new DecodeTables;
+        build_tables(*t);
+        hipError_t e = hipMemcpy(c->tables, t, sizeof(DecodeTables), hipMemcpyHostToDevice);
+        delete t;
+        if (e != hipSuccess) { c->last_hip = (int)e; return fail(M17HIP_EHIP); }
+        float taps[160] = {0};
+        for (int i = 0; i < NTAPS; ++i) taps[i] = rrc_tap(i);
+        float edges[64] = {0};
+        build_llr_edges(edges);
+        if (hipMemcpy(c->taps, taps, sizeof(taps), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
+        if (hipMemcpy(c->llr_edges, edges, sizeof(edges), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
+    }
+    c->coef = build_coef();
+    if (hipFuncSetAttribute((const void*)demod_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_WORDS * 4) != hipSuccess)
+        return fail(M17HIP_EHIP);
+    if (hipFuncSetAttribute((const void*)viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (122 + 122 + 16) * 64 * 4) != hipSuccess)
+        return fail(M17HIP_EHIP);
+    if (hipFuncSetAttribute((const void*)decode_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (92 + 122 + 16) * 64 * 4) != hipSuccess)
+        return fail(M17HIP_EHIP);
+    if (hipMemset(c->overflow, 0, 4) != hipSuccess) return fail(M17HIP_EHIP);
+    *out = c;
+    const int r = m17hip_demod_reset(c);
+    if (r != M17HIP_OK) { *out = nullptr; return fail(r); }
+    return M17HIP_OK;
+}
+
+void m17hip_ctx_destroy(m17hip_ctx* c)
+{
+    if (!c) return;
+    drain_timing(c);
+    for (auto e : c->pool) hipEventDestroy(e);
+    void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
+                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    delete c;
+}
+
+int m17hip_set_stream(m17hip_ctx* c, void* hip_stream)
+{
+    if (!c) return M17HIP_EINVAL;
+    c->stream = (hipStream_t)hip_stream;
+    return M17HIP_OK;
+}
+
+int m17hip_upload_i16(m17hip_ctx* c, const int16_t* host, uint32_t C, uint32_t T, size_t pitch)
+{
+    if (!c || !host || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
+    HIPCHK(c, hipMemcpy2DAsync(c->xbuf + XPRE, c->xpitch * sizeof(int16_t), host, pitch * sizeof(int16_t), (size_t)T * sizeof(int16_t), C,
+                               hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->uploaded = true;
+    c->lastC = C; c->lastT = T;
+    return M17HIP_OK;
+}
+
+int m17hip_upload_i16_device(m17hip_ctx* c, const int16_t* dev, uint32_t C, uint32_t T, size_t pitch)
+{
+    if (!c || !dev || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
+    dim3 grid(((T + 7) / 8 + 255) / 256, C);
+    hipLaunchKernelGGL(copy_rows_i16_kernel, grid, dim3(256), 0, c->stream, dev, pitch, c->xbuf, c->xpitch, T);
+    HIPCHK(c, hipGetLastError());
+    c->uploaded = true;
+    c->lastC = C; c->lastT = T;
+    return M17HIP_OK;
+}
+
+int m17hip_fir_rrc150(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* out_host)
+{
+    if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    if (!c->uploaded) return M17HIP_ESTATE;
+    int r = launch_fir(c, C, T, flags);
+    if (r) return r;
+    if (out_host) {
+        HIPCHK(c, hipMemcpy2DAsync(out_host, (size_t)T * sizeof(float), c->ybuf + YPRE, c->ypitch * sizeof(float), (size_t)T * sizeof(float), C,
+                                   hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M17HIP_OK;
+}
+
+int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, float* corr_host)
+{
+    if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    const size_t n = (size_t)C * T;
+    int r = ensure_scratch(c, 5 * n * sizeof(float));
+    if (r) return r;
+    float* limit = (float*)c->scratch;
+    float* corr = limit + n;
+    {
+        Timed tm(c, KT_CORR);
+        hipLaunchKernelGGL(correlate_kernel, dim3((T + 255) / 256, C), dim3(256), 0, c->stream, c->ybuf, c->ypitch, corr, C, T);
+        hipLaunchKernelGGL(limit_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (limit_host) HIPCHK(c, hipMemcpyAsync(limit_host, limit, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (corr_host) HIPCHK(c, hipMemcpyAsync(corr_host, corr, 4 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M17HIP_OK;
+}
+
+int m17hip_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* sums_host, uint32_t* ticks_out)
+{
+    if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    if (!c->uploaded) return M17HIP_ESTATE;
+    // operator-level call: always from a fresh DFT state at stream position 0
+    HIPCHK(c, hipMemsetAsync(c->dcd_state, 0, (size_t)C * sizeof(DcdState), c->stream));
+    const uint64_t saved = c->pos;
+    c->pos = 0;
+    int r = launch_dcd(c, C, T, flags);
+    c->pos = saved;
+    if (r) return r;
+    const uint32_t ticks = T / TICK;
+    if (ticks_out) *ticks_out = ticks;
+    if (sums_host && ticks)
+        HIPCHK(c, hipMemcpy2DAsync(sums_host, (size_t)ticks * 12 * sizeof(float), c->dcd_table, (size_t)c->ticks_cap * 12 * sizeof(float),
+                                   (size_t)ticks * 12 * sizeof(float), C, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M17HIP_OK;
+}
+
+int m17hip_viterbi(m17hip_ctx* c, const int8_t* soft_host, uint32_t n, int kind, uint8_t* bits_host, int32_t* cost_host)
+{
+    if (!c || !soft_host || n == 0 || kind < 0 || kind > 3) return M17HIP_EINVAL;
+    static const int IN[4] = {488, 296, 420, 402}, OUT[4] = {240, 144, 206, 197};
+    const size_t in_b = (size_t)n * IN[kind], out_b = (size_t)n * OUT[kind];
+    const size_t o1 = round_up(in_b, 256), o2 = o1 + round_up(out_b, 256);
+    int r = ensure_scratch(c, o2 + (size_t)n * 4);
+    if (r) return r;
+    char* base = (char*)c->scratch;
+    HIPCHK(c, hipMemcpyAsync(base, soft_host, in_b, hipMemcpyHostToDevice, c->stream));
+    {
+        Timed tm(c, KT_DEC);
+        hipLaunchKernelGGL(viterbi_kernel, dim3((n + 63) / 64), dim3(64), (122 + 122 + 16) * 64 * 4, c->stream, (const int8_t*)base, n, kind,
+                           (uint8_t*)(base + o1), (int32_t*)(base + o2), c->tables);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (bits_host) HIPCHK(c, hipMemcpyAsync(bits_host, base + o1, out_b, hipMemcpyDeviceToHost, c->stream));
+    if (cost_host) HIPCHK(c, hipMemcpyAsync(cost_host, base + o2, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M17HIP_OK;
+}
+
+int m17hip_decode_frames(m17hip_ctx* c, const int8_t* llr368_host, uint32_t n, const uint8_t* sync_type, uint8_t* state_io,
+                         uint8_t* lich_io, uint8_t* lsf_io, int8_t* dep401_io, int64_t* cost_io, m17_frame_rec* recs, uint8_t* nrec)
+{
+    if (!c || !llr368_host || !sync_type || !state_io || !lich_io || !lsf_io || !dep401_io || !cost_io || !recs || !nrec || n == 0)
+        return M17HIP_EINVAL;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += round_up(bytes, 256); return o; };
+    const size_t o_llr = take((size_t)n * 368), o_st = take(n), o_state = take(n), o_lich = take(n), o_lsf = take((size_t)n * 30),
+                 o_dep = take(n), o_cost = take((size_t)n * 8), o_rec = take((size_t)n * 2 * sizeof(FrameRec)), o_nrec = take(n);
+    int r = ensure_scratch(c, off);
+    if (r) return r;
+    char* b = (char*)c->scratch;
+    HIPCHK(c, hipMemcpyAsync(b + o_llr, llr368_host, (size_t)n * 368, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_st, sync_type, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_state, state_io, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_lich, lich_io, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_lsf, lsf_io, (size_t)n * 30, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_dep, dep401_io, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_cost, cost_io, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(b + o_rec, 0, (size_t)n * 2 * sizeof(FrameRec), c->stream));
+    DecodeFramesParams P{(const int8_t*)(b + o_llr), (const uint8_t*)(b + o_st), (uint8_t*)(b + o_state), (uint8_t*)(b + o_lich),
+                         (uint8_t*)(b + o_lsf), (int8_t*)(b + o_dep), (int64_t*)(b + o_cost), (FrameRec*)(b + o_rec),
+                         (uint8_t*)(b + o_nrec), n, c->tables, c->overflow};
+    {
+        Timed tm(c, KT_DEC);
+        hipLaunchKernelGGL(decode_frames_kernel, dim3((n + 63) / 64), dim3(64), (92 + 122 + 16) * 64 * 4, c->stream, P);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(state_io, b + o_state, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(lich_io, b + o_lich, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(lsf_io, b + o_lsf, (size_t)n * 30, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dep401_io, b + o_dep, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cost_io, b + o_cost, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(recs, b + o_rec, (size_t)n * 2 * sizeof(FrameRec), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nrec, b + o_nrec, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M17HIP_OK;
+}
+
+int m17hip_demod_reset(m17hip_ctx* c)
+{
+    if (!c) return M17HIP_EINVAL;
+    hipLaunchKernelGGL(seq_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->dcd_state, c->maxC);
+    hipLaunchKernelGGL(zero_prefix_kernel, dim3(c->maxC), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, c->maxC);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemsetAsync(c->rec_count, 0, (size_t)c->maxC * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->overflow, 0, 4, c->stream));
+    c->pos = 0;
+    c->have_run = false;
+    return M17HIP_OK;
+}
+
+int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
+{
+    if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    if (!c->uploaded) return M17HIP_ESTATE;
+    if (c->have_run && C != c->lastC) return M17HIP_EINVAL;  // a continued stream keeps its channel count
+    int r;
+    if ((r = launch_fir(c, C, T, flags))) return r;
+    if ((r = launch_dcd(c, C, T, flags))) return r;
+    {
+        Timed tm(c, KT_SEQ);
+        SeqParams P{};
+        P.x = c->xbuf; P.xpitch = c->xpitch; P.y = c->ybuf; P.ypitch = c->ypitch;
+        P.dcd_table = c->dcd_table; P.ticks_cap = c->ticks_cap; P.state = c->seq_state;
+        P.recs = c->recs; P.rec_cap = c->rec_cap; P.rec_count = c->rec_count; P.overflow = c->overflow;
+        P.tables = c->tables; P.taps = c->taps; P.llr_edges = c->llr_edges;
+        P.C = C; P.T = T; P.pos0 = c->pos; P.flags = flags;
+        hipLaunchKernelGGL(demod_seq_kernel, dim3((C + 63) / 64), dim3(64), SEQ_LDS_WORDS * 4, c->stream, P);
+    }
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
+    HIPCHK(c, hipGetLastError());
+    c->pos += T;
+    c->lastC = C; c->lastT = T;
+    c->have_run = true;
+    return M17HIP_OK;
+}
+
+static int compact_into(m17hip_ctx* c, FrameRec* dev_out, uint64_t cap, uint64_t* count)
+{
+    const uint32_t C = c->lastC;
+    {
+        Timed tm(c, KT_COMPACT);
+        hipLaunchKernelGGL(rec_offsets_kernel, dim3(1), dim3(256), 0, c->stream, c->rec_count, c->rec_cap, c->rec_offsets, C);
+        if (dev_out)
+            hipLaunchKernelGGL(compact_kernel, dim3(C), dim3(64), 0, c->stream, c->recs, c->rec_cap, c->rec_count, c->rec_offsets, dev_out, cap, C);
+    }
+    HIPCHK(c, hipGetLastError());
+    uint64_t total = 0;
+    uint32_t ovf = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, c->rec_offsets + C, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&ovf, c->overflow, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (count) *count = total;
+    if (ovf) return M17HIP_EOVERFLOW;
+    return M17HIP_OK;
+}
+
+int m17hip_frames_count(m17hip_ctx* c, uint64_t* total)
+{
+    if (!c || !total) return M17HIP_EINVAL;
+    if (!c->have_run) return M17HIP_ESTATE;
+    return compact_into(c, nullptr, 0, total);
+}
+
+int m17hip_frames_compact_device(m17hip_ctx* c, m17_frame_rec* recs_dev, uint64_t capacity, uint64_t* count)
+{
+    if (!c || !recs_dev) return M17HIP_EINVAL;
+    if (!c->have_run) return M17HIP_ESTATE;
+    return compact_into(c, (FrameRec*)recs_dev, capacity, count);
+}
+
+int m17hip_frames_fetch(m17hip_ctx* c, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* count)
+{
+    if (!c || !recs_host) return M17HIP_EINVAL;
+    if (!c->have_run) return M17HIP_ESTATE;
+    uint64_t total = 0;
+    int r = compact_into(c, nullptr, 0, &total);
+    if (r && r != M17HIP_EOVERFLOW) return r;
+    if (total > c->compact_cap) {
+        if (c->compact) hipFree(c->compact);
+        c->compact = nullptr; c->compact_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->compact, (size_t)std::max<uint64_t>(total, 1024) * sizeof(FrameRec)));
+        c->compact_cap = std::max<uint64_t>(total, 1024);
+    }
+    int r2 = total ? compact_into(c, c->compact, c->compact_cap, &total) : M17HIP_OK;
+    if (r2 && r2 != M17HIP_EOVERFLOW) return r2;
+    const uint64_t n = std::min(total, capacity);
+    if (n) HIPCHK(c, hipMemcpy(recs_host, c->compact, (size_t)n * sizeof(FrameRec), hipMemcpyDeviceToHost));
+    if (count) *count = total;
+    return r ? r : r2;
+}
+
+int m17hip_diag_fetch(m17hip_ctx* c, m17_diag* diag_host, uint32_t C)
+{
+    if (!c || !diag_host || C == 0 || C > c->maxC) return M17HIP_EINVAL;
+    HIPCHK(c, hipMemcpy2DAsync(diag_host, sizeof(Diag), &c->seq_state[0].sc.diag, sizeof(SeqState), sizeof(Diag), C, hipMemcpyDeviceToHost,
+                               c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M17HIP_OK;
+}
+
+int m17hip_timing_enable(m17hip_ctx* c, int on)
+{
+    if (!c) return M17HIP_EINVAL;
+    drain_timing(c);
+    c->timing = on != 0;
+    return M17HIP_OK;
+}
+int m17hip_timing_get(m17hip_ctx* c, int which, double* total_ms, uint64_t* launches)
+{
+    if (!c || which < 0 || which >= KT_N) return M17HIP_EINVAL;
+    drain_timing(c);
+    if (total_ms) *total_ms = c->acc_ms[which];
+    if (launches) *launches = c->acc_n[which];
+    return M17HIP_OK;
+}
+int m17hip_timing_reset(m17hip_ctx* c)
+{
+    if (!c) return M17HIP_EINVAL;
+    drain_timing(c);
+    for (int k = 0; k < KT_N; ++k) { c->acc_ms[k] = 0; c->acc_n[k] = 0; }
+    return M17HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+"""Python (ctypes) binding of the C ABI in include/m17hip.h — the MI355X-native M17 demodulation hot path.
+
+This is plumbing over `libm17hip.so` (hand-written HIP kernels for gfx950): no CPU fallback exists and
+none is attempted — if the library is missing or a HIP call fails, a `M17HipError` is raised.
+Nothing here imports the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libm17hip.so")
+
+FRAME_REC = np.dtype(
+    [("channel", "<u4"), ("seq", "<u4"), ("sample_pos", "<u8"), ("cost", "<i4"), ("frame_type", "u1"), ("sync_type", "u1"),
+     ("len", "u1"), ("flags", "u1"), ("payload", "u1", (32,)), ("pad", "u1", (8,))]
+)
+DIAG = np.dtype(
+    [("dcd", "<i4"), ("evm", "<f4"), ("deviation", "<f4"), ("offset", "<f4"), ("locked", "<i4"), ("clock", "<f4"),
+     ("sample_index", "<i4"), ("sync_index", "<i4"), ("clock_index", "<i4"), ("viterbi_cost", "<i4"), ("dcd_level", "<f4"),
+     ("n_diag", "<u4"), ("demod_state", "<u4"), ("n_frames", "<u4"), ("pad", "<u4", (2,))]
+)
+assert FRAME_REC.itemsize == 64 and DIAG.itemsize == 64
+
+FLAG_INVERT = 1
+KERNELS = {"fir_rrc150": 0, "dcd": 1, "demod_seq": 2, "decode": 3, "correlator": 4, "compact": 5}
+VITERBI_SHAPES = {0: (488, 240), 1: (296, 144), 2: (420, 206), 3: (402, 197)}
+
+EXPORTS = [
+    "m17hip_strerror", "m17hip_last_hip_error", "m17hip_version", "m17hip_ctx_create", "m17hip_ctx_destroy", "m17hip_set_stream",
+    "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_dcd", "m17hip_viterbi",
+    "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
+    "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
+]
+
+
+class M17HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Load libm17hip.so (built by `__graft_entry__.build()` / csrc/Makefile).  Raises if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise M17HipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                              "there is no CPU fallback for the demodulation hot path")
+        lib = C.CDLL(LIB_PATH)
+        lib.m17hip_strerror.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One demodulation context = `channels` independent 48 kSPS channels on one GPU (include/m17hip.h)."""
+
+    def __init__(self, max_channels, max_samples, device=0, stream=None):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        self.max_channels, self.max_samples = int(max_channels), int(max_samples)
+        self._chk(self.lib.m17hip_ctx_create(C.c_int(device), C.c_uint32(max_channels), C.c_uint32(max_samples), C.byref(self.h)))
+        if stream is not None:
+            self.set_stream(stream)
+
+    def _chk(self, code):
+        if code != 0:
+            hip = self.lib.m17hip_last_hip_error(self.h) if self.h else 0
+            raise M17HipError(f"m17hip error {code}: {self.lib.m17hip_strerror(C.c_int(code)).decode()} (hip error {hip})")
+
+    def close(self):
+        if self.h:
+            self.lib.m17hip_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        self._chk(self.lib.m17hip_set_stream(self.h, C.c_void_p(int(stream_handle))))
+
+    # ---- input -------------------------------------------------------------------------------------------------
+    def upload(self, samples):
+        s = np.ascontiguousarray(samples, dtype=np.int16)
+        if s.ndim == 1:
+            s = s[None, :]
+        self.C, self.T = s.shape
+        self._chk(self.lib.m17hip_upload_i16(self.h, _ptr(s), C.c_uint32(self.C), C.c_uint32(self.T), C.c_size_t(self.T)))
+
+    def upload_device(self, dev_ptr, channels, samples, pitch=None):
+        self.C, self.T = int(channels), int(samples)
+        self._chk(self.lib.m17hip_upload_i16_device(self.h, C.c_void_p(int(dev_ptr)), C.c_uint32(self.C), C.c_uint32(self.T),
+                                                    C.c_size_t(self.T if pitch is None else pitch)))
+
+    # ---- per-operator entry points --------------------------------------------------------------------------------
+    def fir(self, flags=0, fetch=True):
+        out = np.empty((self.C, self.T), dtype=np.float32) if fetch else None
+        self._chk(self.lib.m17hip_fir_rrc150(self.h, C.c_uint32(self.C), C.c_uint32(self.T), C.c_uint32(flags), _ptr(out)))
+        return out
+
+    def correlator(self):
+        limit = np.empty((self.C, self.T), dtype=np.float32)
+        corr = np.empty((4, self.C, self.T), dtype=np.float32)
+        self._chk(self.lib.m17hip_correlator(self.h, C.c_uint32(self.C), C.c_uint32(self.T), _ptr(limit), _ptr(corr)))
+        return limit, corr
+
+    def dcd(self, flags=0):
+        ticks = self.T // 192
+        sums = np.empty((self.C, ticks, 6, 2), dtype=np.float32)
+        n = C.c_uint32(0)
+        self._chk(self.lib.m17hip_dcd(self.h, C.c_uint32(self.C), C.c_uint32(self.T), C.c_uint32(flags), _ptr(sums), C.byref(n)))
+        assert n.value == ticks
+        return sums
+
+    def viterbi(self, soft, kind):
+        IN, OUT = VITERBI_SHAPES[kind]
+        s = np.ascontiguousarray(soft, dtype=np.int8).reshape(-1, IN)
+        n = s.shape[0]
+        bits = np.empty((n, OUT), dtype=np.uint8)
+        cost = np.empty(n, dtype=np.int32)
+        self._chk(self.lib.m17hip_viterbi(self.h, _ptr(s), C.c_uint32(n), C.c_int(kind), _ptr(bits), _ptr(cost)))
+        return bits, cost
+
+    def decode_frames(self, llr368, sync_type, state=None, lich=None, lsf=None, dep401=None, cost=None):
+        l = np.ascontiguousarray(llr368, dtype=np.int8).reshape(-1, 368)
+        n = l.shape[0]
+        st = np.ascontiguousarray(sync_type, dtype=np.uint8)
+        state = np.zeros(n, np.uint8) if state is None else np.ascontiguousarray(state, dtype=np.uint8).copy()
+        lich = np.zeros(n, np.uint8) if lich is None else np.ascontiguousarray(lich, dtype=np.uint8).copy()
+        lsf = np.zeros((n, 30), np.uint8) if lsf is None else np.ascontiguousarray(lsf, dtype=np.uint8).copy()
+        dep401 = np.zeros(n, np.int8) if dep401 is None else np.ascontiguousarray(dep401, dtype=np.int8).copy()
+        cost = np.zeros(n, np.int64) if cost is None else np.ascontiguousarray(cost, dtype=np.int64).copy()
+        recs = np.zeros((n, 2), dtype=FRAME_REC)
+        nrec = np.zeros(n, dtype=np.uint8)
+        self._chk(self.lib.m17hip_decode_frames(self.h, _ptr(l), C.c_uint32(n), _ptr(st), _ptr(state), _ptr(lich), _ptr(lsf), _ptr(dep401),
+                                                _ptr(cost), _ptr(recs), _ptr(nrec)))
+        return recs, nrec, state, lich, lsf, dep401, cost
+
+    # ---- the full chain ----------------------------------------------------------------------------------------------
+    def reset(self):
+        self._chk(self.lib.m17hip_demod_reset(self.h))
+
+    def run(self, flags=0, channels=None, samples=None):
+        self._chk(self.lib.m17hip_demod_run(self.h, C.c_uint32(channels or self.C), C.c_uint32(samples or self.T), C.c_uint32(flags)))
+
+    def frames_count(self):
+        n = C.c_uint64(0)
+        self._chk(self.lib.m17hip_frames_count(self.h, C.byref(n)))
+        return n.value
+
+    def frames(self):
+        n = self.frames_count()
+        recs = np.zeros(max(n, 1), dtype=FRAME_REC)
+        got = C.c_uint64(0)
+        self._chk(self.lib.m17hip_frames_fetch(self.h, _ptr(recs), C.c_uint64(recs.size), C.byref(got)))
+        return recs[: got.value]
+
+    def frames_compact_device(self, dev_ptr, capacity):
+        n = C.c_uint64(0)
+        self._chk(self.lib.m17hip_frames_compact_device(self.h, C.c_void_p(int(dev_ptr)), C.c_uint64(capacity), C.byref(n)))
+        return n.value
+
+    def diag(self, channels=None):
+        n = channels or self.C
+        d = np.zeros(n, dtype=DIAG)
+        self._chk(self.lib.m17hip_diag_fetch(self.h, _ptr(d), C.c_uint32(n)))
+        return d
+
+    # ---- measurement ---------------------------------------------------------------------------------------------------
+    def timing(self, on=True):
+        self._chk(self.lib.m17hip_timing_enable(self.h, C.c_int(1 if on else 0)))
+
+    def timing_reset(self):
+        self._chk(self.lib.m17hip_timing_reset(self.h))
+
+    def timing_get(self, kernel):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self._chk(self.lib.m17hip_timing_get(self.h, C.c_int(KERNELS[kernel]), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,244 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the CPU
+oracle on identical seeded inputs.  Integer / decision outputs must be bit-exact; the float operator outputs
+are compared bit-exact as well (the north star allows 1e-5 relative — we assert the stronger property and
+report the looser one only if it ever fails)."""
+import numpy as np
+import pytest
+
+import m17hip
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _signals(C, T, seed=77, sigma=500.0, kind=-1, lead_in=3072):
+    p = ol.gen_params(seed=seed, kind=kind, n_frames=max(1, T // 1920 - 4), lead_in=lead_in, noise_sigma=sigma, tail_sigma=sigma,
+                      lead_sigma=40000.0, total=T)
+    return ol.generate_batch(p, C, T, threads=8)
+
+
+def _oracle_records(x, invert=0):
+    recs, counts, diags = ol.demod_batch(x, invert=invert, cap=2 * (x.shape[1] // 1920 + 2) + 4, threads=8)
+    flat = np.concatenate([recs[c, : counts[c]] for c in range(x.shape[0])]) if counts.sum() else recs[0, :0]
+    return flat, counts, diags
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = m17hip.Context(256, 96000)
+    yield c
+    c.close()
+
+
+def test_scale_exhaustive(ctx):
+    """All 65536 int16 values through K1's scaling: a FIR whose window holds one sample isolates tap*x."""
+    s = np.arange(-32768, 32768, dtype=np.int32).astype(np.int16)
+    # place each value alone, 200 samples apart -> y at the value's position = x * taps[0] (+0 terms)
+    x = np.zeros((16, 4096 * 200), dtype=np.int16)
+    x = x[:, :96000]
+    vals = s.reshape(16, 4096)[:, :480]
+    x[:, ::200] = vals
+    ctx.upload(x)
+    y = ctx.fir()
+    exp = np.stack([ol.fir_i16(x[c]) for c in range(16)])
+    assert np.array_equal(y, exp)
+    yi = ctx.fir(flags=m17hip.FLAG_INVERT)
+    expi = np.stack([ol.fir_i16(x[c], invert=1) for c in range(16)])
+    assert np.array_equal(yi, expi)
+    # and every one of the 65536 values: K3 scales x[n] and x[n-120] itself -> compare the DFT sums on a ramp
+    ramp = np.tile(s, 2)[:96000][None, :].repeat(2, axis=0)
+    ramp[1] = ramp[1][::-1]
+    ctx.upload(ramp)
+    sums = ctx.dcd()
+    for c in range(2):
+        xs = ol.scale(ramp[c])
+        for k in (0, 11, 100, 499):
+            a = ol.dcd_sums(xs, 192 * k, 192)
+            assert (float(sums[c, k, k % 5, 0]), float(sums[c, k, k % 5, 1])) == (float(a[0]), float(a[1]))
+
+
+def test_fir_bit_exact_and_ragged(ctx):
+    x = _signals(24, 40000, seed=5)
+    for T in (40000, 3841, 3839, 150, 149, 1):
+        ctx.upload(x[:, :T])
+        y = ctx.fir()
+        exp = np.stack([ol.fir_i16(x[c, :T]) for c in range(x.shape[0])])
+        assert np.array_equal(y, exp), T
+    rel = 0.0  # documented tolerance of the north star (1e-5 relative) is implied by bit equality
+
+
+def test_correlator_bit_exact(ctx):
+    x = _signals(12, 30000, seed=6, sigma=800.0)
+    ctx.upload(x)
+    y = ctx.fir()
+    limit, corr = ctx.correlator()
+    for c in range(x.shape[0]):
+        l, k = ol.correlator(y[c])
+        assert np.array_equal(limit[c], l), c
+        assert np.array_equal(corr[:, c, :], k), c
+
+
+def test_iir_denormal_decay(ctx):
+    """The limit IIR must not flush denormals: a burst followed by exact zeros decays through the subnormal range."""
+    x = np.zeros((2, 90000), dtype=np.int16)
+    x[:, :300] = 20000
+    ctx.upload(x)
+    y = ctx.fir()
+    limit, _ = ctx.correlator()
+    l, _ = ol.correlator(y[0])
+    assert np.array_equal(limit[0], l)
+    assert (np.abs(l[l != 0]) < 1.2e-38).any(), "test input never reached the subnormal range"
+
+
+def test_dcd_table_bit_exact(ctx):
+    x = _signals(6, 24000, seed=9, sigma=300.0)
+    ctx.upload(x)
+    sums = ctx.dcd()
+    rng = np.random.default_rng(0)
+    for c in range(x.shape[0]):
+        xs = ol.scale(x[c])
+        # first update point of the reference: samples [0, 2304)
+        a = ol.dcd_sums(xs, 0, 2304)
+        assert (float(sums[c, 11, 5, 0]), float(sums[c, 11, 5, 1])) == (float(a[0]), float(a[1]))
+        for _ in range(12):
+            k = int(rng.integers(12, sums.shape[1]))
+            span = int(rng.choice([2, 5, 1, 3]))
+            a0 = k - span + 1
+            e = ol.dcd_sums(xs, 192 * a0, 192 * span)
+            assert (float(sums[c, k, a0 % 5, 0]), float(sums[c, k, a0 % 5, 1])) == (float(e[0]), float(e[1])), (c, k, span)
+
+
+def test_viterbi_bit_exact(ctx, golden):
+    rng = np.random.default_rng(4)
+    for kind, (IN, OUT) in m17hip.VITERBI_SHAPES.items():
+        soft = rng.integers(-7, 8, (200, IN)).astype(np.int8)
+        # half of them: valid codewords with a few errors, punctured positions erased
+        for i in range(0, 200, 2):
+            bits = rng.integers(0, 2, OUT).astype(np.uint8)
+            enc = ol.conv_encode(bits).astype(np.int16) * 2 - 1
+            s = enc * rng.integers(1, 8, IN)
+            s = np.where(rng.random(IN) < 0.04, -s, s)
+            s[rng.random(IN) < 0.1] = 0
+            soft[i] = s.astype(np.int8)
+        bits, cost = ctx.viterbi(soft, kind)
+        for i in range(200):
+            c, out = ol.viterbi(soft[i], OUT)
+            assert c == cost[i] and np.array_equal(out, bits[i]), (kind, i)
+    # the reference's own LSF known-answer vector (tests/ViterbiTest.cpp:173-195)
+    exp = np.array(golden["kat"]["lsf_expected240"], dtype=np.uint8)
+    enc = np.array(golden["kat"]["lsf_encoded488"], dtype=np.int16)
+    enc[11] = 1
+    bits, cost = ctx.viterbi((enc * 14 - 7).astype(np.int8)[None, :], 0)
+    assert cost[0] == 0 and np.array_equal(bits[0], exp)
+
+
+def test_decode_frames_golden_sequences(ctx, golden):
+    """The frame decoder (K4') against the sequences recorded from the reference's own M17FrameDecoder."""
+    state = {}
+    for e in golden["kat"]["frame_decoder_sequences"]:
+        st = state.get(e["seed"], (0, 0, np.zeros(30, np.uint8), 0, 0))
+        recs, nrec, s, li, lsf, d401, cost = ctx.decode_frames(np.array(e["llr"], np.int8), [e["st"]], [st[0]], [st[1]], st[2][None, :],
+                                                               [st[3]], [st[4]])
+        state[e["seed"]] = (int(s[0]), int(li[0]), lsf[0], int(d401[0]), int(cost[0]))
+        assert (int(s[0]), int(li[0]), lsf[0].tolist(), int(d401[0]), int(cost[0])) == (e["state"], e["lich"], e["lsf"], e["d401"], e["cost"])
+        got = [(int(r["frame_type"]), int(r["cost"]), int(r["len"]), bytes(r["payload"]).hex()) for r in recs[0, : nrec[0]]]
+        assert got == [tuple(v) for v in e["recs"]]
+
+
+def test_decode_frames_random_walk_batch(ctx):
+    rng = np.random.default_rng(23)
+    frames = []
+    for kind in (0, 1, 2):
+        fb, st = ol.make_frames(kind, 300 + kind, 6)
+        frames += [(int(t), b) for t, b in zip(st, fb)]
+    n = 192
+    so = [(0, 0, np.zeros(30, np.uint8), 0, 0) for _ in range(n)]
+    for step in range(12):
+        llr = np.zeros((n, 368), np.int8); sts = np.zeros(n, np.uint8)
+        for i in range(n):
+            t, b = frames[rng.integers(len(frames))]
+            if rng.random() < 0.15:
+                t = int(rng.integers(0, 4))
+            fr = (b.astype(np.int16) * 2 - 1) * rng.integers(1, 8, 368)
+            llr[i] = np.where(rng.random(368) < rng.choice([0.0, 0.03, 0.3]), -fr, fr).astype(np.int8)
+            sts[i] = t
+        recs, nrec, s, li, lsf, d401, cost = ctx.decode_frames(llr, sts, [v[0] for v in so], [v[1] for v in so], np.stack([v[2] for v in so]),
+                                                               [v[3] for v in so], [v[4] for v in so])
+        for i in range(n):
+            ro = ol.decode_frame(int(sts[i]), llr[i], *so[i])
+            so[i] = ro[1:]
+            assert (ro[1], ro[2], ro[3].tolist(), ro[4], ro[5]) == (int(s[i]), int(li[i]), lsf[i].tolist(), int(d401[i]), int(cost[i])), (step, i)
+            a = ro[0].copy(); b = recs[i, : nrec[i]].copy()
+            a["channel"] = 0; b["channel"] = 0; a["seq"] = 0; b["seq"] = 0
+            assert a.tobytes() == b.tobytes(), (step, i)
+
+
+@pytest.mark.parametrize("seed,sigma,kind,invert", [(1, 0.0, 0, 0), (2, 400.0, -1, 0), (3, 1500.0, -1, 0), (4, 2500.0, 1, 1), (5, 800.0, 2, 0)])
+def test_full_chain_bit_exact(ctx, seed, sigma, kind, invert):
+    C, T = 64, 48000
+    x = _signals(C, T, seed=seed, sigma=sigma, kind=kind)
+    ctx.upload(x)
+    ctx.reset()
+    ctx.run(flags=invert)
+    got = ctx.frames()
+    exp, counts, diags = _oracle_records(x, invert=invert)
+    assert got.size == exp.size
+    assert got.tobytes() == exp.tobytes()
+    d = ctx.diag()
+    for f in ("dcd", "locked", "sample_index", "sync_index", "clock_index", "viterbi_cost", "n_diag", "demod_state", "n_frames"):
+        assert np.array_equal(d[f], diags[f]), f
+    for f in ("evm", "deviation", "offset", "clock", "dcd_level"):
+        assert np.array_equal(d[f], diags[f], equal_nan=True), f
+    if sigma <= 800:
+        assert got.size > C  # the test does decode frames
+
+
+def test_full_chain_clean_bert_anchor(ctx):
+    """a clean BERT burst decodes to the PRBS9 payloads with cost 0 — on the GPU."""
+    s, truth = ol.generate(ol.gen_params(seed=1, kind=0, n_frames=6, phase=0), with_truth=True)
+    ctx.upload(np.stack([s, s]))
+    ctx.reset()
+    ctx.run()
+    recs = ctx.frames()
+    assert recs.size == 12
+    for i, r in enumerate(recs[:6]):
+        assert r["frame_type"] == 5 and r["cost"] == 0 and bytes(r["payload"][:25]) == bytes(truth["payloads"][i][:25])
+    assert bytes(recs[0]["payload"][:25]).hex() == "08c272ac37a6e450ad3f6496fc9a9980c651a5fd163acb3c78"
+
+
+def test_full_chain_streaming_chunks_equal_one_shot(ctx):
+    """Runs continue from the carried state: 5 chunks of 9600 == one run of 48000 (and == the oracle)."""
+    C, T = 64, 48000
+    x = _signals(C, T, seed=12, sigma=600.0)
+    exp, counts, _ = _oracle_records(x)
+    ctx.reset()
+    parts = []
+    for k in range(5):
+        ctx.upload(x[:, 9600 * k: 9600 * (k + 1)])
+        ctx.run()
+        parts.append(ctx.frames().copy())
+    got = np.concatenate(parts)
+    order = np.lexsort((got["seq"], got["channel"]))
+    assert got[order].tobytes() == exp.tobytes()
+
+
+def test_edge_cases(ctx):
+    # silence with +-1 dither, pure loud noise, DC, a stream cut in the middle of a frame, an all-zero window (NaN poisoning, Q1)
+    T = 20000
+    rng = np.random.default_rng(8)
+    x = np.zeros((6, T), dtype=np.int16)
+    x[0] = rng.choice([-1, 1], T)
+    x[1] = np.clip(rng.normal(0, 20000, T), -32768, 32767).astype(np.int16)
+    x[2] = 12000
+    sig = ol.generate(ol.gen_params(seed=3, kind=0, n_frames=12, lead_in=3072, noise_sigma=300, lead_sigma=40000.0))
+    x[3, :] = sig[:T]
+    x[4, 5000:] = sig[: T - 5000]                     # exact zeros for 5000 samples first: DCD level becomes NaN forever
+    x[5] = -32768
+    ctx.upload(x)
+    ctx.reset()
+    ctx.run()
+    got = ctx.frames()
+    exp, counts, diags = _oracle_records(x)
+    assert got.tobytes() == exp.tobytes()
+    d = ctx.diag()
+    assert np.array_equal(d["dcd_level"], diags["dcd_level"], equal_nan=True) and np.isnan(d["dcd_level"][4])
