@@ -94,13 +94,16 @@ int m17hip_fir_rrc150(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint
 int m17hip_correlator(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, float* limit_host, float* corr_host);
 /* K3: NSlidingDFT<float,48000,120,2> + DataCarrierDetect accumulation (SlidingDFT.h:118-132,
  * DataCarrierDetect.h:53-58) over the uploaded slab.  For every 192-sample tick k the table holds the
- * sequential sums of norm(X0), norm(X1) for segments that started 1..5 ticks ago (index a%5, a = start
- * tick) and since the stream start (index 5): sums[C][ticks][6][2]. */
+ * sequential sums of norm(X0) (bin 0) and norm(X1) (bin 1) for segments that started 1..5 ticks ago (index a%5,
+ * a = start tick) and since the stream start (index 5): sums[C][ticks][2][6]. */
 int m17hip_dcd(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint32_t flags, float* sums_host, uint32_t* ticks_out);
 /* K4: Viterbi<Trellis<4,2>,4>::decode (Viterbi.h:162-239) on n depunctured soft-bit frames.
  * kind: 0 = LSF 488->240, 1 = stream 296->144, 2 = packet 420->206, 3 = BERT 402->197.
  * soft: [n][IN] int8 (0 = erasure); bits: [n][OUT] uint8; cost: [n]. */
 int m17hip_viterbi(m17hip_ctx* ctx, const int8_t* soft_host, uint32_t n_frames, int kind, uint8_t* bits_host, int32_t* cost_host);
+/* a11/a12: llr<float,4> (Util.h:63-104,128-145) and SymbolEvm::update (SymbolEvm.h:31-51, after reset()) on `rows`
+ * independent sequences of n normalised symbols.  llr: [rows][n][2] int8; evm: [rows][n] running evm(). */
+int m17hip_slice_llr(m17hip_ctx* ctx, const float* sym_host, uint32_t rows, uint32_t n, int8_t* llr_host, float* evm_host);
 /* K4': M17FrameDecoder::operator() (M17FrameDecoder.h:353-392: derandomize, deinterleave, depuncture,
  * Viterbi / Golay, CRC, frame-type state machine) on n independent 368-LLR frames, each with its own decoder
  * state in/out.  sync_type[n]; state_io[n] (State enum), lich_io[n], lsf_io[n][30], dep401_io[n], cost_io[n];
@@ -123,6 +126,15 @@ int m17hip_frames_fetch(m17hip_ctx* ctx, m17_frame_rec* recs_host, uint64_t capa
 int m17hip_frames_compact_device(m17hip_ctx* ctx, m17_frame_rec* recs_dev, uint64_t capacity, uint64_t* count);
 /* Per-channel diagnostics after the last run: diag_host[C]. */
 int m17hip_diag_fetch(m17hip_ctx* ctx, m17_diag* diag_host, uint32_t channels);
+
+/* Tuning knobs (performance only, never results).  key 0: waves (= channels) per workgroup of the sequential kernel
+ * (0 = default 4; 1, 2, 4, 8).  key 1: per-channel tick counters of that kernel on/off (m17hip_debug_counters). */
+int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
+
+/* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][8] =
+ * {total, bulk chunks, single-sample steps, frame decodes} in 10 ns ticks, {#chunks, #single steps, samples in chunks,
+ * #chunks cut by a clock move | #decodes << 32}. */
+int m17hip_debug_counters(m17hip_ctx* ctx, uint64_t* host, uint32_t max_waves, uint32_t* waves);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */
 /* When enabled, every kernel launch of the context is bracketed by HIP events on the context's stream. */

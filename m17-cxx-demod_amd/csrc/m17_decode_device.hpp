@@ -28,34 +28,38 @@ struct DecodeTables {
 __device__ __constant__ const int DEC_IN[4] = {488, 296, 420, 402};
 __device__ __constant__ const int DEC_OUT[4] = {240, 144, 206, 197};
 
-// LDS columns: element k of lane l lives at base[k * 64 + l]
+// LDS columns: element k of lane l lives at base[k * stride + l]
 struct DecodeLds {
     uint32_t* llr;    // [92][64]   368 int8 LLRs packed little-endian
     uint32_t* hist;   // [122][64]  16 decision bits per step, two steps per word
     uint32_t* outb;   // [8][64]    decoded bytes (<= 30), little-endian packed
     uint32_t* lsf;    // [8][64]    M17FrameDecoder::output_buffer.lsf (persistent across frames)
+    const uint16_t* src;       // [kinds][488] soft-bit source maps (LDS copy in K5, global in the stand-alone kernels)
+    const uint16_t* lich_src;  // [96]
+    int stride;                // lanes per column (= active lanes of the wave)
+    int32_t* soft;             // [488] depunctured soft bits (wave-cooperative decoder only)
 };
 
-__device__ __forceinline__ int llr_at(const uint32_t* llr, int lane, int idx)
+__device__ __forceinline__ int llr_at(const uint32_t* llr, int stride, int lane, int idx)
 {
-    const uint32_t w = llr[(idx >> 2) * 64 + lane];
+    const uint32_t w = llr[(idx >> 2) * stride + lane];
     return (int)(int8_t)(w >> (8 * (idx & 3)));
 }
-__device__ __forceinline__ int soft_at(const DecodeTables* tb, const uint32_t* llr, int lane, int kind, int i, int stale)
+__device__ __forceinline__ int soft_at(const uint16_t* src, const uint32_t* llr, int stride, int lane, int kind, int i, int stale)
 {
-    const uint32_t e = tb->src[kind][i];
+    const uint32_t e = src[kind * 488 + i];
     if (e & 0x8000u) return 0;
     if (e & 0x4000u) return stale;
-    const int v = llr_at(llr, lane, (int)(e & 0x1FFu));
+    const int v = llr_at(llr, stride, lane, (int)(e & 0x1FFu));
     return (e & 0x200u) ? -v : v;
 }
-__device__ __forceinline__ uint32_t byte_at(const uint32_t* col, int lane, int b)
+__device__ __forceinline__ uint32_t byte_at(const uint32_t* col, int stride, int lane, int b)
 {
-    return (col[(b >> 2) * 64 + lane] >> (8 * (b & 3))) & 0xFFu;
+    return (col[(b >> 2) * stride + lane] >> (8 * (b & 3))) & 0xFFu;
 }
 
 // CRC16<0x5935,0xFFFF> over n bytes of an LDS column (CRC16.h:12-70).
-__device__ __forceinline__ uint32_t crc16_col(const uint32_t* col, int lane, int n)
+__device__ __forceinline__ uint32_t crc16_col(const uint32_t* col, int stride, int lane, int n)
 {
     uint32_t reg = 0xFFFFu;
     for (int i = 0; i != 16; ++i) {  // reset()
@@ -65,7 +69,7 @@ __device__ __forceinline__ uint32_t crc16_col(const uint32_t* col, int lane, int
         if (bit) reg |= 0x8000u;
     }
     for (int k = 0; k < n; ++k) {
-        const uint32_t byte = byte_at(col, lane, k);
+        const uint32_t byte = byte_at(col, stride, lane, k);
         for (int i = 0; i != 8; ++i) {
             const uint32_t msb = reg & 0x8000u;
             reg = ((reg << 1) & 0xFFFFu) | ((byte >> (7 - i)) & 1u);
@@ -111,8 +115,8 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
     m[0] = 0;
     uint32_t prev_bits = 0;
     for (int h = 0; h < steps; ++h) {
-        const int s0 = soft_at(tb, L.llr, lane, kind, 2 * h, stale_io);
-        const int s1 = soft_at(tb, L.llr, lane, kind, 2 * h + 1, stale_io);
+        const int s0 = soft_at(L.src, L.llr, L.stride, lane, kind, 2 * h, stale_io);
+        const int s1 = soft_at(L.src, L.llr, L.stride, lane, kind, 2 * h + 1, stale_io);
         if (2 * h == 400 && (kind & 3) != 3) stale_io = s1;  // this layout writes position 401
         // branch metrics (Viterbi.h:181-200): an erased bit contributes 0
         const int a = s0 ? abs(-7 - s0) : 0, b = s0 ? abs(7 - s0) : 0;  // |c - s0| for c = -7 / +7
@@ -139,10 +143,10 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) m[s] = n[s];
-        if (h & 1) L.hist[(h >> 1) * 64 + lane] = prev_bits | (bits << 16);
+        if (h & 1) L.hist[(h >> 1) * L.stride + lane] = prev_bits | (bits << 16);
         else prev_bits = bits;
     }
-    if (steps & 1) L.hist[(steps >> 1) * 64 + lane] = prev_bits;
+    if (steps & 1) L.hist[(steps >> 1) * L.stride + lane] = prev_bits;
     // end state: first strict minimum scanning 0 -> 15 (Viterbi.h:211-221)
     int best = 0;
     int32_t best_cost = m[0];
@@ -152,24 +156,101 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
     const uint32_t cost = (uint32_t)roundf((float)best_cost / 7.0f);
     // chainback (Viterbi.h:226-236) fused with to_byte_array: bit n of the message -> byte n>>3, bit 7-(n&7)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) L.outb[q * 64 + lane] = 0;
+    for (int q = 0; q < 8; ++q) L.outb[q * L.stride + lane] = 0;
     uint32_t state = (uint32_t)best;
     uint32_t word = 0;
     int o = OUT;
     int index = steps;
     for (int hi = steps; hi > 0 && o > 0;) {
         --hi;
-        const uint32_t hw = L.hist[(hi >> 1) * 64 + lane];
+        const uint32_t hw = L.hist[(hi >> 1) * L.stride + lane];
         const uint32_t hb = (hi & 1) ? (hw >> 16) : (hw & 0xFFFFu);
         const uint32_t v = (hb >> state) & 1u;
         if (index-- <= OUT) {
             --o;
             const int byte = o >> 3;
             word |= (state & 1u) << (8 * (byte & 3) + (7 - (o & 7)));
-            if ((o & 31) == 0) { L.outb[(byte >> 2) * 64 + lane] = word; word = 0; }
+            if ((o & 31) == 0) { L.outb[(byte >> 2) * L.stride + lane] = word; word = 0; }
         }
         state = (state >> 1) + (v ? 8u : 0u);  // prevState_[s] = (s>>1, (s>>1)+8)
     }
+    return cost;
+}
+
+// Wave-cooperative form of the same decoder (one frame per WAVE; used by the one-wave-per-channel demodulator, where
+// a frame completes on one channel at a time): lane l owns trellis state l & 15 (the four 16-lane groups compute the
+// same thing), predecessor metrics come from lanes s>>1 and (s>>1)+8 through ds_bpermute, the 16 decision bits of a
+// step are one ballot.  Columns have stride 1 here (per-wave LDS arrays).  `wl` = lane id in the wave.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int wl, int kind, int& stale_io)
+{
+    const int IN = DEC_IN[kind & 3], OUT = DEC_OUT[kind & 3];
+    const int steps = IN >> 1;
+    constexpr int32_t MAXM = 0x7FFFFFFF / 2;
+    // depuncture / deinterleave / derandomise the whole frame once, 64 positions at a time
+    for (int i = wl; i < IN; i += 64) L.soft[i] = soft_at(L.src, L.llr, 1, 0, kind, i, stale_io);
+    wave_lds_sync();
+    if ((kind & 3) != 3 && IN > 401) stale_io = L.soft[401];  // this layout writes position 401
+    const int ns = wl & 15, j = ns >> 1, bit = ns & 1;
+    const bool c0neg = j < 4;                         // cost_[j][0] == -7   (polys 031/027)
+    const bool c1neg = (((j ^ (j >> 1)) & 1) == 0);   // cost_[j][1] == -7
+    const int p0 = (wl & 48) + j, p1 = p0 + 8;
+    int32_t m = (ns == 0) ? 0 : MAXM;
+    uint32_t prev_bits = 0;
+    for (int h = 0; h < steps; ++h) {
+        const int s0 = L.soft[2 * h], s1 = L.soft[2 * h + 1];
+        const int a = s0 ? abs(-7 - s0) : 0, b = s0 ? abs(7 - s0) : 0;
+        const int d = s1 ? abs(-7 - s1) : 0, e = s1 ? abs(7 - s1) : 0;
+        const int cost0 = (c0neg ? a : b) + (c1neg ? d : e);   // Viterbi.h:190-199
+        const int cost1 = (c0neg ? b : a) + (c1neg ? e : d);
+        const int32_t mj = __shfl(m, p0), mj8 = __shfl(m, p1);
+        const int32_t candA = mj + (bit ? cost1 : cost0);      // m0 / m1 (Viterbi.h:143-146)
+        const int32_t candB = mj8 + (bit ? cost0 : cost1);     // m2 / m3
+        const bool dec = candA > candB;
+        m = dec ? candB : candA;
+        const uint32_t bits = (uint32_t)(__ballot(dec) & 0xFFFFull);
+        if (h & 1) L.hist[h >> 1] = prev_bits | (bits << 16);
+        else prev_bits = bits;
+    }
+    if (steps & 1) L.hist[steps >> 1] = prev_bits;
+    // end state: first strict minimum scanning 0 -> 15 (Viterbi.h:211-221)
+    int best = 0;
+    int32_t best_cost = __shfl(m, 0);
+    for (int s = 1; s < 16; ++s) {
+        const int32_t v = __shfl(m, s);
+        if (v < best_cost) { best_cost = v; best = s; }
+    }
+    const uint32_t cost = (uint32_t)roundf((float)best_cost / 7.0f);
+    wave_lds_sync();
+    for (int q = wl; q < 8; q += 64) L.outb[q] = 0;
+    // decision words into registers: lane l holds words l and l + 64
+    const uint32_t hw0 = L.hist[wl];
+    const uint32_t hw1 = (wl + 64 < 122) ? L.hist[wl + 64] : 0u;
+    wave_lds_sync();
+    uint32_t state = (uint32_t)best;
+    uint32_t word = 0;
+    int o = OUT;
+    int index = steps;
+    for (int hi = steps; hi > 0 && o > 0;) {
+        --hi;
+        const int wi = __builtin_amdgcn_readfirstlane(hi >> 1);
+        const uint32_t hw = (wi < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)hw0, wi) : (uint32_t)__builtin_amdgcn_readlane((int)hw1, wi - 64);
+        const uint32_t hb = (hi & 1) ? (hw >> 16) : (hw & 0xFFFFu);
+        const uint32_t v = (hb >> state) & 1u;
+        if (index-- <= OUT) {
+            --o;
+            const int byte = o >> 3;
+            word |= (state & 1u) << (8 * (byte & 3) + (7 - (o & 7)));
+            if ((o & 31) == 0) { L.outb[byte >> 2] = word; word = 0; }
+        }
+        state = (state >> 1) + (v ? 8u : 0u);
+    }
+    wave_lds_sync();
     return cost;
 }
 
@@ -192,7 +273,7 @@ struct RecSink {  // where callbacks go
 };
 
 __device__ __forceinline__ void emit_record(const RecSink& S, uint32_t& n_run, uint32_t& seq, uint32_t frame_type, int32_t cost,
-                                            const uint32_t* col, int lane, uint32_t len)
+                                            const uint32_t* col, int stride, int lane, uint32_t len)
 {
     if (n_run < S.cap) {
         uint32_t* w = reinterpret_cast<uint32_t*>(S.base + n_run);
@@ -203,7 +284,7 @@ __device__ __forceinline__ void emit_record(const RecSink& S, uint32_t& n_run, u
         w[4] = (uint32_t)cost;
         w[5] = frame_type | (S.sync_type << 8) | (len << 16);
         for (int q = 0; q < 8; ++q) {
-            uint32_t v = col[q * 64 + lane];
+            uint32_t v = col[q * stride + lane];
             const int lo = 4 * q;  // zero bytes at and beyond len
             if (lo + 4 > (int)len) v = (lo >= (int)len) ? 0u : (v & (0xFFFFFFFFu >> (8 * (lo + 4 - (int)len))));
             w[6 + q] = v;
@@ -219,27 +300,31 @@ __device__ __forceinline__ void emit_record(const RecSink& S, uint32_t& n_run, u
 
 // M17FrameDecoder::operator() (M17FrameDecoder.h:353-392).  Returns the new viterbi_cost (unchanged when the
 // reference leaves its by-reference argument untouched).  0xFFFFFFFF stands for size_t(-1).
+template <bool WAVE = false>
 __device__ __forceinline__ uint32_t decode_frame(const DecodeTables* tb, const DecodeLds& L, int lane, uint32_t sync_type,
-                                                 DecoderRegs& D, uint32_t cost_in, const RecSink& S, uint32_t& n_run, uint32_t& seq)
+                                                 DecoderRegs& D, uint32_t cost_in, const RecSink& S, uint32_t& n_run, uint32_t& seq, int wl = 0)
 {
     uint32_t cost = cost_in;
-    auto run_viterbi = [&](int kind) { return viterbi_decode(tb, L, lane, kind, D.stale401); };
+    auto run_viterbi = [&](int kind) {
+        if constexpr (WAVE) return viterbi_decode_wave(L, wl, kind, D.stale401);
+        else return viterbi_decode(tb, L, lane, kind, D.stale401);
+    };
     switch (sync_type) {
     case 0: {  // LSF: decode_lsf :154-178
         D.state = 0;
         cost = run_viterbi(0);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) L.lsf[q * 64 + lane] = L.outb[q * 64 + lane];
-        if (crc16_col(L.lsf, lane, 30) == 0) {
-            const uint32_t b13 = byte_at(L.lsf, lane, 13);  // update_state :113-136 on bits 109..111
+        for (int q = 0; q < 8; ++q) L.lsf[q * L.stride + lane] = L.outb[q * L.stride + lane];
+        if (crc16_col(L.lsf, L.stride, lane, 30) == 0) {
+            const uint32_t b13 = byte_at(L.lsf, L.stride, lane, 13);  // update_state :113-136 on bits 109..111
             const uint32_t bit109 = (b13 >> 2) & 1u, bit110 = (b13 >> 1) & 1u, bit111 = b13 & 1u;
             if (bit111) { if (bit109) D.state = 1; }
             else D.state = (((bit109 << 1) | bit110) == 1u) ? 2u : 3u;
-            emit_record(S, n_run, seq, 0 /*LSF*/, (int32_t)cost, L.lsf, lane, 30);
+            emit_record(S, n_run, seq, 0 /*LSF*/, (int32_t)cost, L.lsf, L.stride, lane, 30);
         } else {
             D.lich_segments = 0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) L.lsf[q * 64 + lane] = 0;
+            for (int q = 0; q < 8; ++q) L.lsf[q * L.stride + lane] = 0;
         }
         break;
     }
@@ -250,8 +335,8 @@ __device__ __forceinline__ uint32_t decode_frame(const DecodeTables* tb, const D
             for (int i = 0; i < 4 && ok; ++i) {
                 uint32_t cw = 0;
                 for (int j = 0; j < 24; ++j) {
-                    const uint32_t e = tb->lich_src[i * 24 + j];
-                    int v = llr_at(L.llr, lane, (int)(e & 0x1FFu));
+                    const uint32_t e = L.lich_src[i * 24 + j];
+                    int v = llr_at(L.llr, L.stride, lane, (int)(e & 0x1FFu));
                     if (e & 0x200u) v = -v;
                     cw = (cw << 1) | (v > 0 ? 1u : 0u);
                 }
@@ -265,32 +350,32 @@ __device__ __forceinline__ uint32_t decode_frame(const DecodeTables* tb, const D
                 else { lich[4] |= (dec >> 8) & 0xFFu; lich[5] = dec & 0xFFu; }
             }
             if (!ok) break;  // FAIL, cost untouched
-            L.outb[0 * 64 + lane] = lich[0] | (lich[1] << 8) | (lich[2] << 16) | (lich[3] << 24);
-            L.outb[1 * 64 + lane] = lich[4] | (lich[5] << 8);
-            emit_record(S, n_run, seq, 1 /*LICH*/, 0, L.outb, lane, 6);
+            L.outb[0 * L.stride + lane] = lich[0] | (lich[1] << 8) | (lich[2] << 16) | (lich[3] << 24);
+            L.outb[1 * L.stride + lane] = lich[4] | (lich[5] << 8);
+            emit_record(S, n_run, seq, 1 /*LICH*/, 0, L.outb, L.stride, lane, 6);
             const uint32_t frag = (lich[5] >> 5) & 7u;
             if (frag > 5) { cost = 0xFFFFFFFFu; break; }
             {  // copy 5 bytes into lsf[frag*5 ..]
                 for (int k = 0; k < 5; ++k) {
                     const int b = (int)frag * 5 + k;
-                    uint32_t w = L.lsf[(b >> 2) * 64 + lane];
+                    uint32_t w = L.lsf[(b >> 2) * L.stride + lane];
                     w = (w & ~(0xFFu << (8 * (b & 3)))) | (lich[k] << (8 * (b & 3)));
-                    L.lsf[(b >> 2) * 64 + lane] = w;
+                    L.lsf[(b >> 2) * L.stride + lane] = w;
                 }
             }
             D.lich_segments |= (1u << frag);
             if ((D.lich_segments & 0x3Fu) != 0x3Fu) { cost = 0xFFFFFFFFu; break; }
-            if (crc16_col(L.lsf, lane, 30) == 0) {
+            if (crc16_col(L.lsf, L.stride, lane, 30) == 0) {
                 D.lich_segments = 0;
                 D.state = 1;
                 cost = 0;
-                emit_record(S, n_run, seq, 0 /*LSF*/, 0, L.lsf, lane, 30);
+                emit_record(S, n_run, seq, 0 /*LSF*/, 0, L.lsf, L.stride, lane, 30);
             } else {
                 cost = 128;
             }
         } else if (D.state == 1) {  // decode_stream :276-289
             cost = run_viterbi(1);
-            emit_record(S, n_run, seq, 2 /*STREAM*/, (int32_t)cost, L.outb, lane, 18);
+            emit_record(S, n_run, seq, 2 /*STREAM*/, (int32_t)cost, L.outb, L.stride, lane, 18);
         } else {
             D.state = 0;
         }
@@ -298,8 +383,8 @@ __device__ __forceinline__ uint32_t decode_frame(const DecodeTables* tb, const D
     case 2:  // PACKET: decode_packet :299-315
         if (D.state == 2 || D.state == 3) {
             cost = run_viterbi(2);
-            emit_record(S, n_run, seq, D.state == 2 ? 3u : 4u, (int32_t)cost, L.outb, lane, 26);
-            if (byte_at(L.outb, lane, 25) & 0x80u) D.state = 0;
+            emit_record(S, n_run, seq, D.state == 2 ? 3u : 4u, (int32_t)cost, L.outb, L.stride, lane, 26);
+            if (byte_at(L.outb, L.stride, lane, 25) & 0x80u) D.state = 0;
         } else {
             D.state = 0;
         }
@@ -307,7 +392,7 @@ __device__ __forceinline__ uint32_t decode_frame(const DecodeTables* tb, const D
     default:  // BERT: decode_bert :264-274
         D.state = 4;
         cost = run_viterbi(3);
-        emit_record(S, n_run, seq, 5 /*BERT*/, (int32_t)cost, L.outb, lane, 25);
+        emit_record(S, n_run, seq, 5 /*BERT*/, (int32_t)cost, L.outb, L.stride, lane, 25);
         break;
     }
     return cost;

@@ -179,43 +179,46 @@ __global__ __launch_bounds__(64) void limit_kernel(const float* __restrict__ y, 
 // pass.  What the state machine needs is the value of (L1, L2) at DCD update points, accumulated
 // sequentially from the previous update point; update points are 384 (carrier off) or 960 (carrier on)
 // samples apart and always fall on 192-sample tick boundaries (M17Demodulator.h:677-686,742-751), the
-// first one 2304 samples after the stream start.  So this pass keeps six running pairs — five that are
+// first one 2304 samples after the stream start.  So this pass keeps six running sums per bin — five that are
 // reset at the start of ticks a = 0,1,2,3,4 (mod 5) and one that runs from the stream start — and writes
-// them at the end of every tick: the state machine later picks the pair whose start matches its segment,
+// them at the end of every tick: the state machine later picks the sum whose start matches its segment,
 // bit-exact with the reference's single accumulator whatever the cadence turned out to be.
 //
-// Float recurrence => sequential in time; one lane per channel.  Each lane streams its row with 16-byte
-// loads (8 samples) for x[n] and x[n-120] (120 = 15 * 8 keeps both aligned; the delayed block is an L1/L2 hit).
+// A float recurrence is sequential in time, and a lone wave pays ~3 ns per dependent instruction, so the kernel
+// minimises instructions per sample per lane and maximises ILP: TWO LANES PER CHANNEL (lane parity = DFT bin; the
+// two bins and their sums are independent), samples converted once and kept in an LDS delay line (x[n-120] is a
+// ds_read_b128 away), straight-line blocks of 8 samples, next block's 16-byte global load in flight while the
+// current one is consumed.  Table layout: [C][ticks][2 bins][6 sums].
 // Algorithmic bytes: 2 B/sample read (+ 48 B per 192 samples written).
 // =====================================================================================================
 struct DcdCoef { float c0r, c0i, c1r, c1i; };  // exp(-j 2 pi f/48000), f = 2400, 3600 — computed on the host
 
-__device__ __forceinline__ void dcd_step(DcdState& s, const DcdCoef& k, float xn, float xd, bool long_acc)
+constexpr int DCD_RING = 128;        // delay line length (>= 120), power of two
+constexpr int DCD_RING_PITCH = 132;  // floats per lane: 16-lane groups of ds_*_b128 fall on distinct banks
+
+// apps/m17-demod.cpp:486-489 through the double-precision product (bit-identical to the division for all int16, see
+// tests/test_oracle_kat.py::test_scale_identities_exhaustive); 3 instructions instead of a division expansion.
+__device__ __forceinline__ float scale_sample_mul(int s, bool invert)
+{
+    if (invert) s = (int)(int16_t)(-s);
+    return (float)((double)s * (1.0 / 41067.0));
+}
+
+struct DcdLane {  // one bin of one channel
+    float xr, xi, cr, ci;
+    float acc[6];
+};
+__device__ __forceinline__ void dcd_step(DcdLane& s, float xn, float xd, bool long_acc)
 {
     const float delta = xn - xd;
-    {
-        const float a = s.xr[0] + delta, b = s.xi[0];
-        const float ac = a * k.c0r, bd = b * k.c0i, ad = a * k.c0i, bc = b * k.c0r;
-        s.xr[0] = ac - bd;
-        s.xi[0] = ad + bc;
-    }
-    {
-        const float a = s.xr[1] + delta, b = s.xi[1];
-        const float ac = a * k.c1r, bd = b * k.c1i, ad = a * k.c1i, bc = b * k.c1r;
-        s.xr[1] = ac - bd;
-        s.xi[1] = ad + bc;
-    }
-    const float n0 = s.xr[0] * s.xr[0] + s.xi[0] * s.xi[0];
-    const float n1 = s.xr[1] * s.xr[1] + s.xi[1] * s.xi[1];
+    const float a = s.xr + delta, b = s.xi;
+    const float ac = a * s.cr, bd = b * s.ci, ad = a * s.ci, bc = b * s.cr;
+    s.xr = ac - bd;
+    s.xi = ad + bc;
+    const float nrm = s.xr * s.xr + s.xi * s.xi;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        s.acc[j][0] = s.acc[j][0] + n0;
-        s.acc[j][1] = s.acc[j][1] + n1;
-    }
-    if (long_acc) {
-        s.acc[5][0] = s.acc[5][0] + n0;
-        s.acc[5][1] = s.acc[5][1] + n1;
-    }
+    for (int j = 0; j < 5; ++j) s.acc[j] = s.acc[j] + nrm;
+    if (long_acc) s.acc[5] = s.acc[5] + nrm;
 }
 
 // pos0: absolute index (since reset) of the first sample of this run — identical for every channel.
@@ -223,48 +226,77 @@ __global__ __launch_bounds__(64) void dcd_kernel(const int16_t* __restrict__ x, 
                                                  float* __restrict__ table, uint32_t ticks_cap, uint32_t C, uint32_t T,
                                                  uint64_t pos0, DcdCoef k, uint32_t flags)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float ringbuf[64 * DCD_RING_PITCH];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * 32 + (lane >> 1);
+    const int bin = lane & 1;
     if (c >= C) return;
     const bool invert = flags & 1u;
     const int16_t* xr = x + (size_t)c * xpitch + XPRE;
-    DcdState s = state[c];
-    float* tab = table + (size_t)c * ticks_cap * 12;
+    float* ring = ringbuf + lane * DCD_RING_PITCH;
+    DcdState* st = state + c;
+    DcdLane s;
+    s.xr = st->xr[bin]; s.xi = st->xi[bin];
+    s.cr = bin ? k.c1r : k.c0r; s.ci = bin ? k.c1i : k.c0i;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s.acc[q] = st->acc[q][bin];
+    // delay line: the 120 samples before this run (zeros after a reset), at ring slot = absolute index mod 128
+    for (int d = 1; d <= 120; ++d) ring[(uint32_t)(pos0 - d) & (DCD_RING - 1)] = scale_sample_mul(xr[-d], invert);
+    float* tab = table + (size_t)c * ticks_cap * 12 + bin * 6;
     uint32_t phase = (uint32_t)(pos0 % TICK);  // position inside the current tick (wave-uniform)
     uint64_t tick = pos0 / TICK;
     uint32_t row = 0;
-    // the stream-start accumulator is only ever read at the first update (sample 2303)
-    auto process = [&](float xn, float xd, uint64_t abs_pos) {
-        if (phase == 0) {
-            const int j = (int)(tick % 5);
+
+    auto tick_begin = [&]() {  // start of tick `tick`: the sum that restarts here
+        const int j = (int)(tick % 5);
 #pragma unroll
-            for (int q = 0; q < 5; ++q)
-                if (q == j) { s.acc[q][0] = 0.f; s.acc[q][1] = 0.f; }
-        }
-        dcd_step(s, k, xn, xd, abs_pos < 12 * TICK);
-        if (++phase == TICK) {
-            float* o = tab + (size_t)row * 12;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) { o[2 * q] = s.acc[q][0]; o[2 * q + 1] = s.acc[q][1]; }
-            phase = 0; ++tick; ++row;
-        }
+        for (int q = 0; q < 5; ++q) s.acc[q] = (q == j) ? 0.f : s.acc[q];
     };
-    uint32_t t = 0;
-    for (; t + 8 <= T; t += 8) {
-        const int4 cur = *reinterpret_cast<const int4*>(xr + t);
-        const int4 old = *reinterpret_cast<const int4*>(xr + (int64_t)t - 120);
-        const int cw[4] = {cur.x, cur.y, cur.z, cur.w};
-        const int ow[4] = {old.x, old.y, old.z, old.w};
+    auto tick_end = [&]() {
+        float* o = tab + (size_t)row * 12;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int a0 = (int)(int16_t)(cw[q] & 0xFFFF), a1 = cw[q] >> 16;
-            const int b0 = (int)(int16_t)(ow[q] & 0xFFFF), b1 = ow[q] >> 16;
-            process(scale_sample(a0, invert), scale_sample(b0, invert), pos0 + t + 2 * q);
-            process(scale_sample(a1, invert), scale_sample(b1, invert), pos0 + t + 2 * q + 1);
+        for (int q = 0; q < 6; ++q) o[q] = s.acc[q];
+        phase = 0; ++tick; ++row;
+    };
+    auto one_sample = [&](uint32_t t) {  // generic path (unaligned head / tail of a run)
+        if (phase == 0) tick_begin();
+        const uint32_t slot = (uint32_t)(pos0 + t) & (DCD_RING - 1);
+        const float xn = scale_sample_mul(xr[t], invert);
+        const float xd = ring[(slot + 8) & (DCD_RING - 1)];
+        ring[slot] = xn;
+        dcd_step(s, xn, xd, pos0 + t < 12 * TICK);
+        if (++phase == TICK) tick_end();
+    };
+
+    uint32_t t = 0;
+    while (t < T && (((pos0 + t) & 7u) != 0)) { one_sample(t); ++t; }  // head: up to the next multiple of 8
+    if (t + 8 <= T && (pos0 & 7u) == 0) {  // (a run that starts off an 8-sample boundary stays on the generic path)
+        int4 nxt = *reinterpret_cast<const int4*>(xr + t);
+        for (; t + 8 <= T; t += 8) {
+            const int4 cur = nxt;
+            if (t + 16 <= T) nxt = *reinterpret_cast<const int4*>(xr + t + 8);  // in flight while `cur` is consumed
+            if (phase == 0) tick_begin();       // ticks are multiples of 8 samples: boundaries fall between blocks
+            const uint32_t slot = (uint32_t)(pos0 + t) & (DCD_RING - 1);
+            const float4 d0 = *reinterpret_cast<const float4*>(ring + ((slot + 8) & (DCD_RING - 1)));
+            const float4 d1 = *reinterpret_cast<const float4*>(ring + ((slot + 12) & (DCD_RING - 1)));
+            float4 n0, n1;
+            n0.x = scale_sample_mul((int)(int16_t)(cur.x & 0xFFFF), invert); n0.y = scale_sample_mul(cur.x >> 16, invert);
+            n0.z = scale_sample_mul((int)(int16_t)(cur.y & 0xFFFF), invert); n0.w = scale_sample_mul(cur.y >> 16, invert);
+            n1.x = scale_sample_mul((int)(int16_t)(cur.z & 0xFFFF), invert); n1.y = scale_sample_mul(cur.z >> 16, invert);
+            n1.z = scale_sample_mul((int)(int16_t)(cur.w & 0xFFFF), invert); n1.w = scale_sample_mul(cur.w >> 16, invert);
+            *reinterpret_cast<float4*>(ring + slot) = n0;
+            *reinterpret_cast<float4*>(ring + slot + 4) = n1;
+            const bool la = pos0 + t < 12 * TICK;  // the stream-start sum is only ever read at the first update (sample 2303)
+            dcd_step(s, n0.x, d0.x, la); dcd_step(s, n0.y, d0.y, la); dcd_step(s, n0.z, d0.z, la); dcd_step(s, n0.w, d0.w, la);
+            dcd_step(s, n1.x, d1.x, la); dcd_step(s, n1.y, d1.y, la); dcd_step(s, n1.z, d1.z, la); dcd_step(s, n1.w, d1.w, la);
+            phase += 8;
+            if (phase == TICK) tick_end();
         }
     }
-    for (; t < T; ++t)
-        process(scale_sample(xr[t], invert), scale_sample(xr[(int64_t)t - 120], invert), pos0 + t);
-    state[c] = s;
+    for (; t < T; ++t) one_sample(t);  // tail
+    st->xr[bin] = s.xr; st->xi[bin] = s.xi;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) st->acc[q][bin] = s.acc[q];
 }
 
 }  // namespace m17

@@ -1,0 +1,123 @@
+// Stand-alone operator kernels behind the per-operator C-ABI entry points (parity API): slicer/EVM, Viterbi,
+// frame decoder.  They reuse the device functions of the full-chain kernel, one lane per row / frame.
+#pragma once
+
+#include "m17_common.hpp"
+#include "m17_decode_device.hpp"
+#include "m17_state.hpp"
+
+namespace m17 {
+
+// a11/a12 stand-alone (parity API): normalised symbols -> LLR pairs (Util.h:128-145) and the running EVM
+// (SymbolEvm.h:31-51) of each row.  One lane per row.
+__global__ __launch_bounds__(64) void slice_kernel(const float* __restrict__ sym, uint32_t rows, uint32_t n, int8_t* __restrict__ llr,
+                                                   float* __restrict__ evm, const float* __restrict__ edges)
+{
+    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= rows) return;
+    float S = 0.f;  // evm.reset()
+    const float alpha = (float)(1.0 / 184);
+    for (uint32_t k = 0; k < n; ++k) {
+        const float sample = sym[(size_t)r * n + k];
+        const uint32_t pair = slice_llr(sample, edges);
+        llr[((size_t)r * n + k) * 2] = (int8_t)(pair & 0xFF);
+        llr[((size_t)r * n + k) * 2 + 1] = (int8_t)(pair >> 8);
+        float e;
+        if (sample > 2.f) e = sample - 3.f;
+        else if (sample > 0.f) e = sample - 1.f;
+        else if (sample > -2.f) e = sample + 1.f;
+        else e = sample + 3.f;
+        S = S - S * alpha;
+        S = S + (e * e) * alpha;
+        evm[(size_t)r * n + k] = sqrtf(S);
+    }
+}
+
+// Standalone K4 entry points (parity API): one lane per frame.
+__global__ __launch_bounds__(64) void viterbi_kernel(const int8_t* __restrict__ soft, uint32_t n_frames, int kind,
+                                                     uint8_t* __restrict__ bits, int32_t* __restrict__ cost,
+                                                     const DecodeTables* ident)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    DecodeLds L;
+    L.llr = lds;                 // [122][64] here: up to 488 soft bits per lane
+    L.hist = lds + 122 * 64;     // [122][64]
+    L.outb = L.hist + 122 * 64;  // [8][64]
+    L.lsf = L.outb + 8 * 64;
+    L.stride = 64;
+    L.src = &ident->src[0][0];
+    L.lich_src = ident->lich_src;
+    const int lane = threadIdx.x;
+    const uint32_t f = blockIdx.x * 64 + lane;
+    const int IN = DEC_IN[kind], OUT = DEC_OUT[kind];
+    if (f < n_frames) {
+        const int8_t* src = soft + (size_t)f * IN;
+        for (int k = 0; k < (IN + 3) / 4; ++k) {
+            uint32_t w = 0;
+            for (int q = 0; q < 4; ++q)
+                if (4 * k + q < IN) w |= (uint32_t)(uint8_t)src[4 * k + q] << (8 * q);
+            L.llr[k * 64 + lane] = w;
+        }
+        int stale = llr_at(L.llr, 64, lane, kind == 3 ? 401 : 0);  // BERT callers pass position 401 explicitly
+        const uint32_t cst = viterbi_decode(ident, L, lane, kind + 4, stale);  // tables 4..7: identity source map
+        cost[f] = (int32_t)cst;
+        for (int n = 0; n < OUT; ++n) bits[(size_t)f * OUT + n] = (uint8_t)((byte_at(L.outb, 64, lane, n >> 3) >> (7 - (n & 7))) & 1u);
+    }
+}
+
+struct DecodeFramesParams {
+    const int8_t* llr;        // [n][368]
+    const uint8_t* sync_type; // [n]
+    uint8_t* state_io;        // [n]
+    uint8_t* lich_io;         // [n]
+    uint8_t* lsf_io;          // [n][30]
+    int8_t* dep401_io;        // [n]
+    int64_t* cost_io;         // [n]
+    FrameRec* recs;           // [n][2]
+    uint8_t* nrec;            // [n]
+    uint32_t n;
+    const DecodeTables* tables;
+    uint32_t* overflow;
+};
+
+__global__ __launch_bounds__(64) void decode_frames_kernel(DecodeFramesParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    DecodeLds L;
+    L.llr = lds;                // [92][64]
+    L.hist = lds + 92 * 64;     // [122][64]
+    L.outb = L.hist + 122 * 64; // [8][64]
+    L.lsf = L.outb + 8 * 64;    // [8][64]
+    L.stride = 64;
+    L.src = &P.tables->src[0][0];
+    L.lich_src = P.tables->lich_src;
+    const int lane = threadIdx.x;
+    const uint32_t f = blockIdx.x * 64 + lane;
+    if (f >= P.n) return;
+    const int8_t* src = P.llr + (size_t)f * 368;
+    for (int k = 0; k < 92; ++k) {
+        uint32_t w = 0;
+        for (int q = 0; q < 4; ++q) w |= (uint32_t)(uint8_t)src[4 * k + q] << (8 * q);
+        L.llr[k * 64 + lane] = w;
+    }
+    for (int k = 0; k < 8; ++k) {
+        uint32_t w = 0;
+        for (int q = 0; q < 4; ++q)
+            if (4 * k + q < 30) w |= (uint32_t)P.lsf_io[(size_t)f * 30 + 4 * k + q] << (8 * q);
+        L.lsf[k * 64 + lane] = w;
+    }
+    DecoderRegs D{P.state_io[f], P.lich_io[f], (int)P.dep401_io[f]};
+    const int64_t cin = P.cost_io[f];
+    uint32_t cost = cin < 0 ? 0xFFFFFFFFu : (uint32_t)cin;
+    uint32_t n_run = 0, seq = 0;
+    RecSink S{P.recs + (size_t)f * 2, 2, nullptr, nullptr, f, 0, P.sync_type[f], P.overflow};
+    cost = decode_frame(P.tables, L, lane, P.sync_type[f], D, cost, S, n_run, seq);
+    P.state_io[f] = (uint8_t)D.state;
+    P.lich_io[f] = (uint8_t)D.lich_segments;
+    P.dep401_io[f] = (int8_t)D.stale401;
+    P.cost_io[f] = cost == 0xFFFFFFFFu ? (int64_t)-1 : (int64_t)cost;
+    P.nrec[f] = (uint8_t)n_run;
+    for (int k = 0; k < 30; ++k) P.lsf_io[(size_t)f * 30 + k] = (uint8_t)byte_at(L.lsf, 64, lane, k);
+}
+
+}  // namespace m17

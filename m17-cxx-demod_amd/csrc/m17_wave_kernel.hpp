@@ -1,0 +1,552 @@
+// K5: the per-channel sequential glue — reference a3, a5, a6, a8 (decision half), a9-a13, a19:
+// Correlator::sample / SyncWord / outer_symbol_levels (Correlator.h), DataCarrierDetect::update,
+// ClockRecovery + KalmanFilter, FreqDevEstimator, SymbolEvm, llr<float,4>, M17Framer and the
+// M17Demodulator state machine (M17Demodulator.h:233-753) — plus K4 (frame decode, wave-cooperative).
+//
+// Mapping: ONE WAVE PER CHANNEL.  Everything here is a recurrence or a state machine per channel, so there is
+// no data parallelism across time; what the hardware punishes is (a) a lone wave's ~3 ns per dependent
+// instruction and (b) divergence.  With one wave per channel 4096 channels are 4096 waves = 4 per SIMD (the whole
+// chip busy, latencies of one wave hidden by its three neighbours), the state machine is wave-uniform (every
+// branch is taken by all lanes, untaken code is skipped), and the 64 lanes cooperate where a stretch of the
+// stream allows it:
+//   * "bulk chunks": while nothing but feeding happens (initialisation, the 77 quiet samples after a frame, the
+//     inside of a payload frame) up to 960 samples are loaded coalesced into LDS, the limit IIR runs over them as
+//     one tight dependent chain, the <= 96 payload symbols of the chunk are normalised / sliced by 64 lanes at once,
+//     the running EVM is folded sequentially, and the correlator ring is refilled from the chunk's tail;
+//   * the frame decode uses 16 lanes as the 16 trellis states (m17_decode_device.hpp, viterbi_decode_wave).
+// The massively parallel work (K1 FIR) and the state-machine-independent recurrence (K3 sliding DFT) have
+// already run as their own passes; this kernel consumes
+//   ybuf[c][t]    the matched-filter output, valid wherever the last 149 FIR inputs were consecutive samples
+//   dcd table     the sequential carrier-detect sums for every possible segment (see K3)
+// The reference gates the FIR and the correlator with the carrier detect: their input is the
+// concatenation of gated-on runs.  Runs start and end on tick boundaries and last >= 960 samples, so only the
+// first 148 outputs of a run see samples of the previous run; for those the FIR is recomputed from a 149-sample
+// snapshot taken when the previous run ended ("slow FIR", rare).
+//
+// All 64 lanes hold the same scalar state and execute the single-sample path redundantly; stores of state are
+// issued by every lane with identical values (no cross-lane ordering is relied on).
+#pragma once
+
+#include "m17_common.hpp"
+#include "m17_decode_device.hpp"
+#include "m17_frontend_kernels.hpp"
+#include "m17_state.hpp"
+
+namespace m17 {
+
+constexpr int WV_YCH = 960;                                             // largest bulk chunk (one DCD period)
+constexpr int WV_TAB_WORDS = 64 + 4 * 244 + 48;                         // per block: llr edges, source maps, lich map
+constexpr int WV_COLD_WORDS = (sizeof(Cold) + 3) / 4;
+constexpr int WV_WAVE_WORDS = 80 + 40 + 92 + 122 + 8 + 8 + WV_YCH + 96 + 64 + WV_COLD_WORDS; // per wave: ring, sync samples, llr, hist, outb, lsf, chunk, evm terms, look-ahead, cold state
+constexpr int wave_lds_words(int waves_per_block) { return WV_TAB_WORDS + waves_per_block * WV_WAVE_WORDS; }
+
+// M17FrameDecoder::operator() on the wave's completed frame; returns (viterbi_cost, decoder state)
+__device__ __noinline__ uint2 nf_decode_wave(const DecodeTables* tb, DecodeLds L, int wl, uint32_t sync_type, Cold* cd, uint32_t cost_in,
+                                             FrameRec* rec_base, uint32_t rec_cap, uint32_t channel, uint64_t pos, uint32_t* overflow)
+{
+    DecoderRegs D{cd->dec_state, cd->lich_segments, cd->stale401};
+    RecSink S{rec_base, rec_cap, nullptr, nullptr, channel, pos, sync_type, overflow};
+    uint32_t n_run = cd->n_run, seq = cd->seq;
+    const uint32_t cost = decode_frame<true>(tb, L, 0, sync_type, D, cost_in, S, n_run, seq, wl);
+    cd->dec_state = D.state; cd->lich_segments = D.lich_segments; cd->stale401 = D.stale401;
+    cd->n_run = n_run; cd->seq = seq;
+    return make_uint2(cost, D.state);
+}
+
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    float* edges = reinterpret_cast<float*>(lds);                        // [64] llr table edges (43 used)
+    uint16_t* srcmap = reinterpret_cast<uint16_t*>(edges + 64);          // [4][488] depuncture/deinterleave/derandomise maps
+    uint16_t* lichmap = srcmap + 4 * 488;                                // [96]
+    for (int k = threadIdx.x; k < 43; k += 64 * WPB) edges[k] = P.llr_edges[k];
+    for (int k = threadIdx.x; k < 4 * 488; k += 64 * WPB) srcmap[k] = P.tables->src[k / 488][k % 488];
+    for (int k = threadIdx.x; k < 96; k += 64 * WPB) lichmap[k] = P.tables->lich_src[k];
+    __syncthreads();  // the only block-level barrier: the waves of a block are independent from here on
+
+    const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * WPB + wave;
+    if (c >= P.C) return;
+    uint32_t* wb = lds + WV_TAB_WORDS + wave * WV_WAVE_WORDS;
+    float* ring = reinterpret_cast<float*>(wb);              // [80]  Correlator::buffer_
+    float* swsm = ring + 80;                                 // [4][10] SyncWord::samples_
+    DecodeLds DL;
+    DL.llr = wb + 120;                                       // [92]  M17Framer::buffer_ (368 int8)
+    DL.hist = DL.llr + 92;                                   // [122] Viterbi decisions
+    DL.outb = DL.hist + 122;                                 // [8]
+    DL.lsf = DL.outb + 8;                                    // [8]   output_buffer.lsf
+    float* ych = reinterpret_cast<float*>(DL.lsf + 8);       // [WV_YCH] chunk of matched-filter samples
+    float* e2 = ych + WV_YCH;                                // [96]  per-symbol EVM terms of a chunk
+    float* ylook = e2 + 96;                                  // [64]  look-ahead window of matched-filter samples for the single-sample path
+    Cold* cd = reinterpret_cast<Cold*>(ylook + 64);          // cold state lives in LDS while the kernel runs
+    DL.soft = reinterpret_cast<int32_t*>(ych);               // the chunk buffer is free while a frame decodes
+    DL.src = srcmap;
+    DL.lich_src = lichmap;
+    DL.stride = 1;
+    uint16_t* llr16 = reinterpret_cast<uint16_t*>(DL.llr);
+
+    const bool invert = P.flags & 1u;
+    SeqState* gs = P.state + c;
+    Hot s = gs->hot;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&gs->cold);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(cd);
+        for (int k = wl; k < WV_COLD_WORDS; k += 64) dst[k] = src[k];
+    }
+    for (int k = wl; k < 80; k += 64) ring[k] = gs->ring[k];
+    for (int k = wl; k < 40; k += 64) swsm[k] = gs->sw_samples[k / 10][k % 10];
+    for (int k = wl; k < 92; k += 64) DL.llr[k] = gs->llr[k];
+    for (int k = wl; k < 8; k += 64) DL.lsf[k] = gs->lsf[k];
+    wave_lds_sync();
+    cd->n_run = 0;
+    uint32_t look_t = 0x80000000u;  // ylook holds samples [look_t, look_t + 64); this value = "empty"
+
+    const int16_t* xr = P.x + (size_t)c * P.xpitch + XPRE;
+    const float* yr = P.y + (size_t)c * P.ypitch + YPRE;
+    const float* tab = P.dcd_table + (size_t)c * P.ticks_cap * 12;
+    const uint64_t tick0 = P.pos0 / TICK;
+    FrameRec* rec_base = P.recs + (size_t)c * P.rec_cap;
+    uint32_t t = 0;  // next sample (relative to this run)
+
+    // ---------------- wave-uniform helpers ------------------------------------------------------------------------
+    auto corr_index = [&]() -> uint32_t { return s.prev_pos % 10u; };
+    float r8[8];  // the eight ring samples one symbol apart that end at the newest sample (shared by all sync words)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r8[i] = 0.f;
+    auto load_r8 = [&]() {
+        uint32_t p = s.prev_pos + 10u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (p >= 80u) p -= 80u;
+            r8[i] = ring[p];
+            p += 10u;
+        }
+    };
+    auto correlate = [&](int w) -> float {  // Correlator.h:51-64: oldest symbol first
+        float r = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float prod = (float)SYNC_WORDS[w][i] * r8[i];
+            r = r + prod;
+        }
+        return r;
+    };
+    auto sw_triggered = [&](int w) -> float {  // Correlator.h:150-157
+        const float lim = iir_output(s.h0, s.h1, s.h2);
+        const float l1 = lim * SW_MAG1[w];
+        const float l2 = lim * SW_MAG2[w];
+        const float v = correlate(w);
+        return (v > l1 || v < l2) ? v : 0.0f;
+    };
+    auto sw_step = [&](int w) -> uint32_t {  // SyncWord::operator() :179-200 (+ find_peak :161-177)
+        const float v = sw_triggered(w);
+        if (v != 0.f) {
+            if (!s.sw_trig[w]) {
+                for (int k = 0; k < 10; ++k) swsm[w * 10 + k] = 0.f;
+                s.sw_trig[w] = 1;
+            }
+            swsm[w * 10 + (int)corr_index()] = v;
+        } else if (s.sw_trig[w]) {
+            s.sw_trig[w] = 0;
+            s.sw_timing[w] = 0;
+            float peak = v;
+            for (int k = 0; k < 10; ++k) {
+                const float f = swsm[w * 10 + k];
+                if (fabsf(f) > fabsf(peak)) { peak = f; s.sw_timing[w] = (uint32_t)k; }
+            }
+            s.sw_updated[w] = peak > 0.f ? 1 : -1;
+        }
+        return s.sw_timing[w];
+    };
+    auto sw_updated = [&](int w) -> int32_t { const int32_t r = s.sw_updated[w]; s.sw_updated[w] = 0; return r; };
+    auto update_values = [&](uint32_t index) {  // M17Demodulator.h:233-241
+        const float2 r = nf_update_values(cd, ring, 1, 0, s.sample_index);
+        s.idev = r.x; s.offset = r.y;
+        s.sync_sample_index = index;
+    };
+    auto dev_reset = [&]() { cd->dev_reset = 1; };
+    auto clock_flags = [&]() {  // the index-0 prologue of operator() (:695-709)
+        if (s.need_clock_reset) {
+            Kal2 k;
+            kal_reset(k, (float)s.sync_sample_index);  // ClockRecovery::reset :33-39
+            cd->ck = k;
+            s.ck_count = 0;
+            s.ck_sample_index = (int32_t)(int8_t)(float)s.sync_sample_index;
+            s.ck_clock_est = 0.f;
+            s.need_clock_reset = 0;
+            s.sample_index = s.sync_sample_index;
+        } else if (s.need_clock_update) {
+            const ClockOut o = nf_clock_update_idx(cd, s.sync_sample_index, s.ck_count);
+            s.ck_sample_est = o.sample_est; s.ck_clock_est = o.clock_est; s.ck_sample_index = o.sample_index;
+            s.ck_count = 0;
+            s.need_clock_update = 0;
+        }
+    };
+    auto corr_sample = [&](float v) {  // Correlator::sample :43-49
+        const float h0n = iir_advance(fabsf(v), s.h0, s.h1);  // history shifts: h2 <- h1, h1 <- h0
+        s.h2 = s.h1; s.h1 = s.h0; s.h0 = h0n;
+        ring[s.ring_pos] = v;
+        s.prev_pos = s.ring_pos;
+        if (++s.ring_pos == 80u) s.ring_pos = 0;
+        if (s.run_pos < 148) s.run_pos++;
+    };
+    // symbol normalisation + EVM error term (do_frame :610-614, SymbolEvm.h:31-51)
+    auto normalise = [&](float filtered, float& err) -> float {
+        float sample = filtered - s.offset;
+        sample = sample * s.idev;
+        sample = sample * 1.0f;  // polarity
+        if (sample > 2.f) err = sample - 3.f;
+        else if (sample > 0.f) err = sample - 1.f;
+        else if (sample > -2.f) err = sample + 1.f;
+        else err = sample + 3.f;
+        return sample;
+    };
+    const float alpha = (float)(1.0 / 184);  // RunningStandardDeviation<float,184>::alpha
+    // carrier-on update point: tail of operator() (:742-752); te = relative index of the sample just processed
+    auto dcd_point_on = [&](uint32_t te) {
+        if (!s.dcd_trig) {  // update_dcd -> dcd_off :260-265 (dcd_ is on here)
+            s.st = ST_UNLOCKED;
+            s.dcd_on = 0;
+            nf_snapshot_hist(gs->hist, xr, te);
+        }
+        s.count = 0;
+        nf_fire_diag(cd, s.dcd_on, sqrtf(s.evm_S), s.idev, s.offset, s.st != ST_UNLOCKED, s.ck_clock_est, s.sample_index,
+                     s.sync_sample_index, s.ck_sample_index, s.viterbi_cost);
+        s.dcd_trig = nf_dcd_update(cd, tab, tick0, (P.pos0 + te + 1) / TICK - 1, s.dcd_trig);
+    };
+
+    unsigned long long n_bulk = 0, n_bulk_samples = 0, n_scalar = 0, n_flip = 0, n_decode = 0;
+    const bool prof = P.dbg != nullptr;
+    auto now = [&]() -> unsigned long long { return prof ? wall_clock64() : 0ull; };
+    const unsigned long long tk0 = now();
+    unsigned long long tk_bulk = 0, tk_scalar = 0, tk_decode = 0;
+
+    // ---------------- main loop (wave-uniform control flow) ------------------------------------------------------------
+    while (t < P.T) {
+        // ---- carrier off: nothing happens until the next DCD update point (:675-689) -> jump there ----------------------
+        if (!s.initializing && !s.dcd_on) {
+            const uint32_t n = min(384u - s.count, P.T - t);
+            s.count += n;
+            t += n;
+            if (s.count == 384u) {
+                const uint32_t te = t - 1;
+                if (s.dcd_trig) {   // update_dcd :275-286 -> dcd_on :244-257
+                    s.dcd_on = 1;
+                    if (s.st == ST_UNLOCKED) {
+                        s.sync_count = 0; s.missing_sync_count = 0;
+                        for (int k = wl; k < 92; k += 64) DL.llr[k] = 0;  // framer.reset()
+                        s.framer_idx = 0;
+                        cd->dec_state = 0;                                 // decoder.reset()
+                        s.evm_S = 0.f;                                     // evm.reset()
+                        wave_lds_sync();
+                    }
+                    s.need_clock_reset = 1;
+                    s.run_pos = 0;  // a new gated run starts with the next sample
+                }
+                s.dcd_trig = nf_dcd_update(cd, tab, tick0, (P.pos0 + te + 1) / TICK - 1, s.dcd_trig);
+                nf_fire_diag(cd, s.dcd_on, 0.f, s.idev, s.offset, s.st != ST_UNLOCKED, s.ck_clock_est, s.sample_index,
+                             s.sync_sample_index, s.ck_sample_index, s.viterbi_cost);
+                s.count = 0;
+            }
+            continue;
+        }
+
+        // ---- bulk chunk: n samples during which the state machine only feeds the correlator (and, inside a frame, slices
+        //      payload symbols at a fixed sample_index) ----------------------------------------------------------------------
+        enum { BULK_NONE, BULK_INIT, BULK_QUIET, BULK_FRAME };
+        int mode = BULK_NONE;
+        uint32_t n = 0, o1 = 0;
+        if (s.run_pos >= 148) {
+            const uint32_t room = min(P.T - t, (uint32_t)WV_YCH);
+            const bool flags = s.need_clock_reset | s.need_clock_update;
+            if (s.initializing) {
+                n = min((uint32_t)s.initializing, room);
+                mode = BULK_INIT;
+            } else {
+                const uint32_t lim = min(room, 960u - s.count);
+                const bool is_sync = s.st == ST_STREAM_SYNC || s.st == ST_PACKET_SYNC || s.st == ST_BERT_SYNC;
+                if (is_sync && !flags) {
+                    if (s.sync_count < 77) { n = min((uint32_t)(77 - s.sync_count), lim); mode = BULK_QUIET; }
+                } else if (s.st == ST_SYNC_WAIT && !flags) {  // do_sync_wait :583-593 only counts until MAX_SYNC_COUNT
+                    if (s.sync_count < 86) { n = min((uint32_t)(86 - s.sync_count), lim); mode = BULK_QUIET; }
+                } else if (s.st == ST_FRAME) {
+                    const uint32_t idx0 = s.ring_pos % 10u;                         // correlator index of sample t
+                    o1 = (s.sample_index + 10u - idx0) % 10u;                       // offset of the first payload symbol
+                    const uint32_t remaining = (368u - s.framer_idx) >> 1;          // symbols until the frame is complete
+                    const uint32_t last = o1 + 10u * (remaining - 1u);              // offset of the completing symbol
+                    n = min(last, lim);                                             // stop before it
+                    if (flags) n = min(n, (10u - idx0) % 10u);                      // and before a pending clock reset/update (index 0)
+                    mode = BULK_FRAME;
+                }
+            }
+            if (n < 4u) mode = BULK_NONE;
+        }
+        if (mode == BULK_FRAME) {
+            // every anti-phase clock_recovery.update() of the chunk (:601-606) must leave sample_index where it is
+            const uint32_t S = s.sample_index, idx0 = s.ring_pos % 10u;
+            const uint32_t a1 = ((S + 5u) % 10u + 10u - idx0) % 10u;  // offset of the first anti-phase sample
+            // (lane l checks anti-phase samples l and l + 64; the chunk is cut before the first one that would move it)
+            for (uint32_t base = a1; base < n; base += 640u) {
+                const uint32_t a = base + 10u * wl;
+                bool bad = false;
+                if (a < n) bad = (uint32_t)(uint8_t)clock_predict(s.ck_sample_est, s.ck_clock_est, s.ck_count + a + 1u) != S;
+                const unsigned long long mask = __ballot(bad);
+                if (mask != 0ull) {
+                    n = base + 10u * (uint32_t)(__ffsll((long long)mask) - 1);
+                    ++n_flip;
+                    break;
+                }
+            }
+            if (n < 4u) mode = BULK_NONE;
+        }
+        if (mode != BULK_NONE) {
+            const unsigned long long b0 = now();
+            for (uint32_t k = wl; k < n; k += 64) ych[k] = yr[t + k];
+            wave_lds_sync();
+            if (mode == BULK_FRAME) {
+                const uint32_t m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;  // payload symbols inside the chunk (<= 96)
+                for (uint32_t k = wl; k < m; k += 64) {
+                    float err;
+                    const float sample = normalise(ych[o1 + 10u * k], err);
+                    e2[k] = (err * err) * alpha;
+                    llr16[(s.framer_idx >> 1) + k] = (uint16_t)slice_llr(sample, edges);
+                }
+                wave_lds_sync();
+                float S = s.evm_S;
+                for (uint32_t k = 0; k < m; ++k) {  // RunningStandardDeviation::capture, sequential
+                    S = S - S * alpha;
+                    S = S + e2[k];
+                }
+                s.evm_S = S;
+                s.framer_idx += 2u * m;
+                {   // the anti-phase updates of the chunk (if any) returned sample_index
+                    const uint32_t a1 = ((s.sample_index + 5u) % 10u + 10u - s.ring_pos % 10u) % 10u;
+                    if (a1 < n) s.ck_sample_index = (int32_t)s.sample_index;
+                }
+            }
+            {   // Correlator::sample x n: the limit IIR is one dependent chain; the ring keeps the last 80 samples
+                float h0 = s.h0, h1 = s.h1, h2 = s.h2;
+                uint32_t k = 0;
+                if (n >= 4u) {
+                    float4 v = *reinterpret_cast<const float4*>(ych);
+                    for (; k + 4 <= n; k += 4) {
+                        const float4 nx = *reinterpret_cast<const float4*>(ych + ((k + 8 <= n) ? k + 4 : k));  // next group in flight
+                        float hn;
+                        hn = iir_advance(fabsf(v.x), h0, h1); h2 = h1; h1 = h0; h0 = hn;
+                        hn = iir_advance(fabsf(v.y), h0, h1); h2 = h1; h1 = h0; h0 = hn;
+                        hn = iir_advance(fabsf(v.z), h0, h1); h2 = h1; h1 = h0; h0 = hn;
+                        hn = iir_advance(fabsf(v.w), h0, h1); h2 = h1; h1 = h0; h0 = hn;
+                        v = nx;
+                    }
+                }
+                for (; k < n; ++k) {
+                    const float hn = iir_advance(fabsf(ych[k]), h0, h1);
+                    h2 = h1; h1 = h0; h0 = hn;
+                }
+                s.h0 = h0; s.h1 = h1; s.h2 = h2;
+                const uint32_t first = n > 80u ? n - 80u : 0u;
+                for (uint32_t o = first + wl; o < n; o += 64) ring[(s.ring_pos + o) % 80u] = ych[o];
+                s.prev_pos = (s.ring_pos + n - 1u) % 80u;
+                s.ring_pos = (s.ring_pos + n) % 80u;
+            }
+            if (mode == BULK_INIT) {
+                s.initializing -= (int32_t)n;
+                s.count = 0;
+                if (s.initializing == 0) nf_snapshot_hist(gs->hist, xr, t + n - 1u);  // the init run ends; the carrier is off
+            } else {
+                s.count += n;
+                s.ck_count += n;
+                if (mode == BULK_QUIET) s.sync_count += (int32_t)n;
+            }
+            wave_lds_sync();
+            t += n;
+            if (mode != BULK_INIT && s.count == 960u) dcd_point_on(t - 1u);
+            ++n_bulk; n_bulk_samples += n;
+            tk_bulk += now() - b0;
+            continue;
+        }
+
+        // ---- one input sample: M17Demodulator::operator() :657-753 -----------------------------------------------------------
+        const unsigned long long c0 = now();
+        ++n_scalar;
+        const uint32_t tt = t;
+        s.count++;
+        float filtered;
+        if (s.run_pos >= 148) {
+            if (tt - look_t >= 64u) {  // refill the look-ahead window: one coalesced load per 64 single-sample steps
+                look_t = tt;
+                if (tt + wl < P.T) ylook[wl] = yr[tt + wl];
+                wave_lds_sync();
+            }
+            filtered = ylook[tt - look_t];
+        } else {
+            filtered = nf_fir_slow(xr, gs->hist, P.taps, tt, s.run_pos, invert);
+        }
+        corr_sample(filtered);
+        wave_lds_sync();
+        if (s.initializing) {
+            --s.initializing;
+            s.count = 0;
+            if (s.initializing == 0) nf_snapshot_hist(gs->hist, xr, tt);
+            ++t;
+            tk_scalar += now() - c0;
+            continue;
+        }
+        if (corr_index() == 0) clock_flags();
+        s.ck_count++;
+        bool decode_due = false;
+        if (s.st <= ST_BERT_SYNC && !(s.st >= ST_STREAM_SYNC && s.sync_count + 1 < 78)) load_r8();  // states that correlate
+        switch (s.st) {
+        case ST_UNLOCKED: {  // do_unlocked :289-342
+            if (s.missing_sync_count < 1920) {
+                s.missing_sync_count += 1;
+                const uint32_t si = sw_step(0);
+                if (sw_updated(0)) {
+                    s.sync_count = 0; s.missing_sync_count = 0; s.need_clock_reset = 1;
+                    dev_reset(); s.sample_index = si; update_values(si);
+                    s.st = ST_LSF_SYNC;
+                }
+                break;
+            }
+            uint32_t si = sw_step(1);
+            int32_t up = sw_updated(1);
+            if (up) {
+                s.sync_count = 86; s.missing_sync_count = 0; s.need_clock_reset = 1;
+                dev_reset(); s.sample_index = si; update_values(si);
+                s.st = ST_FRAME;
+                s.sync_word_type = up < 0 ? 1u : 0u;
+            }
+            si = sw_step(2);
+            up = sw_updated(2);
+            if (up < 0) {
+                s.sync_count = 86; s.missing_sync_count = 0; s.need_clock_reset = 1;
+                dev_reset(); s.sample_index = si; update_values(si);
+                s.st = ST_FRAME;
+                s.sync_word_type = 3u;
+            }
+            break;
+        }
+        case ST_LSF_SYNC: {  // do_lsf_sync :350-411
+            if (corr_index() != s.sample_index) break;
+            float sync_triggered = sw_triggered(0);
+            if ((double)sync_triggered > 0.1) { s.need_clock_update = 1; s.sync_count += 1; break; }
+            sync_triggered = sw_triggered(1);
+            const float bert_triggered = sw_triggered(2);
+            if (bert_triggered < 0.f) {
+                s.missing_sync_count = 0; s.sync_count = 86; s.need_clock_update = 1;
+                update_values(s.sample_index); s.st = ST_FRAME; s.sync_word_type = 3u;
+            } else if ((double)fabsf(sync_triggered) > 0.1) {
+                s.missing_sync_count = 0; s.sync_count = 86; s.need_clock_update = 1;
+                update_values(s.sample_index); s.st = ST_FRAME;
+                s.sync_word_type = sync_triggered > 0.f ? 0u : 1u;
+            } else if (++s.missing_sync_count > 192) {
+                if (s.sync_count >= 10) { s.missing_sync_count = 0; s.need_clock_update = 1; }
+                else { s.sync_count = 0; s.st = ST_UNLOCKED; s.missing_sync_count = 0; s.dcd_trig = 0; }
+            } else {
+                update_values(s.sample_index);
+            }
+            break;
+        }
+        case ST_STREAM_SYNC:   // do_stream_sync :420-482, do_packet_sync :489-530, do_bert_sync :536-574
+        case ST_PACKET_SYNC:
+        case ST_BERT_SYNC: {
+            s.sync_count += 1;
+            if (s.sync_count < 78) break;
+            const uint32_t mode_st = s.st;
+            if (mode_st == ST_STREAM_SYNC && sw_triggered(3) > 0.1f) {
+                s.sync_word_type = 1u; s.st = ST_FRAME; s.eot_flag = 1; s.missing_sync_count = 0;
+                break;
+            }
+            uint32_t si;
+            int32_t up;
+            if (mode_st == ST_STREAM_SYNC) { si = sw_step(1) & 0xFFu; up = sw_updated(1); }
+            else { si = sw_step(2) & 0xFFu; up = sw_updated(2); }
+            const bool hit = (mode_st == ST_PACKET_SYNC) ? (up != 0) : (up < 0);
+            const uint32_t swt = (mode_st == ST_STREAM_SYNC) ? 1u : (mode_st == ST_PACKET_SYNC ? 2u : 3u);
+            if (hit) {
+                s.missing_sync_count = 0; update_values(si);
+                s.sync_word_type = swt; s.st = ST_SYNC_WAIT;
+                if (mode_st == ST_STREAM_SYNC) s.eot_flag = 0;
+            } else if (s.sync_count > 86) {
+                const uint32_t limit = (mode_st == ST_PACKET_SYNC) ? 60u : 80u;
+                if (s.viterbi_cost < limit) {
+                    if (!s.missing_sync_count) s.missing_sync_count = 1;
+                    s.sync_word_type = swt; s.st = ST_FRAME;
+                } else if (mode_st == ST_STREAM_SYNC && s.eot_flag) {
+                    s.st = ST_UNLOCKED; s.dcd_trig = 0;
+                } else if (s.missing_sync_count < 10) {
+                    s.missing_sync_count += 1; s.sync_word_type = swt; s.st = ST_FRAME;
+                } else {
+                    s.st = ST_UNLOCKED; s.dcd_trig = 0;
+                }
+                if (mode_st == ST_STREAM_SYNC) s.eot_flag = 0;
+            }
+            break;
+        }
+        case ST_SYNC_WAIT:  // do_sync_wait :583-593
+            if (s.sync_count < 86) { s.sync_count += 1; break; }
+            s.need_clock_update = 1;
+            s.st = ST_FRAME;
+            break;
+        default: {  // do_frame :596-654
+            const int d = (int)s.sample_index - (int)corr_index();
+            if (abs(d) == 5) {
+                s.ck_sample_index = clock_predict(s.ck_sample_est, s.ck_clock_est, s.ck_count);
+                s.sample_index = (uint32_t)(uint8_t)s.ck_sample_index;
+            } else if (corr_index() == s.sample_index) {
+                float err;
+                const float sample = normalise(filtered, err);
+                s.evm_S = s.evm_S - s.evm_S * alpha;
+                s.evm_S = s.evm_S + (err * err) * alpha;
+                llr16[s.framer_idx >> 1] = (uint16_t)slice_llr(sample, edges);  // llr<float,4> + M17Framer :42-53
+                s.framer_idx += 2;
+                if (s.framer_idx == 368u) {
+                    s.framer_idx = 0;
+                    s.sync_count = 0;
+                    decode_due = true;
+                }
+            }
+            break;
+        }
+        }
+        wave_lds_sync();
+        if (decode_due) {  // decoder(...) and the rest of do_frame (:623-642)
+            const unsigned long long d0 = now();
+            const uint2 r = nf_decode_wave(P.tables, DL, wl, s.sync_word_type, cd, s.viterbi_cost, rec_base, P.rec_cap, c, P.pos0 + tt, P.overflow);
+            s.viterbi_cost = r.x;
+            s.st = (r.y == 1u || r.y == 0u) ? ST_STREAM_SYNC : (r.y == 4u ? ST_BERT_SYNC : ST_PACKET_SYNC);
+            ++n_decode;
+            tk_decode += now() - d0;
+        }
+        if (s.count == 960u) dcd_point_on(tt);
+        ++t;
+        tk_scalar += now() - c0;
+    }
+
+    // ---------------- save state ------------------------------------------------------------------------------
+    wave_lds_sync();
+    gs->hot = s;
+    Diag d = cd->diag;
+    d.demod_state = s.st;
+    d.n_frames = cd->seq;
+    cd->diag = d;
+    wave_lds_sync();
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(cd);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&gs->cold);
+        for (int k = wl; k < WV_COLD_WORDS; k += 64) dst[k] = src[k];
+    }
+    for (int k = wl; k < 80; k += 64) gs->ring[k] = ring[k];
+    for (int k = wl; k < 40; k += 64) gs->sw_samples[k / 10][k % 10] = swsm[k];
+    for (int k = wl; k < 92; k += 64) gs->llr[k] = DL.llr[k];
+    for (int k = wl; k < 8; k += 64) gs->lsf[k] = DL.lsf[k];
+    P.rec_count[c] = cd->n_run;
+    if (P.dbg && wl == 0) {
+        unsigned long long* o = P.dbg + (size_t)c * 8;
+        o[0] = now() - tk0; o[1] = tk_bulk; o[2] = tk_scalar; o[3] = tk_decode;
+        o[4] = n_bulk; o[5] = n_scalar; o[6] = n_bulk_samples; o[7] = n_flip | (n_decode << 32);
+    }
+}
+
+}  // namespace m17

@@ -6,7 +6,9 @@
 #include "m17_common.hpp"
 #include "m17_decode_device.hpp"
 #include "m17_frontend_kernels.hpp"
-#include "m17_seq_kernel.hpp"
+#include "m17_state.hpp"
+#include "m17_wave_kernel.hpp"
+#include "m17_parity_kernels.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -55,6 +57,10 @@ struct m17hip_ctx {
     bool have_run = false;
     bool uploaded = false;
     bool timing = false;
+    uint32_t seq_lanes = 0;    // waves per workgroup in K5 (0 = default)
+    bool profile = false;      // K5 writes per-channel tick counters (tuning knob 1)
+    unsigned long long* dbg = nullptr;  // [maxC][8] diagnostic cycle counters of K5
+    uint32_t dbg_waves = 0;
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> pool;
     double acc_ms[KT_N] = {0};
@@ -186,12 +192,13 @@ __global__ void seq_reset_kernel(SeqState* st, DcdState* ds, uint32_t C)
     for (size_t k = 0; k < sizeof(SeqState) / 4; ++k) w[k] = 0;
     uint32_t* d = reinterpret_cast<uint32_t*>(ds + c);
     for (size_t k = 0; k < sizeof(DcdState) / 4; ++k) d[k] = 0;
-    SeqScalars& s = st[c].sc;
+    Hot& s = st[c].hot;
+    Cold& k = st[c].cold;
     s.run_pos = 148;              // the stream start is exact in ybuf (zero history)
-    kal_reset(s.ck, 0.f);         // KalmanFilter() : reset(0.)
-    kal_reset(s.kmin, 0.f);
-    kal_reset(s.kmax, 0.f);
-    s.dev_reset = 1;              // FreqDevEstimator::reset_ = true
+    kal_reset(k.ck, 0.f);         // KalmanFilter() : reset(0.)
+    kal_reset(k.kmin, 0.f);
+    kal_reset(k.kmax, 0.f);
+    k.dev_reset = 1;              // FreqDevEstimator::reset_ = true
     s.evm_S = 1.0f;               // RunningStandardDeviation::S{1.0}
     s.initializing = 1920;        // M17Demodulator.h:659 (per channel)
     s.st = ST_UNLOCKED;
@@ -276,7 +283,7 @@ int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
 int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
 {
     Timed tm(c, KT_DCD);
-    hipLaunchKernelGGL(dcd_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->dcd_state, c->dcd_table,
+    hipLaunchKernelGGL(dcd_kernel, dim3((C + 31) / 32), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->dcd_state, c->dcd_table,
                        c->ticks_cap, C, T, c->pos, c->coef, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
@@ -333,6 +340,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->tables, sizeof(DecodeTables));
     ALLOC(c->taps, 160 * sizeof(float));
     ALLOC(c->llr_edges, 64 * sizeof(float));
+    ALLOC(c->dbg, C * 8 * sizeof(unsigned long long));
 #undef ALLOC
     {
         DecodeTables* t = new DecodeTables;
@@ -348,7 +356,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
         if (hipMemcpy(c->llr_edges, edges, sizeof(edges), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
     }
     c->coef = build_coef();
-    if (hipFuncSetAttribute((const void*)demod_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_WORDS * 4) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)demod_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, wave_lds_words(8) * 4) != hipSuccess)
         return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (122 + 122 + 16) * 64 * 4) != hipSuccess)
         return fail(M17HIP_EHIP);
@@ -367,7 +375,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     drain_timing(c);
     for (auto e : c->pool) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch};
+                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -478,6 +486,24 @@ int m17hip_viterbi(m17hip_ctx* c, const int8_t* soft_host, uint32_t n, int kind,
     return M17HIP_OK;
 }
 
+int m17hip_slice_llr(m17hip_ctx* c, const float* sym_host, uint32_t rows, uint32_t n, int8_t* llr_host, float* evm_host)
+{
+    if (!c || !sym_host || rows == 0 || n == 0) return M17HIP_EINVAL;
+    const size_t cnt = (size_t)rows * n;
+    const size_t o1 = round_up(cnt * 4, 256), o2 = o1 + round_up(cnt * 2, 256);
+    int r = ensure_scratch(c, o2 + cnt * 4);
+    if (r) return r;
+    char* b = (char*)c->scratch;
+    HIPCHK(c, hipMemcpyAsync(b, sym_host, cnt * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(slice_kernel, dim3((rows + 63) / 64), dim3(64), 0, c->stream, (const float*)b, rows, n, (int8_t*)(b + o1),
+                       (float*)(b + o2), c->llr_edges);
+    HIPCHK(c, hipGetLastError());
+    if (llr_host) HIPCHK(c, hipMemcpyAsync(llr_host, b + o1, cnt * 2, hipMemcpyDeviceToHost, c->stream));
+    if (evm_host) HIPCHK(c, hipMemcpyAsync(evm_host, b + o2, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M17HIP_OK;
+}
+
 int m17hip_decode_frames(m17hip_ctx* c, const int8_t* llr368_host, uint32_t n, const uint8_t* sync_type, uint8_t* state_io,
                          uint8_t* lich_io, uint8_t* lsf_io, int8_t* dep401_io, int64_t* cost_io, m17_frame_rec* recs, uint8_t* nrec)
 {
@@ -546,7 +572,18 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         P.recs = c->recs; P.rec_cap = c->rec_cap; P.rec_count = c->rec_count; P.overflow = c->overflow;
         P.tables = c->tables; P.taps = c->taps; P.llr_edges = c->llr_edges;
         P.C = C; P.T = T; P.pos0 = c->pos; P.flags = flags;
-        hipLaunchKernelGGL(demod_seq_kernel, dim3((C + 63) / 64), dim3(64), SEQ_LDS_WORDS * 4, c->stream, P);
+        // one wave per channel; `seq_lanes` (tuning knob 0) = waves per workgroup
+        const uint32_t wpb = c->seq_lanes ? c->seq_lanes : 4;
+        const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
+        const size_t lds = (size_t)wave_lds_words((int)wpb) * 4;
+        P.dbg = c->profile ? c->dbg : nullptr;
+        c->dbg_waves = c->profile ? C : 0;
+        switch (wpb) {
+        case 1: hipLaunchKernelGGL(demod_wave_kernel<1>, grid, block, lds, c->stream, P); break;
+        case 2: hipLaunchKernelGGL(demod_wave_kernel<2>, grid, block, lds, c->stream, P); break;
+        case 8: hipLaunchKernelGGL(demod_wave_kernel<8>, grid, block, lds, c->stream, P); break;
+        default: hipLaunchKernelGGL(demod_wave_kernel<4>, grid, block, lds, c->stream, P); break;
+        }
     }
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
@@ -615,9 +652,33 @@ int m17hip_frames_fetch(m17hip_ctx* c, m17_frame_rec* recs_host, uint64_t capaci
 int m17hip_diag_fetch(m17hip_ctx* c, m17_diag* diag_host, uint32_t C)
 {
     if (!c || !diag_host || C == 0 || C > c->maxC) return M17HIP_EINVAL;
-    HIPCHK(c, hipMemcpy2DAsync(diag_host, sizeof(Diag), &c->seq_state[0].sc.diag, sizeof(SeqState), sizeof(Diag), C, hipMemcpyDeviceToHost,
+    HIPCHK(c, hipMemcpy2DAsync(diag_host, sizeof(Diag), &c->seq_state[0].cold.diag, sizeof(SeqState), sizeof(Diag), C, hipMemcpyDeviceToHost,
                                c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M17HIP_OK;
+}
+
+int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
+{
+    if (!c) return M17HIP_EINVAL;
+    switch (key) {
+    case 0:  // waves (= channels) per workgroup of the sequential kernel: 0 (default 4), 1, 2, 4 or 8
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return M17HIP_EINVAL;
+        c->seq_lanes = (uint32_t)value;
+        return M17HIP_OK;
+    case 1:  // per-channel tick counters of the sequential kernel on/off (m17hip_debug_counters)
+        c->profile = value != 0;
+        return M17HIP_OK;
+    default: return M17HIP_EINVAL;
+    }
+}
+
+int m17hip_debug_counters(m17hip_ctx* c, uint64_t* host, uint32_t max_waves, uint32_t* waves)
+{
+    if (!c || !host || !waves) return M17HIP_EINVAL;
+    const uint32_t n = std::min(max_waves, c->dbg_waves);
+    HIPCHK(c, hipMemcpy(host, c->dbg, (size_t)n * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    *waves = n;
     return M17HIP_OK;
 }
 

@@ -30,8 +30,8 @@ VITERBI_SHAPES = {0: (488, 240), 1: (296, 144), 2: (420, 206), 3: (402, 197)}
 EXPORTS = [
     "m17hip_strerror", "m17hip_last_hip_error", "m17hip_version", "m17hip_ctx_create", "m17hip_ctx_destroy", "m17hip_set_stream",
     "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_dcd", "m17hip_viterbi",
-    "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
-    "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
+    "m17hip_slice_llr", "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
+    "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
 ]
 
 
@@ -116,7 +116,7 @@ class Context:
 
     def dcd(self, flags=0):
         ticks = self.T // 192
-        sums = np.empty((self.C, ticks, 6, 2), dtype=np.float32)
+        sums = np.empty((self.C, ticks, 2, 6), dtype=np.float32)
         n = C.c_uint32(0)
         self._chk(self.lib.m17hip_dcd(self.h, C.c_uint32(self.C), C.c_uint32(self.T), C.c_uint32(flags), _ptr(sums), C.byref(n)))
         assert n.value == ticks
@@ -130,6 +130,16 @@ class Context:
         cost = np.empty(n, dtype=np.int32)
         self._chk(self.lib.m17hip_viterbi(self.h, _ptr(s), C.c_uint32(n), C.c_int(kind), _ptr(bits), _ptr(cost)))
         return bits, cost
+
+    def slice_llr(self, sym):
+        s = np.ascontiguousarray(sym, dtype=np.float32)
+        if s.ndim == 1:
+            s = s[None, :]
+        rows, n = s.shape
+        llr = np.empty((rows, n, 2), dtype=np.int8)
+        evm = np.empty((rows, n), dtype=np.float32)
+        self._chk(self.lib.m17hip_slice_llr(self.h, _ptr(s), C.c_uint32(rows), C.c_uint32(n), _ptr(llr), _ptr(evm)))
+        return llr, evm
 
     def decode_frames(self, llr368, sync_type, state=None, lich=None, lsf=None, dep401=None, cost=None):
         l = np.ascontiguousarray(llr368, dtype=np.int8).reshape(-1, 368)
@@ -175,6 +185,15 @@ class Context:
         d = np.zeros(n, dtype=DIAG)
         self._chk(self.lib.m17hip_diag_fetch(self.h, _ptr(d), C.c_uint32(n)))
         return d
+
+    def tune(self, key, value):
+        self._chk(self.lib.m17hip_tune(self.h, C.c_int(key), C.c_int64(value)))
+
+    def debug_counters(self, max_waves=4096):
+        buf = np.zeros((max_waves, 8), dtype=np.uint64)
+        n = C.c_uint32(0)
+        self._chk(self.lib.m17hip_debug_counters(self.h, _ptr(buf), C.c_uint32(max_waves), C.byref(n)))
+        return buf[: n.value]
 
     # ---- measurement ---------------------------------------------------------------------------------------------------
     def timing(self, on=True):

@@ -54,7 +54,7 @@ def test_scale_exhaustive(ctx):
         xs = ol.scale(ramp[c])
         for k in (0, 11, 100, 499):
             a = ol.dcd_sums(xs, 192 * k, 192)
-            assert (float(sums[c, k, k % 5, 0]), float(sums[c, k, k % 5, 1])) == (float(a[0]), float(a[1]))
+            assert (float(sums[c, k, 0, k % 5]), float(sums[c, k, 1, k % 5])) == (float(a[0]), float(a[1]))
 
 
 def test_fir_bit_exact_and_ragged(ctx):
@@ -99,13 +99,38 @@ def test_dcd_table_bit_exact(ctx):
         xs = ol.scale(x[c])
         # first update point of the reference: samples [0, 2304)
         a = ol.dcd_sums(xs, 0, 2304)
-        assert (float(sums[c, 11, 5, 0]), float(sums[c, 11, 5, 1])) == (float(a[0]), float(a[1]))
+        assert (float(sums[c, 11, 0, 5]), float(sums[c, 11, 1, 5])) == (float(a[0]), float(a[1]))
         for _ in range(12):
             k = int(rng.integers(12, sums.shape[1]))
             span = int(rng.choice([2, 5, 1, 3]))
             a0 = k - span + 1
             e = ol.dcd_sums(xs, 192 * a0, 192 * span)
-            assert (float(sums[c, k, a0 % 5, 0]), float(sums[c, k, a0 % 5, 1])) == (float(e[0]), float(e[1])), (c, k, span)
+            assert (float(sums[c, k, 0, a0 % 5]), float(sums[c, k, 1, a0 % 5])) == (float(e[0]), float(e[1])), (c, k, span)
+
+
+def test_slicer_and_evm_bit_exact(ctx, golden):
+    """llr<float,4> incl. every float within +-64 ulp of each of the 43 table edges, and the running EVM."""
+    import ctypes as C
+    edges = np.zeros(43, dtype=np.float32); l0 = np.zeros(43, np.int8); l1 = np.zeros(43, np.int8)
+    ol.oracle().m17o_llr_table(ol._p(edges), ol._p(l0), ol._p(l1))
+    near = []
+    for e in edges:
+        v = np.float32(e)
+        lo = v
+        for _ in range(64):
+            lo = np.nextafter(lo, np.float32(-10))
+        cur = lo
+        for _ in range(129):
+            near.append(cur)
+            cur = np.nextafter(cur, np.float32(10))
+    rng = np.random.default_rng(2)
+    sym = np.concatenate([np.array(near, np.float32), golden["llr_in"], rng.normal(0, 2.5, 50000).astype(np.float32),
+                          np.array([np.nan, np.inf, -np.inf, -0.0, 0.0, 3.0, -3.0, 1e-45], np.float32)])
+    sym = np.concatenate([sym, np.zeros((-sym.size) % 8, np.float32)]).reshape(8, -1)
+    llr, evm = ctx.slice_llr(sym)
+    for r in range(8):
+        assert np.array_equal(llr[r].reshape(-1), ol.llr(sym[r])), r
+        assert np.array_equal(evm[r], ol.evm_trace(sym[r], 1), equal_nan=True), r
 
 
 def test_viterbi_bit_exact(ctx, golden):
@@ -220,6 +245,31 @@ def test_full_chain_streaming_chunks_equal_one_shot(ctx):
     got = np.concatenate(parts)
     order = np.lexsort((got["seq"], got["channel"]))
     assert got[order].tobytes() == exp.tobytes()
+
+
+def test_full_chain_ragged_chunks(ctx):
+    """Chunk lengths that are not multiples of 8 / 192 / 1920 (unaligned DCD blocks, FIR tiles, bulk chunks)."""
+    C, T = 32, 40000
+    x = _signals(C, T, seed=31, sigma=700.0)
+    exp, counts, diags = _oracle_records(x)
+    ctx.reset()
+    parts, pos = [], 0
+    for n in (1, 7, 149, 1919, 3841, 9601, 12345, 5000, T):
+        n = min(n, T - pos)
+        if n <= 0:
+            break
+        ctx.upload(x[:, pos: pos + n])
+        ctx.run()
+        parts.append(ctx.frames().copy())
+        pos += n
+    assert pos == T
+    got = np.concatenate(parts)
+    order = np.lexsort((got["seq"], got["channel"]))
+    assert got[order].tobytes() == exp.tobytes()
+    d = ctx.diag()
+    for f in ("dcd", "locked", "sample_index", "viterbi_cost", "n_diag", "demod_state", "n_frames"):
+        assert np.array_equal(d[f], diags[f]), f
+    assert np.array_equal(d["dcd_level"], diags["dcd_level"], equal_nan=True)
 
 
 def test_edge_cases(ctx):
