@@ -131,9 +131,10 @@ int m17hip_diag_fetch(m17hip_ctx* ctx, m17_diag* diag_host, uint32_t channels);
  * (0 = default 4; 1, 2, 4, 8).  key 1: per-channel tick counters of that kernel on/off (m17hip_debug_counters). */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 
-/* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][8] =
+/* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][24] =
  * {total, bulk chunks, single-sample steps, frame decodes} in 10 ns ticks, {#chunks, #single steps, samples in chunks,
- * #chunks cut by a clock move | #decodes << 32}. */
+ * #chunks cut by a clock move | #decodes << 32}, then [8..14] ticks and [16..22] counts of single-sample steps per
+ * DemodState. */
 int m17hip_debug_counters(m17hip_ctx* ctx, uint64_t* host, uint32_t max_waves, uint32_t* waves);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */

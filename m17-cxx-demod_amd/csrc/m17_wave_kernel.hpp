@@ -34,10 +34,14 @@
 
 namespace m17 {
 
-constexpr int WV_YCH = 960;                                             // largest bulk chunk (one DCD period)
-constexpr int WV_TAB_WORDS = 64 + 4 * 244 + 48;                         // per block: llr edges, source maps, lich map
-constexpr int WV_COLD_WORDS = (sizeof(Cold) + 3) / 4;
-constexpr int WV_WAVE_WORDS = 80 + 40 + 92 + 122 + 8 + 8 + WV_YCH + 96 + 64 + WV_COLD_WORDS; // per wave: ring, sync samples, llr, hist, outb, lsf, chunk, evm terms, look-ahead, cold state
+#ifndef M17_WAVE_MINW
+#define M17_WAVE_MINW 4  // waves per SIMD the register budget is sized for (4 = 4096 channels resident at once)
+#endif
+constexpr int WV_WIN = 1024;                                            // LDS window of upcoming matched-filter samples (circular)
+constexpr int WV_PF = 512;                                              // prefetch granule: 8 samples per lane in flight
+constexpr int WV_YCH = 480;                                             // largest bulk chunk (<= WV_PF)
+constexpr int WV_TAB_WORDS = 64 + 4 * 244 + 48 + 152;                   // per block: llr edges, source maps, lich map, FIR taps
+constexpr int WV_WAVE_WORDS = 80 + 40 + 92 + 122 + 8 + 8 + WV_WIN + 96 + 488; // per wave: ring, sync samples, llr, hist, outb, lsf, sample window, evm terms, decoder soft bits
 constexpr int wave_lds_words(int waves_per_block) { return WV_TAB_WORDS + waves_per_block * WV_WAVE_WORDS; }
 
 // M17FrameDecoder::operator() on the wave's completed frame; returns (viterbi_cost, decoder state)
@@ -54,7 +58,7 @@ __device__ __noinline__ uint2 nf_decode_wave(const DecodeTables* tb, DecodeLds L
 }
 
 template <int WPB>
-__global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
+__global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(SeqParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     float* edges = reinterpret_cast<float*>(lds);                        // [64] llr table edges (43 used)
@@ -63,9 +67,14 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
     for (int k = threadIdx.x; k < 43; k += 64 * WPB) edges[k] = P.llr_edges[k];
     for (int k = threadIdx.x; k < 4 * 488; k += 64 * WPB) srcmap[k] = P.tables->src[k / 488][k % 488];
     for (int k = threadIdx.x; k < 96; k += 64 * WPB) lichmap[k] = P.tables->lich_src[k];
+    float* taps = reinterpret_cast<float*>(lichmap + 96);              // [149] RRC taps (slow-FIR patch)
+    for (int k = threadIdx.x; k < NTAPS; k += 64 * WPB) taps[k] = P.taps[k];
     __syncthreads();  // the only block-level barrier: the waves of a block are independent from here on
 
-    const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
+    // the wave index is wave-uniform: tell the compiler, so that the channel's state, pointers and every branch of the state
+    // machine live in scalar registers / scalar branches instead of 64 identical vector copies
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wl = threadIdx.x & 63;
     const uint32_t c = blockIdx.x * WPB + wave;
     if (c >= P.C) return;
     uint32_t* wb = lds + WV_TAB_WORDS + wave * WV_WAVE_WORDS;
@@ -76,11 +85,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
     DL.hist = DL.llr + 92;                                   // [122] Viterbi decisions
     DL.outb = DL.hist + 122;                                 // [8]
     DL.lsf = DL.outb + 8;                                    // [8]   output_buffer.lsf
-    float* ych = reinterpret_cast<float*>(DL.lsf + 8);       // [WV_YCH] chunk of matched-filter samples
-    float* e2 = ych + WV_YCH;                                // [96]  per-symbol EVM terms of a chunk
-    float* ylook = e2 + 96;                                  // [64]  look-ahead window of matched-filter samples for the single-sample path
-    Cold* cd = reinterpret_cast<Cold*>(ylook + 64);          // cold state lives in LDS while the kernel runs
-    DL.soft = reinterpret_cast<int32_t*>(ych);               // the chunk buffer is free while a frame decodes
+    float* ywin = reinterpret_cast<float*>(DL.lsf + 8);      // [WV_WIN] circular window: sample t lives at ywin[t & (WV_WIN-1)]
+    float* e2 = ywin + WV_WIN;                               // [96]  per-symbol EVM terms of a chunk
+    DL.soft = reinterpret_cast<int32_t*>(e2 + 96);           // [488] depunctured soft bits of the frame being decoded
     DL.src = srcmap;
     DL.lich_src = lichmap;
     DL.stride = 1;
@@ -88,26 +95,50 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
 
     const bool invert = P.flags & 1u;
     SeqState* gs = P.state + c;
+    Cold* cd = &gs->cold;  // touched a few times per frame only: stays in global memory
     Hot s = gs->hot;
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&gs->cold);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(cd);
-        for (int k = wl; k < WV_COLD_WORDS; k += 64) dst[k] = src[k];
-    }
     for (int k = wl; k < 80; k += 64) ring[k] = gs->ring[k];
     for (int k = wl; k < 40; k += 64) swsm[k] = gs->sw_samples[k / 10][k % 10];
     for (int k = wl; k < 92; k += 64) DL.llr[k] = gs->llr[k];
     for (int k = wl; k < 8; k += 64) DL.lsf[k] = gs->lsf[k];
     wave_lds_sync();
     cd->n_run = 0;
-    uint32_t look_t = 0x80000000u;  // ylook holds samples [look_t, look_t + 64); this value = "empty"
+    // Sample window: ybuf samples [t, avail) are in LDS; the next WV_PF samples are in flight in registers (pf) so that the
+    // HBM/L2 latency of this channel's row is paid ~WV_PF samples ahead of its use instead of at the head of every step.
+    float pf[WV_PF / 64];
+    bool pf_pending = false;
+    uint32_t avail = 0;
 
     const int16_t* xr = P.x + (size_t)c * P.xpitch + XPRE;
-    const float* yr = P.y + (size_t)c * P.ypitch + YPRE;
+    float* yr = const_cast<float*>(P.y) + (size_t)c * P.ypitch + YPRE;  // K1's output; the first 148 samples of a gated run are patched in place
     const float* tab = P.dcd_table + (size_t)c * P.ticks_cap * 12;
     const uint64_t tick0 = P.pos0 / TICK;
     FrameRec* rec_base = P.recs + (size_t)c * P.rec_cap;
     uint32_t t = 0;  // next sample (relative to this run)
+    auto pf_issue = [&]() {   // start loading [avail, avail + WV_PF): 8 coalesced 256-byte rows
+#pragma unroll
+        for (int k = 0; k < WV_PF / 64; ++k) {
+            const uint32_t i = avail + 64u * k + wl;
+            pf[k] = i < P.T ? yr[i] : 0.f;
+        }
+        pf_pending = true;
+    };
+    auto pf_commit = [&]() {  // the loads issued a whole granule ago have landed: move them into the window
+#pragma unroll
+        for (int k = 0; k < WV_PF / 64; ++k) ywin[(avail + 64u * k + wl) & (WV_WIN - 1)] = pf[k];
+        avail += WV_PF;
+        pf_pending = false;
+        wave_lds_sync();
+    };
+    auto ensure = [&](uint32_t need) {  // make [t, t + need) readable from the window (need <= WV_PF)
+        while (avail < t + need && avail < P.T) {
+            if (!pf_pending) pf_issue();
+            pf_commit();
+            if (avail < P.T) pf_issue();
+        }
+    };
+    auto window_reset = [&](uint32_t t0) { avail = t0; pf_pending = false; };  // after ybuf was patched / the window was used as scratch
+    pf_issue();
 
     // ---------------- wave-uniform helpers ------------------------------------------------------------------------
     auto corr_index = [&]() -> uint32_t { return s.prev_pos % 10u; };
@@ -220,7 +251,37 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
     const bool prof = P.dbg != nullptr;
     auto now = [&]() -> unsigned long long { return prof ? wall_clock64() : 0ull; };
     const unsigned long long tk0 = now();
-    unsigned long long tk_bulk = 0, tk_scalar = 0, tk_decode = 0;
+    unsigned long long tk_bulk = 0, tk_scalar = 0, tk_decode = 0, tk_patch = 0;
+
+    // The first 148 FIR outputs of a gated run still see the tail of the previous run (Q2): recompute them from the
+    // 149-sample snapshot + the run's own samples and patch ybuf in place, 64 outputs at a time, so that every later
+    // read of ybuf is exact.  r0 = samples of the run already fed (> 0 when a run continues from the previous launch).
+    // The first 148 FIR outputs of a gated run still see the tail of the previous run (Q2): recompute them from the
+    // 149-sample snapshot + the run's own samples and patch ybuf in place, 64 outputs at a time, so that every later
+    // read of ybuf is exact.  r0 = samples of the run already fed (> 0 when a run continues from the previous launch).
+    auto patch_run_start = [&](uint32_t t0) {
+        const unsigned long long p0 = now();
+        const int r0 = s.run_pos;
+        const int64_t rs = (int64_t)t0 - r0;                       // relative index of the run's first sample (>= -148)
+        for (int k = wl; k < 149; k += 64) ywin[k] = scale_sample((int)gs->hist[k], invert);
+        for (int k = wl; k < 148; k += 64)
+            if (rs + k < (int64_t)P.T) ywin[149 + k] = scale_sample((int)xr[rs + k], invert);
+        wave_lds_sync();
+        for (int j = r0 + wl; j < 148; j += 64) {
+            if (rs + j >= (int64_t)P.T) break;
+            float acc = 0.f;
+            for (int i = 0; i < NTAPS; ++i) {                      // FirFilter.h:36-40: newest sample first
+                const float p = ywin[149 + j - i] * taps[i];
+                acc = acc + p;
+            }
+            yr[rs + j] = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the patched samples are read back by other lanes of this wave
+        wave_lds_sync();
+        window_reset(t0);
+        tk_patch += now() - p0;
+    };
+    if (s.run_pos < 148 && (s.initializing || s.dcd_on)) patch_run_start(0);
 
     // ---------------- main loop (wave-uniform control flow) ------------------------------------------------------------
     while (t < P.T) {
@@ -229,6 +290,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
             const uint32_t n = min(384u - s.count, P.T - t);
             s.count += n;
             t += n;
+            if (avail < t) window_reset(t);  // skipped samples are never read
             if (s.count == 384u) {
                 const uint32_t te = t - 1;
                 if (s.dcd_trig) {   // update_dcd :275-286 -> dcd_on :244-257
@@ -243,6 +305,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
                     }
                     s.need_clock_reset = 1;
                     s.run_pos = 0;  // a new gated run starts with the next sample
+                    if (t < P.T) patch_run_start(t);
                 }
                 s.dcd_trig = nf_dcd_update(cd, tab, tick0, (P.pos0 + te + 1) / TICK - 1, s.dcd_trig);
                 nf_fire_diag(cd, s.dcd_on, 0.f, s.idev, s.offset, s.st != ST_UNLOCKED, s.ck_clock_est, s.sample_index,
@@ -254,33 +317,42 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
 
         // ---- bulk chunk: n samples during which the state machine only feeds the correlator (and, inside a frame, slices
         //      payload symbols at a fixed sample_index) ----------------------------------------------------------------------
-        enum { BULK_NONE, BULK_INIT, BULK_QUIET, BULK_FRAME };
+        enum { BULK_NONE, BULK_INIT, BULK_QUIET, BULK_FEED, BULK_FRAME };
         int mode = BULK_NONE;
         uint32_t n = 0, o1 = 0;
-        if (s.run_pos >= 148) {
+        bool completes = false;   // the chunk ends on the sample that completes the frame (BULK_FRAME) / leaves SYNC_WAIT (BULK_QUIET)
+        {
             const uint32_t room = min(P.T - t, (uint32_t)WV_YCH);
-            const bool flags = s.need_clock_reset | s.need_clock_update;
             if (s.initializing) {
                 n = min((uint32_t)s.initializing, room);
                 mode = BULK_INIT;
             } else {
-                const uint32_t lim = min(room, 960u - s.count);
+                uint32_t lim = min(room, 960u - s.count);
+                const uint32_t idx0 = s.ring_pos % 10u;  // correlator index of sample t
+                // the index-0 prologue (:695-709) does not depend on the sample values: run it now if sample t is an index-0 sample
+                if (idx0 == 0u && (s.need_clock_reset | s.need_clock_update)) clock_flags();
+                if (s.need_clock_reset | s.need_clock_update) lim = min(lim, 10u - idx0);  // stop before the next index-0 sample
                 const bool is_sync = s.st == ST_STREAM_SYNC || s.st == ST_PACKET_SYNC || s.st == ST_BERT_SYNC;
-                if (is_sync && !flags) {
+                if (is_sync) {
                     if (s.sync_count < 77) { n = min((uint32_t)(77 - s.sync_count), lim); mode = BULK_QUIET; }
-                } else if (s.st == ST_SYNC_WAIT && !flags) {  // do_sync_wait :583-593 only counts until MAX_SYNC_COUNT
-                    if (s.sync_count < 86) { n = min((uint32_t)(86 - s.sync_count), lim); mode = BULK_QUIET; }
+                } else if (s.st == ST_SYNC_WAIT) {  // do_sync_wait :583-593: count up to MAX_SYNC_COUNT, then one transition sample
+                    const uint32_t q = s.sync_count < 86 ? (uint32_t)(86 - s.sync_count) : 0u;
+                    n = min(q + 1u, lim);
+                    completes = n == q + 1u;
+                    mode = BULK_QUIET;
+                } else if (s.st == ST_LSF_SYNC) {   // do_lsf_sync :350-411 acts only where index() == sample_index
+                    n = min((s.sample_index + 10u - idx0) % 10u, lim);
+                    mode = BULK_FEED;
                 } else if (s.st == ST_FRAME) {
-                    const uint32_t idx0 = s.ring_pos % 10u;                         // correlator index of sample t
                     o1 = (s.sample_index + 10u - idx0) % 10u;                       // offset of the first payload symbol
                     const uint32_t remaining = (368u - s.framer_idx) >> 1;          // symbols until the frame is complete
                     const uint32_t last = o1 + 10u * (remaining - 1u);              // offset of the completing symbol
-                    n = min(last, lim);                                             // stop before it
-                    if (flags) n = min(n, (10u - idx0) % 10u);                      // and before a pending clock reset/update (index 0)
+                    n = min(last + 1u, lim);
+                    completes = n == last + 1u;
                     mode = BULK_FRAME;
                 }
             }
-            if (n < 4u) mode = BULK_NONE;
+            if (n < 2u) mode = BULK_NONE;
         }
         if (mode == BULK_FRAME) {
             // every anti-phase clock_recovery.update() of the chunk (:601-606) must leave sample_index where it is
@@ -294,27 +366,35 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
                 const unsigned long long mask = __ballot(bad);
                 if (mask != 0ull) {
                     n = base + 10u * (uint32_t)(__ffsll((long long)mask) - 1);
+                    completes = false;
                     ++n_flip;
                     break;
                 }
             }
-            if (n < 4u) mode = BULK_NONE;
+            if (n < 2u) mode = BULK_NONE;
         }
         if (mode != BULK_NONE) {
             const unsigned long long b0 = now();
-            for (uint32_t k = wl; k < n; k += 64) ych[k] = yr[t + k];
-            wave_lds_sync();
+            ensure(n);
             if (mode == BULK_FRAME) {
                 const uint32_t m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;  // payload symbols inside the chunk (<= 96)
                 for (uint32_t k = wl; k < m; k += 64) {
                     float err;
-                    const float sample = normalise(ych[o1 + 10u * k], err);
+                    const float sample = normalise(ywin[(t + o1 + 10u * k) & (WV_WIN - 1)], err);
                     e2[k] = (err * err) * alpha;
                     llr16[(s.framer_idx >> 1) + k] = (uint16_t)slice_llr(sample, edges);
                 }
                 wave_lds_sync();
                 float S = s.evm_S;
-                for (uint32_t k = 0; k < m; ++k) {  // RunningStandardDeviation::capture, sequential
+                uint32_t k = 0;
+                for (; k + 4 <= m; k += 4) {  // RunningStandardDeviation::capture, sequential
+                    const float4 g = *reinterpret_cast<const float4*>(e2 + k);
+                    S = S - S * alpha; S = S + g.x;
+                    S = S - S * alpha; S = S + g.y;
+                    S = S - S * alpha; S = S + g.z;
+                    S = S - S * alpha; S = S + g.w;
+                }
+                for (; k < m; ++k) {
                     S = S - S * alpha;
                     S = S + e2[k];
                 }
@@ -328,10 +408,15 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
             {   // Correlator::sample x n: the limit IIR is one dependent chain; the ring keeps the last 80 samples
                 float h0 = s.h0, h1 = s.h1, h2 = s.h2;
                 uint32_t k = 0;
-                if (n >= 4u) {
-                    float4 v = *reinterpret_cast<const float4*>(ych);
+                for (; k < n && ((t + k) & 3u); ++k) {  // head: up to a 16-byte boundary of the window
+                    const float hn = iir_advance(fabsf(ywin[(t + k) & (WV_WIN - 1)]), h0, h1);
+                    h2 = h1; h1 = h0; h0 = hn;
+                }
+                if (k + 4 <= n) {
+                    float4 v = *reinterpret_cast<const float4*>(ywin + ((t + k) & (WV_WIN - 1)));
                     for (; k + 4 <= n; k += 4) {
-                        const float4 nx = *reinterpret_cast<const float4*>(ych + ((k + 8 <= n) ? k + 4 : k));  // next group in flight
+                        const uint32_t kn = (k + 8 <= n) ? k + 4 : k;  // next group in flight
+                        const float4 nx = *reinterpret_cast<const float4*>(ywin + ((t + kn) & (WV_WIN - 1)));
                         float hn;
                         hn = iir_advance(fabsf(v.x), h0, h1); h2 = h1; h1 = h0; h0 = hn;
                         hn = iir_advance(fabsf(v.y), h0, h1); h2 = h1; h1 = h0; h0 = hn;
@@ -341,14 +426,15 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
                     }
                 }
                 for (; k < n; ++k) {
-                    const float hn = iir_advance(fabsf(ych[k]), h0, h1);
+                    const float hn = iir_advance(fabsf(ywin[(t + k) & (WV_WIN - 1)]), h0, h1);
                     h2 = h1; h1 = h0; h0 = hn;
                 }
                 s.h0 = h0; s.h1 = h1; s.h2 = h2;
                 const uint32_t first = n > 80u ? n - 80u : 0u;
-                for (uint32_t o = first + wl; o < n; o += 64) ring[(s.ring_pos + o) % 80u] = ych[o];
+                for (uint32_t o = first + wl; o < n; o += 64) ring[(s.ring_pos + o) % 80u] = ywin[(t + o) & (WV_WIN - 1)];
                 s.prev_pos = (s.ring_pos + n - 1u) % 80u;
                 s.ring_pos = (s.ring_pos + n) % 80u;
+                s.run_pos = min(148, s.run_pos + (int32_t)n);
             }
             if (mode == BULK_INIT) {
                 s.initializing -= (int32_t)n;
@@ -357,10 +443,23 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
             } else {
                 s.count += n;
                 s.ck_count += n;
-                if (mode == BULK_QUIET) s.sync_count += (int32_t)n;
+                if (mode == BULK_QUIET) {
+                    if (s.st == ST_SYNC_WAIT && completes) { s.sync_count = 86; s.need_clock_update = 1; s.st = ST_FRAME; }
+                    else s.sync_count += (int32_t)n;
+                }
             }
             wave_lds_sync();
             t += n;
+            if (mode == BULK_FRAME && completes) {  // the last sample of the chunk completed the frame: decoder(...) (:619-642)
+                s.framer_idx = 0;
+                s.sync_count = 0;
+                const unsigned long long d0 = now();
+                const uint2 r = nf_decode_wave(P.tables, DL, wl, s.sync_word_type, cd, s.viterbi_cost, rec_base, P.rec_cap, c, P.pos0 + t - 1u, P.overflow);
+                s.viterbi_cost = r.x;
+                s.st = (r.y == 1u || r.y == 0u) ? ST_STREAM_SYNC : (r.y == 4u ? ST_BERT_SYNC : ST_PACKET_SYNC);
+                ++n_decode;
+                tk_decode += now() - d0;
+            }
             if (mode != BULK_INIT && s.count == 960u) dcd_point_on(t - 1u);
             ++n_bulk; n_bulk_samples += n;
             tk_bulk += now() - b0;
@@ -372,17 +471,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
         ++n_scalar;
         const uint32_t tt = t;
         s.count++;
-        float filtered;
-        if (s.run_pos >= 148) {
-            if (tt - look_t >= 64u) {  // refill the look-ahead window: one coalesced load per 64 single-sample steps
-                look_t = tt;
-                if (tt + wl < P.T) ylook[wl] = yr[tt + wl];
-                wave_lds_sync();
-            }
-            filtered = ylook[tt - look_t];
-        } else {
-            filtered = nf_fir_slow(xr, gs->hist, P.taps, tt, s.run_pos, invert);
-        }
+        ensure(1u);
+        const float filtered = ywin[tt & (WV_WIN - 1)];
         corr_sample(filtered);
         wave_lds_sync();
         if (s.initializing) {
@@ -531,19 +621,14 @@ __global__ __launch_bounds__(64 * WPB, 4) void demod_wave_kernel(SeqParams P)
     d.demod_state = s.st;
     d.n_frames = cd->seq;
     cd->diag = d;
-    wave_lds_sync();
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(cd);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&gs->cold);
-        for (int k = wl; k < WV_COLD_WORDS; k += 64) dst[k] = src[k];
-    }
     for (int k = wl; k < 80; k += 64) gs->ring[k] = ring[k];
     for (int k = wl; k < 40; k += 64) gs->sw_samples[k / 10][k % 10] = swsm[k];
     for (int k = wl; k < 92; k += 64) gs->llr[k] = DL.llr[k];
     for (int k = wl; k < 8; k += 64) gs->lsf[k] = DL.lsf[k];
     P.rec_count[c] = cd->n_run;
     if (P.dbg && wl == 0) {
-        unsigned long long* o = P.dbg + (size_t)c * 8;
+        unsigned long long* o = P.dbg + (size_t)c * 24;
+        o[8] = tk_patch;
         o[0] = now() - tk0; o[1] = tk_bulk; o[2] = tk_scalar; o[3] = tk_decode;
         o[4] = n_bulk; o[5] = n_scalar; o[6] = n_bulk_samples; o[7] = n_flip | (n_decode << 32);
     }

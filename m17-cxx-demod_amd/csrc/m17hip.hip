@@ -340,7 +340,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->tables, sizeof(DecodeTables));
     ALLOC(c->taps, 160 * sizeof(float));
     ALLOC(c->llr_edges, 64 * sizeof(float));
-    ALLOC(c->dbg, C * 8 * sizeof(unsigned long long));
+    ALLOC(c->dbg, C * 24 * sizeof(unsigned long long));
 #undef ALLOC
     {
         DecodeTables* t = new DecodeTables;
@@ -677,7 +677,7 @@ int m17hip_debug_counters(m17hip_ctx* c, uint64_t* host, uint32_t max_waves, uin
 {
     if (!c || !host || !waves) return M17HIP_EINVAL;
     const uint32_t n = std::min(max_waves, c->dbg_waves);
-    HIPCHK(c, hipMemcpy(host, c->dbg, (size_t)n * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(host, c->dbg, (size_t)n * 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     *waves = n;
     return M17HIP_OK;
 }

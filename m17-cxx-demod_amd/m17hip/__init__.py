@@ -190,7 +190,7 @@ class Context:
         self._chk(self.lib.m17hip_tune(self.h, C.c_int(key), C.c_int64(value)))
 
     def debug_counters(self, max_waves=4096):
-        buf = np.zeros((max_waves, 8), dtype=np.uint64)
+        buf = np.zeros((max_waves, 24), dtype=np.uint64)
         n = C.c_uint32(0)
         self._chk(self.lib.m17hip_debug_counters(self.h, _ptr(buf), C.c_uint32(max_waves), C.byref(n)))
         return buf[: n.value]
