@@ -26,7 +26,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # algorithmic HBM bytes per input sample, per kernel and for the whole chain
-ALG_BYTES = {"fir_rrc150": 6.0, "dcd": 2.0 + 48.0 / 192.0, "demod_seq": 4.0 + 64.0 / 1920.0, "compact": 2 * 64.0 / 1920.0}
+ALG_BYTES = {"fir_rrc150": 6.0, "dcd": 2.0 + 48.0 / 192.0, "demod_seq": 4.0 + 48.0 / 192.0 + 64.0 / 1920.0, "compact": 2 * 64.0 / 1920.0}
 CHAIN_BYTES = 2.0 + 64.0 / 1920.0
 
 
@@ -76,20 +76,14 @@ def main():
     rec_cap_total = C * (2 * (T // 1920 + 2) + 4)
     rec_buf = torch.zeros(rec_cap_total * 64, dtype=torch.uint8, device=dev)
 
+    from m17hip import dist as mdist
+
     def gather(n_local):
-        """The only exchange of the path: decoded frame records of every shard to every rank (RCCL all_gather)."""
+        """The only exchange of the path: decoded frame records of every shard to every rank (RCCL all_gather over xGMI)."""
         if world == 1:
             return n_local
-        cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
-        counts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(counts, cnt)
-        nmax = int(max(int(c.item()) for c in counts))
-        if nmax == 0:
-            return 0
-        mine = rec_buf[: nmax * 64]
-        out = torch.empty(world * nmax * 64, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(out, mine)
-        return int(sum(int(c.item()) for c in counts))
+        allrecs, counts = mdist.gather_records(rec_buf, n_local)
+        return int(allrecs.shape[0])
 
     def step():
         ctx.reset()
@@ -149,8 +143,14 @@ def main():
     dom = max((k for k in kern if kern[k]["ms_avg"]), key=lambda k: kern[k]["ms_avg"])
     dom_s = kern[dom]["ms_avg"] / 1e3
     achieved = ALG_BYTES[dom] * C * T / dom_s / 1e9
+    traffic = None  # HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile_round.sh (profiles/)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("channels") == C and tj.get("samples") == T and dom in tj.get("kernels", {}):
+            traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "alg_bytes_per_sample": ALG_BYTES[dom], "kernel_ms": {k: (round(v["ms_avg"], 4) if v["ms_avg"] else None) for k, v in kern.items()},
                 "chain_achieved_GBs": round(CHAIN_BYTES * C * T * args.steps / dt / 1e9 / world, 2),
                 "chain_frac": round(CHAIN_BYTES * C * T * args.steps / dt / 1e9 / world / HBM_PEAK_GBS, 6)}

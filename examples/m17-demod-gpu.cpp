@@ -1,0 +1,43 @@
+// A reference-style demodulator front end on the GPU path: 48 kSPS s16le mono on stdin, one line per frame callback on
+// stdout.  It is written the way apps/m17-demod.cpp drives the reference (construct M17Demodulator<float> with a
+// handle_frame callback, push sample / 41067.0 per sample) — audio (codec2) and the CLI options are out of scope.
+//   g++ -std=c++20 -O2 examples/m17-demod-gpu.cpp -I m17-cxx-demod_amd/include -L m17-cxx-demod_amd -lm17hip -Wl,-rpath,... -o m17-demod-gpu
+#include "m17cxx/M17Demodulator.h"
+
+#include <cstdio>
+#include <iostream>
+
+bool display_lsf = false;  // the reference's M17FrameDecoder.h:19 expects the application to define this
+
+static bool handle_frame(mobilinkd::M17FrameDecoder::output_buffer_t const& frame, int viterbi_cost)
+{
+    using FrameType = mobilinkd::M17FrameDecoder::FrameType;
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    switch (frame.type) {
+    case FrameType::LSF: p = frame.lsf.data(); n = 30; break;
+    case FrameType::LICH: p = frame.lich.data(); n = 6; break;
+    case FrameType::STREAM: p = frame.stream.data(); n = 18; break;
+    case FrameType::BERT: p = frame.bert.data(); n = 25; break;
+    default: p = frame.packet.data(); n = 26; break;
+    }
+    std::printf("%d %d ", (int)frame.type, viterbi_cost);
+    for (size_t i = 0; i < n; ++i) std::printf("%02x", p[i]);
+    std::printf("\n");
+    return true;
+}
+
+int main()
+{
+    using namespace mobilinkd;
+    M17Demodulator<float> demod(handle_frame);
+    demod.diagnostics([](bool, float, float, float, bool, float, int, int, int, int) {});
+    while (std::cin) {
+        int16_t sample;
+        std::cin.read(reinterpret_cast<char*>(&sample), 2);
+        if (!std::cin) break;
+        demod(sample / 41067.0);
+    }
+    demod.flush();
+    return 0;
+}

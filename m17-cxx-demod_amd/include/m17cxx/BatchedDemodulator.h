@@ -1,0 +1,90 @@
+// C++ RAII face of the C ABI (include/m17hip.h) for C independent channels on one GPU.  What the reference does with
+// one M17Demodulator<float> object per channel and one operator() call per sample (apps/m17-demod.cpp:455,484-490),
+// this does with one context and one run() per block of samples.  Errors become std::runtime_error.
+#pragma once
+
+#include "../../../include/m17hip.h"
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mobilinkd
+{
+
+class BatchedDemodulator
+{
+    m17hip_ctx* ctx_ = nullptr;
+    uint32_t channels_ = 0, samples_ = 0;
+
+    static void check(int code, const char* what)
+    {
+        if (code != M17HIP_OK) throw std::runtime_error(std::string(what) + ": " + m17hip_strerror(code));
+    }
+
+public:
+    BatchedDemodulator(uint32_t max_channels, uint32_t max_samples, int device = 0)
+    {
+        check(m17hip_ctx_create(device, max_channels, max_samples, &ctx_), "m17hip_ctx_create");
+    }
+    ~BatchedDemodulator() { m17hip_ctx_destroy(ctx_); }
+    BatchedDemodulator(const BatchedDemodulator&) = delete;
+    BatchedDemodulator& operator=(const BatchedDemodulator&) = delete;
+
+    m17hip_ctx* handle() const { return ctx_; }
+
+    // [channels][samples] int16, row pitch in samples
+    void upload(const int16_t* host, uint32_t channels, uint32_t samples, size_t pitch)
+    {
+        check(m17hip_upload_i16(ctx_, host, channels, samples, pitch), "m17hip_upload_i16");
+        channels_ = channels; samples_ = samples;
+    }
+    void reset() { check(m17hip_demod_reset(ctx_), "m17hip_demod_reset"); }
+    void run(uint32_t flags = 0) { check(m17hip_demod_run(ctx_, channels_, samples_, flags), "m17hip_demod_run"); }
+
+    std::vector<m17_frame_rec> frames()
+    {
+        uint64_t n = 0;
+        check(m17hip_frames_count(ctx_, &n), "m17hip_frames_count");
+        std::vector<m17_frame_rec> out(n ? n : 1);
+        uint64_t got = 0;
+        check(m17hip_frames_fetch(ctx_, out.data(), out.size(), &got), "m17hip_frames_fetch");
+        out.resize(got);
+        return out;
+    }
+    std::vector<m17_diag> diagnostics()
+    {
+        std::vector<m17_diag> d(channels_);
+        check(m17hip_diag_fetch(ctx_, d.data(), channels_), "m17hip_diag_fetch");
+        return d;
+    }
+
+    // batched counterparts of the reference's operators (parity API)
+    std::vector<float> fir(uint32_t flags = 0)  // BaseFirFilter<float,150> with the RRC taps: FirFilter.h:28-43
+    {
+        std::vector<float> y((size_t)channels_ * samples_);
+        check(m17hip_fir_rrc150(ctx_, channels_, samples_, flags, y.data()), "m17hip_fir_rrc150");
+        return y;
+    }
+    void correlator(std::vector<float>& limit, std::vector<float>& corr)  // Correlator::sample/correlate: Correlator.h:43-64
+    {
+        limit.resize((size_t)channels_ * samples_);
+        corr.resize((size_t)4 * channels_ * samples_);
+        check(m17hip_correlator(ctx_, channels_, samples_, limit.data(), corr.data()), "m17hip_correlator");
+    }
+    std::vector<float> dcd_sums(uint32_t flags = 0)  // NSlidingDFT + DataCarrierDetect accumulation: DataCarrierDetect.h:53-58
+    {
+        std::vector<float> s((size_t)channels_ * (samples_ / 192) * 12);
+        uint32_t ticks = 0;
+        check(m17hip_dcd(ctx_, channels_, samples_, flags, s.data(), &ticks), "m17hip_dcd");
+        return s;
+    }
+    // Viterbi<Trellis<4,2>,4>::decode<IN,OUT>: kind 0 = <488,240>, 1 = <296,144>, 2 = <420,206>, 3 = <402,197> (Viterbi.h:162-239)
+    void viterbi(const int8_t* soft, uint32_t n_frames, int kind, uint8_t* bits, int32_t* cost)
+    {
+        check(m17hip_viterbi(ctx_, soft, n_frames, kind, bits, cost), "m17hip_viterbi");
+    }
+};
+
+} // mobilinkd

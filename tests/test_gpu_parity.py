@@ -292,3 +292,18 @@ def test_edge_cases(ctx):
     assert got.tobytes() == exp.tobytes()
     d = ctx.diag()
     assert np.array_equal(d["dcd_level"], diags["dcd_level"], equal_nan=True) and np.isnan(d["dcd_level"][4])
+
+
+def test_cxx_drop_in_demodulator_app():
+    """examples/m17-demod-gpu.cpp drives mobilinkd::M17Demodulator<float> (the mirror header) exactly as apps/m17-demod.cpp
+    drives the reference: its frame callbacks must be the oracle's, in order."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "m17-demod-gpu")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    s = ol.generate(ol.gen_params(seed=5, kind=1, n_frames=12, lead_in=3072, noise_sigma=300.0, tail=4000, tail_sigma=300.0, lead_sigma=40000.0))
+    out = subprocess.run([exe], input=s.tobytes(), capture_output=True, check=True).stdout.decode().split("\n")
+    got = [l for l in out if l.strip()]
+    recs, _ = ol.demod(s)
+    exp = [f"{int(r['frame_type'])} {int(r['cost'])} {bytes(r['payload'][:r['len']]).hex()}" for r in recs]
+    assert got == exp and len(exp) > 3

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round profile on the GPU box: per-kernel durations (rocprofv3 --kernel-trace --stats) and, in SEPARATE passes,
+# the HBM traffic counters (FETCH_SIZE / WRITE_SIZE need 3 + 2 of the 4 TCC slots) and SQ issue/stall counters.
+# Usage (from the repo root, inside gpurun):  bash tools/profile_round.sh r1
+set -u
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 2 --warmup 1 --cpu-seconds 0 --parity-channels 0"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -d $OUT/sq -o sq -- python3 $R/bench.py $ARGS > $OUT/sq.log 2>&1
+for p in trace fetch write sq; do
+  python3 $R/tools/rocpd_summary.py $OUT/$p/${p}_results.db $OUT/${p}_summary.md > /dev/null 2>&1
+  grep -h '"metric"' $OUT/$p.log | head -1 > $OUT/${p}_bench_line.json
+done
+ls -la $OUT
