@@ -41,7 +41,7 @@ constexpr int WV_WIN = 1024;                                            // LDS w
 constexpr int WV_PF = 512;                                              // prefetch granule: 8 samples per lane in flight
 constexpr int WV_YCH = 480;                                             // largest bulk chunk (<= WV_PF)
 constexpr int WV_TAB_WORDS = 64 + 4 * 244 + 48 + 152;                   // per block: llr edges, source maps, lich map, FIR taps
-constexpr int WV_WAVE_WORDS = 80 + 40 + 92 + 122 + 8 + 8 + WV_WIN + 96 + 488; // per wave: ring, sync samples, llr, hist, outb, lsf, sample window, evm terms, decoder soft bits
+constexpr int WV_WAVE_WORDS = 80 + 40 + 92 + 122 + 8 + 8 + WV_WIN + 96 + 488 + 64; // per wave: ring, sync samples, llr, hist, outb, lsf, sample window, evm terms, decoder soft bits, hot state
 constexpr int wave_lds_words(int waves_per_block) { return WV_TAB_WORDS + waves_per_block * WV_WAVE_WORDS; }
 
 // M17FrameDecoder::operator() on the wave's completed frame; returns (viterbi_cost, decoder state)
@@ -88,6 +88,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     float* ywin = reinterpret_cast<float*>(DL.lsf + 8);      // [WV_WIN] circular window: sample t lives at ywin[t & (WV_WIN-1)]
     float* e2 = ywin + WV_WIN;                               // [96]  per-symbol EVM terms of a chunk
     DL.soft = reinterpret_cast<int32_t*>(e2 + 96);           // [488] depunctured soft bits of the frame being decoded
+    Hot* hot_lds = reinterpret_cast<Hot*>(DL.soft + 488);    // [64]  the channel's hot scalars (see below)
+    static_assert(sizeof(Hot) <= 64 * 4, "Hot must fit its LDS slot");
     DL.src = srcmap;
     DL.lich_src = lichmap;
     DL.stride = 1;
@@ -96,7 +98,15 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     const bool invert = P.flags & 1u;
     SeqState* gs = P.state + c;
     Cold* cd = &gs->cold;  // touched a few times per frame only: stays in global memory
-    Hot s = gs->hot;
+    // The hot scalars live in LDS, not in registers: every lane holds the same values anyway, and with a 128-VGPR budget
+    // (4 waves per SIMD) keeping ~45 of them live across the whole loop spills to scratch (= HBM latency); an LDS word is
+    // 64 cycles away and costs no register between uses.
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&gs->hot);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(hot_lds);
+        for (int k = wl; k < (int)(sizeof(Hot) / 4); k += 64) dst[k] = src[k];
+    }
+    Hot& s = *hot_lds;
     for (int k = wl; k < 80; k += 64) ring[k] = gs->ring[k];
     for (int k = wl; k < 40; k += 64) swsm[k] = gs->sw_samples[k / 10][k % 10];
     for (int k = wl; k < 92; k += 64) DL.llr[k] = gs->llr[k];
@@ -616,7 +626,11 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
 
     // ---------------- save state ------------------------------------------------------------------------------
     wave_lds_sync();
-    gs->hot = s;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(hot_lds);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&gs->hot);
+        for (int k = wl; k < (int)(sizeof(Hot) / 4); k += 64) dst[k] = src[k];
+    }
     Diag d = cd->diag;
     d.demod_state = s.st;
     d.n_frames = cd->seq;
