@@ -179,14 +179,58 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
 
 // Wave-cooperative form of the same decoder (one frame per WAVE; used by the one-wave-per-channel demodulator, where
 // a frame completes on one channel at a time): lane l owns trellis state l & 15 (the four 16-lane groups compute the
-// same thing), predecessor metrics come from lanes s>>1 and (s>>1)+8 through ds_bpermute, the 16 decision bits of a
-// step are one ballot.  Columns have stride 1 here (per-wave LDS arrays).  `wl` = lane id in the wave.
+// same thing), the 16 decision bits of a step are one ballot, and the add-compare-select exchanges metrics between lanes
+// with register-to-register lane swaps (see below).  Columns have stride 1 here (per-wave LDS arrays).  `wl` = lane id in the wave.
 __device__ __forceinline__ void wave_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Lane <-> trellis state mapping of the wave decoder.  A 4-bit "position" p lives in lane bits (5,4,1,0) (bits 3,2 number
+// four identical replicas).  Before step h the metric of state s sits at position rotr4(s, h mod 4); the two predecessors
+// j and j+8 of the new states (2j, 2j+1) then differ in position bit 3 - (h mod 4), and the new states land on the SAME two
+// lanes (in-place butterfly).  So every step needs exactly one lane-bit exchange: lane bit 5 (v_permlane32_swap), 4
+// (v_permlane16_swap), 1 or 0 (DPP quad_perm) for h mod 4 = 0, 1, 2, 3 — register-to-register, no LDS round trip.
+__device__ __forceinline__ int vit_pos_of_lane(int wl) { return (wl & 3) | ((wl >> 2) & 12); }
+__device__ __forceinline__ int vit_lane_of_pos(int p) { return (p & 3) | ((p & 12) << 2); }
+__device__ __forceinline__ int rotl4(int v, int r) { r &= 3; return ((v << r) | (v >> (4 - r))) & 15; }
+__device__ __forceinline__ int rotr4(int v, int r) { return rotl4(v, 4 - (r & 3)); }
+
+template <int R>  // R = h mod 4
+__device__ __forceinline__ int32_t vit_partner(int32_t m, int wl)
+{
+    if constexpr (R == 3) return __builtin_amdgcn_update_dpp(m, m, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]: lane ^ 1
+    else if constexpr (R == 2) return __builtin_amdgcn_update_dpp(m, m, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]: lane ^ 2
+    else if constexpr (R == 1) {
+        const auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false);                      // odd rows of [0] <-> even rows of [1]
+        return (wl & 16) ? (int32_t)r[0] : (int32_t)r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(m, m, false, false);                      // upper half of [0] <-> lower half of [1]
+        return (wl & 32) ? (int32_t)r[0] : (int32_t)r[1];
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void vit_step(const DecodeLds& L, int wl, int h, int32_t& m, bool c0neg, bool c1neg, bool bit, uint32_t& prev_bits)
+{
+    const int s0 = L.soft[2 * h], s1 = L.soft[2 * h + 1];
+    const int a = s0 ? abs(-7 - s0) : 0, b = s0 ? abs(7 - s0) : 0;  // |c - s0| for c = -7 / +7; an erased bit costs 0
+    const int d = s1 ? abs(-7 - s1) : 0, e = s1 ? abs(7 - s1) : 0;
+    const int cost0 = (c0neg ? a : b) + (c1neg ? d : e);            // Viterbi.h:190-199 for this lane's butterfly j
+    const int cost1 = (c0neg ? b : a) + (c1neg ? e : d);
+    const int32_t mp = vit_partner<R>(m, wl);
+    const int32_t mj = bit ? mp : m, mj8 = bit ? m : mp;            // this lane held j+8 if its position bit is set
+    const int32_t candA = mj + (bit ? cost1 : cost0);               // m0 / m1 (Viterbi.h:143-146)
+    const int32_t candB = mj8 + (bit ? cost0 : cost1);              // m2 / m3
+    const bool dec = candA > candB;
+    m = dec ? candB : candA;
+    const unsigned long long bal = __ballot(dec);                   // decision of the state now at position p is bit lane_of(p)
+    const uint32_t bits = (uint32_t)(bal & 0xFull) | ((uint32_t)(bal >> 12) & 0xF0u) | ((uint32_t)(bal >> 24) & 0xF00u) | ((uint32_t)(bal >> 36) & 0xF000u);
+    if (h & 1) L.hist[h >> 1] = prev_bits | (bits << 16);
+    else prev_bits = bits;
+}
+
 __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int wl, int kind, int& stale_io)
 {
     const int IN = DEC_IN[kind & 3], OUT = DEC_OUT[kind & 3];
@@ -196,33 +240,36 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
     for (int i = wl; i < IN; i += 64) L.soft[i] = soft_at(L.src, L.llr, 1, 0, kind, i, stale_io);
     wave_lds_sync();
     if ((kind & 3) != 3 && IN > 401) stale_io = L.soft[401];  // this layout writes position 401
-    const int ns = wl & 15, j = ns >> 1, bit = ns & 1;
-    const bool c0neg = j < 4;                         // cost_[j][0] == -7   (polys 031/027)
-    const bool c1neg = (((j ^ (j >> 1)) & 1) == 0);   // cost_[j][1] == -7
-    const int p0 = (wl & 48) + j, p1 = p0 + 8;
-    int32_t m = (ns == 0) ? 0 : MAXM;
-    uint32_t prev_bits = 0;
-    for (int h = 0; h < steps; ++h) {
-        const int s0 = L.soft[2 * h], s1 = L.soft[2 * h + 1];
-        const int a = s0 ? abs(-7 - s0) : 0, b = s0 ? abs(7 - s0) : 0;
-        const int d = s1 ? abs(-7 - s1) : 0, e = s1 ? abs(7 - s1) : 0;
-        const int cost0 = (c0neg ? a : b) + (c1neg ? d : e);   // Viterbi.h:190-199
-        const int cost1 = (c0neg ? b : a) + (c1neg ? e : d);
-        const int32_t mj = __shfl(m, p0), mj8 = __shfl(m, p1);
-        const int32_t candA = mj + (bit ? cost1 : cost0);      // m0 / m1 (Viterbi.h:143-146)
-        const int32_t candB = mj8 + (bit ? cost0 : cost1);     // m2 / m3
-        const bool dec = candA > candB;
-        m = dec ? candB : candA;
-        const uint32_t bits = (uint32_t)(__ballot(dec) & 0xFFFFull);
-        if (h & 1) L.hist[h >> 1] = prev_bits | (bits << 16);
-        else prev_bits = bits;
+    const int pos = vit_pos_of_lane(wl);
+    // per phase r = h mod 4: which butterfly j this lane serves, whether it is the upper lane of its pair (bit), and the
+    // signs of cost_[j] (polys 031/027): cost_[j][0] == -7 <=> j < 4, cost_[j][1] == -7 <=> j in {0,3,4,7}
+    bool c0n[4], c1n[4], bt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int pb = 3 - r;
+        bt[r] = (pos >> pb) & 1;
+        const int j = rotl4(pos & ~(1 << pb), r);
+        c0n[r] = j < 4;
+        c1n[r] = (((j ^ (j >> 1)) & 1) == 0);
     }
+    int32_t m = (pos == 0) ? 0 : MAXM;  // state 0 sits at position 0 before step 0
+    uint32_t prev_bits = 0;
+    int h = 0;
+    for (; h + 4 <= steps; h += 4) {
+        vit_step<0>(L, wl, h, m, c0n[0], c1n[0], bt[0], prev_bits);
+        vit_step<1>(L, wl, h + 1, m, c0n[1], c1n[1], bt[1], prev_bits);
+        vit_step<2>(L, wl, h + 2, m, c0n[2], c1n[2], bt[2], prev_bits);
+        vit_step<3>(L, wl, h + 3, m, c0n[3], c1n[3], bt[3], prev_bits);
+    }
+    if (h < steps) { vit_step<0>(L, wl, h, m, c0n[0], c1n[0], bt[0], prev_bits); ++h; }
+    if (h < steps) { vit_step<1>(L, wl, h, m, c0n[1], c1n[1], bt[1], prev_bits); ++h; }
+    if (h < steps) { vit_step<2>(L, wl, h, m, c0n[2], c1n[2], bt[2], prev_bits); ++h; }
     if (steps & 1) L.hist[steps >> 1] = prev_bits;
-    // end state: first strict minimum scanning 0 -> 15 (Viterbi.h:211-221)
+    // end state: first strict minimum scanning 0 -> 15 (Viterbi.h:211-221); state s now sits at position rotr4(s, steps)
     int best = 0;
-    int32_t best_cost = __shfl(m, 0);
+    int32_t best_cost = __shfl(m, vit_lane_of_pos(rotr4(0, steps)));
     for (int s = 1; s < 16; ++s) {
-        const int32_t v = __shfl(m, s);
+        const int32_t v = __shfl(m, vit_lane_of_pos(rotr4(s, steps)));
         if (v < best_cost) { best_cost = v; best = s; }
     }
     const uint32_t cost = (uint32_t)roundf((float)best_cost / 7.0f);
@@ -241,14 +288,14 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
         const int wi = __builtin_amdgcn_readfirstlane(hi >> 1);
         const uint32_t hw = (wi < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)hw0, wi) : (uint32_t)__builtin_amdgcn_readlane((int)hw1, wi - 64);
         const uint32_t hb = (hi & 1) ? (hw >> 16) : (hw & 0xFFFFu);
-        const uint32_t v = (hb >> state) & 1u;
+        const uint32_t v = (hb >> rotr4((int)state, hi + 1)) & 1u;  // the decision taken when `state` was entered at step hi
         if (index-- <= OUT) {
             --o;
             const int byte = o >> 3;
             word |= (state & 1u) << (8 * (byte & 3) + (7 - (o & 7)));
             if ((o & 31) == 0) { L.outb[byte >> 2] = word; word = 0; }
         }
-        state = (state >> 1) + (v ? 8u : 0u);
+        state = (state >> 1) + (v ? 8u : 0u);  // prevState_[s] = (s>>1, (s>>1)+8)
     }
     wave_lds_sync();
     return cost;

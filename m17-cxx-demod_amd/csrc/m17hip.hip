@@ -32,6 +32,8 @@ struct m17hip_ctx {
     int device = 0;
     int last_hip = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;        // K3 runs here, concurrently with K1
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t maxC = 0, maxT = 0;
     size_t xpitch = 0, ypitch = 0;
     uint32_t ticks_cap = 0, rec_cap = 0;
@@ -150,15 +152,16 @@ hipEvent_t get_event(m17hip_ctx* c)
     hipEventCreate(&e);
     return e;
 }
-struct Timed {
-    m17hip_ctx* c; int which; hipEvent_t a = nullptr, b = nullptr;
-    Timed(m17hip_ctx* ctx, int w) : c(ctx), which(w)
+struct Timed {  // HIP events on the stream the kernel is launched on
+    m17hip_ctx* c; int which; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    Timed(m17hip_ctx* ctx, int w, hipStream_t stream) : c(ctx), which(w), st(stream)
     {
-        if (c->timing) { a = get_event(c); b = get_event(c); hipEventRecord(a, c->stream); }
+        if (c->timing) { a = get_event(c); b = get_event(c); hipEventRecord(a, st); }
     }
+    Timed(m17hip_ctx* ctx, int w) : Timed(ctx, w, ctx->stream) {}
     ~Timed()
     {
-        if (c->timing) { hipEventRecord(b, c->stream); c->pending.push_back({a, b, which}); }
+        if (c->timing) { hipEventRecord(b, st); c->pending.push_back({a, b, which}); }
     }
 };
 void drain_timing(m17hip_ctx* c)
@@ -280,10 +283,10 @@ int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
-int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
+int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st)
 {
-    Timed tm(c, KT_DCD);
-    hipLaunchKernelGGL(dcd_kernel, dim3((C + 31) / 32), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->dcd_state, c->dcd_table,
+    Timed tm(c, KT_DCD, st);
+    hipLaunchKernelGGL(dcd_kernel, dim3((C + 31) / 32), dim3(64), 0, st, c->xbuf, c->xpitch, c->dcd_state, c->dcd_table,
                        c->ticks_cap, C, T, c->pos, c->coef, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
@@ -356,6 +359,9 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
         if (hipMemcpy(c->llr_edges, edges, sizeof(edges), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
     }
     c->coef = build_coef();
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
+    if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)demod_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, wave_lds_words(8) * 4) != hipSuccess)
         return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (122 + 122 + 16) * 64 * 4) != hipSuccess)
@@ -374,6 +380,9 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     if (!c) return;
     drain_timing(c);
     for (auto e : c->pool) hipEventDestroy(e);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->side) hipStreamDestroy(c->side);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
                     c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg};
     for (void* p : ptrs)
@@ -452,7 +461,7 @@ int m17hip_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* sum
     HIPCHK(c, hipMemsetAsync(c->dcd_state, 0, (size_t)C * sizeof(DcdState), c->stream));
     const uint64_t saved = c->pos;
     c->pos = 0;
-    int r = launch_dcd(c, C, T, flags);
+    int r = launch_dcd(c, C, T, flags, c->stream);
     c->pos = saved;
     if (r) return r;
     const uint32_t ticks = T / TICK;
@@ -562,8 +571,13 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     if (!c->uploaded) return M17HIP_ESTATE;
     if (c->have_run && C != c->lastC) return M17HIP_EINVAL;  // a continued stream keeps its channel count
     int r;
+    // K3 (128 latency-bound waves) runs beside K1 (the whole chip) on a side stream; K5 needs both
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    if ((r = launch_dcd(c, C, T, flags, c->side))) return r;
+    HIPCHK(c, hipEventRecord(c->ev_join, c->side));
     if ((r = launch_fir(c, C, T, flags))) return r;
-    if ((r = launch_dcd(c, C, T, flags))) return r;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     {
         Timed tm(c, KT_SEQ);
         SeqParams P{};
