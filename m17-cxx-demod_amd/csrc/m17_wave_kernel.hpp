@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
 
         // ---- bulk chunk: n samples during which the state machine only feeds the correlator (and, inside a frame, slices
         //      payload symbols at a fixed sample_index) ----------------------------------------------------------------------
-        enum { BULK_NONE, BULK_INIT, BULK_QUIET, BULK_FEED, BULK_FRAME };
+        enum { BULK_NONE, BULK_INIT, BULK_QUIET, BULK_FEED, BULK_FRAME, BULK_SEARCH };
         int mode = BULK_NONE;
         uint32_t n = 0, o1 = 0;
         bool completes = false;   // the chunk ends on the sample that completes the frame (BULK_FRAME) / leaves SYNC_WAIT (BULK_QUIET)
@@ -353,6 +353,14 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 } else if (s.st == ST_LSF_SYNC) {   // do_lsf_sync :350-411 acts only where index() == sample_index
                     n = min((s.sample_index + 10u - idx0) % 10u, lim);
                     mode = BULK_FEED;
+                } else if (s.st == ST_UNLOCKED) {   // do_unlocked :289-342 while no sync word is (or becomes) triggered
+                    const bool phase_a = s.missing_sync_count < 1920;
+                    const bool armed = phase_a ? !s.sw_trig[0] : !(s.sw_trig[1] | s.sw_trig[2]);
+                    if (armed) {
+                        n = min(64u, lim);
+                        if (phase_a) n = min(n, (uint32_t)(1920 - s.missing_sync_count));
+                        mode = BULK_SEARCH;
+                    }
                 } else if (s.st == ST_FRAME) {
                     o1 = (s.sample_index + 10u - idx0) % 10u;                       // offset of the first payload symbol
                     const uint32_t remaining = (368u - s.framer_idx) >> 1;          // symbols until the frame is complete
@@ -383,9 +391,68 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             }
             if (n < 2u) mode = BULK_NONE;
         }
+        if (mode == BULK_SEARCH) {
+            // Up to 64 samples of sync-word search at once: the limit IIR is advanced as one chain (its trajectory kept in
+            // LDS), lane k then evaluates SyncWord::triggered (Correlator.h:150-157) for sample k; the samples before the
+            // first one that triggers are committed as quiet, the triggering one goes through the single-sample path.
+            const unsigned long long b0 = now();
+            ensure(n);
+            float* W = reinterpret_cast<float*>(DL.soft);   // [80 + 64] correlator ring in time order, then the new samples
+            float* hb = W + 160;                            // [3 + 64] h0 trajectory: hb[2], hb[1], hb[0] = h0, h1, h2 before the chunk
+            for (uint32_t k = wl; k < 80u; k += 64) W[k] = ring[(s.prev_pos + 1u + k) % 80u];   // oldest first
+            if (wl < n) W[80u + wl] = ywin[(t + wl) & (WV_WIN - 1)];
+            {
+                float h0 = s.h0, h1 = s.h1;
+                hb[0] = s.h2; hb[1] = h1; hb[2] = h0;
+                wave_lds_sync();
+                for (uint32_t k = 0; k < n; ++k) {
+                    const float hn = iir_advance(fabsf(W[80u + k]), h0, h1);
+                    h1 = h0; h0 = hn;
+                    hb[3u + k] = hn;
+                }
+            }
+            wave_lds_sync();
+            const bool phase_a = s.missing_sync_count < 1920;
+            bool hit = false;
+            if (wl < n) {
+                const float lim_k = iir_output(hb[3u + wl], hb[2u + wl], hb[1u + wl]);
+                float r[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r[i] = W[10u + wl + 10u * i];   // samples k-70, k-60, ..., k
+                auto trig = [&](int wd) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const float p = (float)SYNC_WORDS[wd][i] * r[i]; v = v + p; }
+                    return v > lim_k * SW_MAG1[wd] || v < lim_k * SW_MAG2[wd];
+                };
+                hit = phase_a ? trig(0) : (trig(1) || trig(2));
+            }
+            const unsigned long long mask = __ballot(hit);
+            const uint32_t f = mask ? (uint32_t)(__ffsll((long long)mask) - 1) : n;   // leading samples that stay quiet
+            if (f > 0u) {
+                s.h0 = hb[2u + f]; s.h1 = hb[1u + f]; s.h2 = hb[f];
+                const uint32_t first = f > 80u ? f - 80u : 0u;
+                for (uint32_t o = first + wl; o < f; o += 64) ring[(s.ring_pos + o) % 80u] = W[80u + o];
+                s.prev_pos = (s.ring_pos + f - 1u) % 80u;
+                s.ring_pos = (s.ring_pos + f) % 80u;
+                s.run_pos = min(148, s.run_pos + (int32_t)f);
+                s.count += f;
+                s.ck_count += f;
+                if (phase_a) s.missing_sync_count += (int32_t)f;
+                wave_lds_sync();
+                t += f;
+                if (s.count == 960u) dcd_point_on(t - 1u);
+                ++n_bulk; n_bulk_samples += f;
+                tk_bulk += now() - b0;
+                continue;
+            }
+            mode = BULK_NONE;  // the very next sample triggers: single-sample path
+            tk_bulk += now() - b0;
+        }
         if (mode != BULK_NONE) {
             const unsigned long long b0 = now();
             ensure(n);
+
             if (mode == BULK_FRAME) {
                 const uint32_t m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;  // payload symbols inside the chunk (<= 96)
                 for (uint32_t k = wl; k < m; k += 64) {
