@@ -74,7 +74,6 @@ struct SeqParams {
 };
 
 // LDS words for a wave of `ls` channels: ring, sync samples, llr, hist, outb, lsf columns; edges, src maps, lich map
-constexpr int seq_lds_words(int ls) { return (80 + 40 + 92 + 122 + 8 + 8) * ls + 64 + 4 * 244 + 48; }
 
 __device__ __constant__ const float SW_MAG1[4] = {29.f, 31.f, 31.f, 31.f};
 __device__ __constant__ const float SW_MAG2[4] = {-3.402823466e+38f, -31.f, -31.f, -3.402823466e+38f};
@@ -250,18 +249,6 @@ __device__ __noinline__ void nf_fire_diag(Cold* cd, uint32_t dcd_on, float evm_a
     d.sync_index = (int32_t)sync_index; d.clock_index = (int32_t)(uint8_t)clock_index;
     d.viterbi_cost = (int32_t)vcost; d.dcd_level = cd->dcd_level; d.n_diag++;
     cd->diag = d;
-}
-// FIR output for one of the first 148 samples of a gated run (reference a2 under the gating of Q2)
-__device__ __noinline__ float nf_fir_slow(const int16_t* xr, const int16_t* hist, const float* taps, uint32_t tt, int j, bool invert)
-{
-    float acc = 0.f;
-    for (int i = 0; i < NTAPS; ++i) {
-        const int k = j - i;
-        const int sv = k >= 0 ? (int)xr[(int64_t)tt - i] : (int)hist[149 + k];
-        const float p = scale_sample(sv, invert) * taps[i];
-        acc = acc + p;
-    }
-    return acc;
 }
 __device__ __noinline__ void nf_snapshot_hist(int16_t* hist, const int16_t* xr, uint32_t te)
 {
