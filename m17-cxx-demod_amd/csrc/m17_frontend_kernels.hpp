@@ -184,17 +184,24 @@ __global__ __launch_bounds__(64) void limit_kernel(const float* __restrict__ y, 
 // them at the end of every tick: the state machine later picks the sum whose start matches its segment,
 // bit-exact with the reference's single accumulator whatever the cadence turned out to be.
 //
-// A float recurrence is sequential in time, and a lone wave pays ~3 ns per dependent instruction, so the kernel
-// minimises instructions per sample per lane and maximises ILP: TWO LANES PER CHANNEL (lane parity = DFT bin; the
-// two bins and their sums are independent), samples converted once and kept in an LDS delay line (x[n-120] is a
-// ds_read_b128 away), straight-line blocks of 8 samples, next block's 16-byte global load in flight while the
-// current one is consumed.  Table layout: [C][ticks][2 bins][6 sums].
-// Algorithmic bytes: 2 B/sample read (+ 48 B per 192 samples written).
+// A float recurrence is sequential in time and a lone wave pays for every instruction it issues (~3 ns), so the kernel
+// is built around the fewest instructions per sample on the recurrence:
+//   * 16 LANES PER CHANNEL, 4 channels per wave.  Lane role (bin, j): the lane carries DFT bin `bin` (redundantly with
+//     the 7 other lanes of that bin — a VALU instruction costs the same for 1 or 64 lanes) and ONE of the six running
+//     sums, so a sample costs one accumulate instead of six.
+//   * the complex recurrence on packed fp32 (v_pk_mul_f32 / v_pk_add_f32: IEEE mul/add on two floats per instruction,
+//     no contraction): t = Xr + delta; (ac, ad) = (t,t)*(cr,ci); (-bd, bc) = (Xi,Xi)*(-ci,cr); X = (ac + -bd, ad + bc);
+//     (p, q) = X*X; sum += p + q  — 7 VALU instructions per sample.
+//   * the time-parallel part (int16 -> float scaling of x[n] and x[n-120], delta) is done by the 16 lanes for a whole
+//     192-sample tick at once (8-byte loads, issued two ticks ahead of their use) and handed to the recurrence through
+//     LDS.  x[n-120] comes from the carried prefix of xbuf (XPRE >= 120), so there is no delay line to maintain.
+//   * the recurrence runs as straight-line 64-sample blocks in a pinned, software-pipelined issue order.
+// Measured (tools/k3bench.hip): a lone wave issues one VALU instruction per ~2.6 ns whether dependent or not, so the
+// time is instructions x 2.6 ns: 7 per sample on the recurrence + ~1 for conversion = 9.6 ms per 480 000 samples.
+// Sum 5 runs from the stream start (it is read at the first update point, sample 2303, only).
+// Table layout: [C][ticks][2 bins][6 sums].  Algorithmic bytes: 2 B/sample read (+ 48 B per 192 samples written).
 // =====================================================================================================
 struct DcdCoef { float c0r, c0i, c1r, c1i; };  // exp(-j 2 pi f/48000), f = 2400, 3600 — computed on the host
-
-constexpr int DCD_RING = 128;        // delay line length (>= 120), power of two
-constexpr int DCD_RING_PITCH = 132;  // floats per lane: 16-lane groups of ds_*_b128 fall on distinct banks
 
 // apps/m17-demod.cpp:486-489 through the double-precision product (bit-identical to the division for all int16, see
 // tests/test_oracle_kat.py::test_scale_identities_exhaustive); 3 instructions instead of a division expansion.
@@ -204,99 +211,177 @@ __device__ __forceinline__ float scale_sample_mul(int s, bool invert)
     return (float)((double)s * (1.0 / 41067.0));
 }
 
-struct DcdLane {  // one bin of one channel
-    float xr, xi, cr, ci;
-    float acc[6];
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int DCD_BLK = 64;  // samples per straight-line block of the recurrence = 16 lanes x 4
+constexpr int DCD_CPW = 4;   // channels per wave
+
+struct DcdLane {  // one (bin, sum) role of one channel
+    v2f X, cc, cs;  // DFT state (re, im); (cr, ci); (-ci, cr)
+    float acc;
 };
-__device__ __forceinline__ void dcd_step(DcdLane& s, float xn, float xd, bool long_acc)
+__device__ __forceinline__ void dcd_step(DcdLane& s, float delta)
 {
-    const float delta = xn - xd;
-    const float a = s.xr + delta, b = s.xi;
-    const float ac = a * s.cr, bd = b * s.ci, ad = a * s.ci, bc = b * s.cr;
-    s.xr = ac - bd;
-    s.xi = ad + bc;
-    const float nrm = s.xr * s.xr + s.xi * s.xi;
+    const float a = s.X.x + delta;
+    const v2f m1 = v2f{a, a} * s.cc;          // (ac, ad)
+    const v2f m2 = v2f{s.X.y, s.X.y} * s.cs;  // (-bd, bc): negating a factor negates the product exactly
+    s.X = m1 + m2;                            // libstdc++ complex multiply: (ac - bd, ad + bc)
+    const v2f p = s.X * s.X;
+    const float nrm = p.x + p.y;
+    s.acc = s.acc + nrm;
+}
+// N steps as straight-line code in a pinned issue order.  A wave alone on its SIMD waits ~8 ns for the result of the
+// instruction it has just issued but can issue an independent one every ~3 ns, so the three-deep recurrence
+// (add -> mul -> add) is interleaved with the norm / accumulate work of the two previous samples: same operations on
+// the same values in the same order per variable, only the instruction order differs from dcd_step().
+#define M17_PIN() __builtin_amdgcn_sched_barrier(0)
+template <int N>
+__device__ __forceinline__ void dcd_steps_pipelined(DcdLane& s, const float (&d)[N])
+{
+    v2f P = {0.f, 0.f};   // X*X of the previous sample, norm not yet formed
+    float nrm = 0.f;      // norm of the sample before that, not yet accumulated
 #pragma unroll
-    for (int j = 0; j < 5; ++j) s.acc[j] = s.acc[j] + nrm;
-    if (long_acc) s.acc[5] = s.acc[5] + nrm;
+    for (int n = 0; n < N; ++n) {
+        const float a = s.X.x + d[n];                M17_PIN();
+        v2f Pn = P;
+        if (n >= 1) { Pn = s.X * s.X;                M17_PIN(); }
+        const v2f m2 = v2f{s.X.y, s.X.y} * s.cs;     M17_PIN();
+        const v2f m1 = v2f{a, a} * s.cc;             M17_PIN();
+        if (n >= 3) { s.acc = s.acc + nrm;           M17_PIN(); }
+        if (n >= 2) { nrm = P.x + P.y;               M17_PIN(); }
+        s.X = m1 + m2;                               M17_PIN();
+        P = Pn;
+    }
+    // drain: norms of the last samples
+    if (N >= 3) { s.acc = s.acc + nrm; M17_PIN(); }
+    if (N >= 2) { nrm = P.x + P.y; M17_PIN(); }
+    const v2f Pl = s.X * s.X; M17_PIN();
+    if (N >= 2) { s.acc = s.acc + nrm; M17_PIN(); }
+    nrm = Pl.x + Pl.y; M17_PIN();
+    s.acc = s.acc + nrm; M17_PIN();
 }
 
 // pos0: absolute index (since reset) of the first sample of this run — identical for every channel.
+constexpr int DCD_PF = 2;  // whole ticks of input in flight ahead of the recurrence (a tick is ~3 us of recurrence)
 __global__ __launch_bounds__(64) void dcd_kernel(const int16_t* __restrict__ x, size_t xpitch, DcdState* __restrict__ state,
                                                  float* __restrict__ table, uint32_t ticks_cap, uint32_t C, uint32_t T,
                                                  uint64_t pos0, DcdCoef k, uint32_t flags)
 {
-    __shared__ __attribute__((aligned(16))) float ringbuf[64 * DCD_RING_PITCH];
+    __shared__ __attribute__((aligned(16))) float dl[DCD_CPW][TICK];
+    __builtin_amdgcn_s_setprio(3);  // a long dependent chain: issue ahead of the throughput kernels sharing the SIMD
     const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x * 32 + (lane >> 1);
-    const int bin = lane & 1;
-    if (c >= C) return;
+    const int g = lane >> 4, r = lane & 15, bin = r >> 3, j = r & 7;
+    uint32_t c = blockIdx.x * DCD_CPW + g;
+    const bool owner = c < C;
+    const bool live = owner && j < 6;  // lanes that own a sum of an existing channel (the others shadow and never store)
+    if (c >= C) c = C - 1;
     const bool invert = flags & 1u;
     const int16_t* xr = x + (size_t)c * xpitch + XPRE;
-    float* ring = ringbuf + lane * DCD_RING_PITCH;
     DcdState* st = state + c;
     DcdLane s;
-    s.xr = st->xr[bin]; s.xi = st->xi[bin];
-    s.cr = bin ? k.c1r : k.c0r; s.ci = bin ? k.c1i : k.c0i;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) s.acc[q] = st->acc[q][bin];
-    // delay line: the 120 samples before this run (zeros after a reset), at ring slot = absolute index mod 128
-    for (int d = 1; d <= 120; ++d) ring[(uint32_t)(pos0 - d) & (DCD_RING - 1)] = scale_sample_mul(xr[-d], invert);
-    float* tab = table + (size_t)c * ticks_cap * 12 + bin * 6;
+    s.X = v2f{st->xr[bin], st->xi[bin]};
+    s.cc = bin ? v2f{k.c1r, k.c1i} : v2f{k.c0r, k.c0i};
+    s.cs = v2f{-s.cc.y, s.cc.x};
+    s.acc = st->acc[j < 6 ? j : 0][bin];
+    float* tab = table + (size_t)c * ticks_cap * 12 + bin * 6 + j;
+    float* mydl = dl[g];
     uint32_t phase = (uint32_t)(pos0 % TICK);  // position inside the current tick (wave-uniform)
     uint64_t tick = pos0 / TICK;
     uint32_t row = 0;
-
-    auto tick_begin = [&]() {  // start of tick `tick`: the sum that restarts here
-        const int j = (int)(tick % 5);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) s.acc[q] = (q == j) ? 0.f : s.acc[q];
+    auto lds_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    auto tick_end = [&]() {
-        float* o = tab + (size_t)row * 12;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) o[q] = s.acc[q];
+    auto tick_begin = [&] { if ((uint32_t)j == (uint32_t)(tick % 5)) s.acc = 0.f; };  // the sum that restarts with this tick
+    auto tick_end = [&] {
+        if (live) tab[(size_t)row * 12] = s.acc;
         phase = 0; ++tick; ++row;
     };
-    auto one_sample = [&](uint32_t t) {  // generic path (unaligned head / tail of a run)
+    // generic path (head / tail of a run, unaligned runs): up to 64 samples at a time, never across a tick boundary
+    auto slow_block = [&](uint32_t t0, uint32_t n) {
+        float4 dv;
+        float* d4 = &dv.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = 4u * r + q;
+            const bool in = i < n;
+            const int a = in ? (int)xr[(int64_t)t0 + i] : 0, b = in ? (int)xr[(int64_t)t0 + i - 120] : 0;
+            d4[q] = scale_sample_mul(a, invert) - scale_sample_mul(b, invert);
+        }
+        *reinterpret_cast<float4*>(mydl + 4 * r) = dv;
+        lds_sync();
         if (phase == 0) tick_begin();
-        const uint32_t slot = (uint32_t)(pos0 + t) & (DCD_RING - 1);
-        const float xn = scale_sample_mul(xr[t], invert);
-        const float xd = ring[(slot + 8) & (DCD_RING - 1)];
-        ring[slot] = xn;
-        dcd_step(s, xn, xd, pos0 + t < 12 * TICK);
-        if (++phase == TICK) tick_end();
+        for (uint32_t i = 0; i < n; ++i) dcd_step(s, mydl[i]);
+        phase += n;
+        if (phase == TICK) tick_end();
+        lds_sync();
     };
 
     uint32_t t = 0;
-    while (t < T && (((pos0 + t) & 7u) != 0)) { one_sample(t); ++t; }  // head: up to the next multiple of 8
-    if (t + 8 <= T && (pos0 & 7u) == 0) {  // (a run that starts off an 8-sample boundary stays on the generic path)
-        int4 nxt = *reinterpret_cast<const int4*>(xr + t);
-        for (; t + 8 <= T; t += 8) {
-            const int4 cur = nxt;
-            if (t + 16 <= T) nxt = *reinterpret_cast<const int4*>(xr + t + 8);  // in flight while `cur` is consumed
-            if (phase == 0) tick_begin();       // ticks are multiples of 8 samples: boundaries fall between blocks
-            const uint32_t slot = (uint32_t)(pos0 + t) & (DCD_RING - 1);
-            const float4 d0 = *reinterpret_cast<const float4*>(ring + ((slot + 8) & (DCD_RING - 1)));
-            const float4 d1 = *reinterpret_cast<const float4*>(ring + ((slot + 12) & (DCD_RING - 1)));
-            float4 n0, n1;
-            n0.x = scale_sample_mul((int)(int16_t)(cur.x & 0xFFFF), invert); n0.y = scale_sample_mul(cur.x >> 16, invert);
-            n0.z = scale_sample_mul((int)(int16_t)(cur.y & 0xFFFF), invert); n0.w = scale_sample_mul(cur.y >> 16, invert);
-            n1.x = scale_sample_mul((int)(int16_t)(cur.z & 0xFFFF), invert); n1.y = scale_sample_mul(cur.z >> 16, invert);
-            n1.z = scale_sample_mul((int)(int16_t)(cur.w & 0xFFFF), invert); n1.w = scale_sample_mul(cur.w >> 16, invert);
-            *reinterpret_cast<float4*>(ring + slot) = n0;
-            *reinterpret_cast<float4*>(ring + slot + 4) = n1;
-            const bool la = pos0 + t < 12 * TICK;  // the stream-start sum is only ever read at the first update (sample 2303)
-            dcd_step(s, n0.x, d0.x, la); dcd_step(s, n0.y, d0.y, la); dcd_step(s, n0.z, d0.z, la); dcd_step(s, n0.w, d0.w, la);
-            dcd_step(s, n1.x, d1.x, la); dcd_step(s, n1.y, d1.y, la); dcd_step(s, n1.z, d1.z, la); dcd_step(s, n1.w, d1.w, la);
-            phase += 8;
-            if (phase == TICK) tick_end();
+    while (t < T && phase != 0) {  // head: up to the next tick boundary
+        const uint32_t n = min(min(64u, TICK - phase), T - t);
+        slow_block(t, n);
+        t += n;
+    }
+    // whole ticks: lane r of a channel converts samples 4r..4r+3 of each of the tick's three 64-sample blocks (8-byte loads)
+    if (((pos0 + t) & 3u) == 0 && (xpitch & 3u) == 0 && t + TICK <= T) {
+        int2 pa[DCD_PF][3], pb[DCD_PF][3];
+        auto issue = [&](int slot, uint32_t t0) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int16_t* p = xr + (size_t)t0 + 64 * b + 4 * r;
+                pa[slot][b] = *reinterpret_cast<const int2*>(p);
+                pb[slot][b] = *reinterpret_cast<const int2*>(p - 120);
+            }
+        };
+        const uint32_t nt = (T - t) / TICK;
+#pragma unroll
+        for (int q = 0; q < DCD_PF; ++q)
+            if ((uint32_t)q < nt) issue(q, t + q * TICK);
+        auto conv = [&](int v) { return scale_sample_mul(v, invert); };
+        auto lo = [](int w) { return (int)(int16_t)(w & 0xFFFF); };
+        auto hi = [](int w) { return w >> 16; };
+        for (uint32_t it = 0; it < nt; it += DCD_PF) {
+#pragma unroll
+            for (int q = 0; q < DCD_PF; ++q) {
+                if (it + q < nt) {  // wave-uniform
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const int2 a = pa[q][b], d = pb[q][b];
+                        float4 dv;
+                        dv.x = conv(lo(a.x)) - conv(lo(d.x));
+                        dv.y = conv(hi(a.x)) - conv(hi(d.x));
+                        dv.z = conv(lo(a.y)) - conv(lo(d.y));
+                        dv.w = conv(hi(a.y)) - conv(hi(d.y));
+                        *reinterpret_cast<float4*>(mydl + 64 * b + 4 * r) = dv;
+                    }
+                    lds_sync();
+                    if (it + q + DCD_PF < nt) issue(q, t + DCD_PF * TICK);  // this slot's next tick: in flight for DCD_PF ticks
+                    tick_begin();
+#pragma unroll 1
+                    for (int b = 0; b < 3; ++b) {
+                        float d[DCD_BLK];
+#pragma unroll
+                        for (int u = 0; u < DCD_BLK / 4; ++u) {
+                            const float4 v = *reinterpret_cast<const float4*>(mydl + 64 * b + 4 * u);
+                            d[4 * u] = v.x; d[4 * u + 1] = v.y; d[4 * u + 2] = v.z; d[4 * u + 3] = v.w;
+                        }
+                        dcd_steps_pipelined<DCD_BLK>(s, d);
+                    }
+                    tick_end();
+                    lds_sync();
+                    t += TICK;
+                }
+            }
         }
     }
-    for (; t < T; ++t) one_sample(t);  // tail
-    st->xr[bin] = s.xr; st->xi[bin] = s.xi;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) st->acc[q][bin] = s.acc[q];
+    while (t < T) {  // tail (or a whole unaligned run)
+        const uint32_t n = min(min(64u, TICK - phase), T - t);
+        slow_block(t, n);
+        t += n;
+    }
+    if (live) st->acc[j][bin] = s.acc;
+    if (owner && j == 0) { st->xr[bin] = s.X.x; st->xi[bin] = s.X.y; }
 }
 
 }  // namespace m17

@@ -286,7 +286,7 @@ int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
 int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st)
 {
     Timed tm(c, KT_DCD, st);
-    hipLaunchKernelGGL(dcd_kernel, dim3((C + 31) / 32), dim3(64), 0, st, c->xbuf, c->xpitch, c->dcd_state, c->dcd_table,
+    hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW - 1) / DCD_CPW), dim3(64), 0, st, c->xbuf, c->xpitch, c->dcd_state, c->dcd_table,
                        c->ticks_cap, C, T, c->pos, c->coef, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;

@@ -114,9 +114,9 @@ class Context:
         self._chk(self.lib.m17hip_correlator(self.h, C.c_uint32(self.C), C.c_uint32(self.T), _ptr(limit), _ptr(corr)))
         return limit, corr
 
-    def dcd(self, flags=0):
+    def dcd(self, flags=0, fetch=True):
         ticks = self.T // 192
-        sums = np.empty((self.C, ticks, 2, 6), dtype=np.float32)
+        sums = np.empty((self.C, ticks, 2, 6), dtype=np.float32) if fetch else None
         n = C.c_uint32(0)
         self._chk(self.lib.m17hip_dcd(self.h, C.c_uint32(self.C), C.c_uint32(self.T), C.c_uint32(flags), _ptr(sums), C.byref(n)))
         assert n.value == ticks
