@@ -37,8 +37,16 @@ struct DecodeLds {
     const uint16_t* src;       // [kinds][488] soft-bit source maps (LDS copy in K5, global in the stand-alone kernels)
     const uint16_t* lich_src;  // [96]
     int stride;                // lanes per column (= active lanes of the wave)
-    int32_t* soft;             // [488] depunctured soft bits (wave-cooperative decoder only)
+    int32_t* soft;             // [488] branch-cost words of the frame being decoded (wave-cooperative decoder only)
+    unsigned long long* prof;  // optional 100 MHz tick accumulators {depuncture, trellis, chainback} (diagnostics)
 };
+
+// The wave decoder only ever runs on LDS-resident buffers: say so, so that the accesses are ds_* instructions instead of
+// flat ones (DecodeLds carries generic pointers because the stand-alone kernels keep their tables in global memory).
+#define M17_LDS __attribute__((address_space(3)))
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ M17_LDS T* as_lds(T* p) { return (M17_LDS T*)p; }
+template <typename T> __device__ __forceinline__ const M17_LDS T* as_lds(const T* p) { return (const M17_LDS T*)p; }
 
 __device__ __forceinline__ int llr_at(const uint32_t* llr, int stride, int lane, int idx)
 {
@@ -211,93 +219,152 @@ __device__ __forceinline__ int32_t vit_partner(int32_t m, int wl)
     }
 }
 
+// One trellis step.  W (wave-uniform) = the four branch costs of the step, one byte each: (-7,-7) | (-7,+7) << 8 |
+// (+7,-7) << 16 | (+7,+7) << 24 (Viterbi.h:181-200, an erased bit costs 0).  sh = 8 * index of cost_[j] of this lane's
+// butterfly in that word; the complementary cost (Viterbi.h:143-146: m1/m2 use it) sits at 24 - sh.  A lane always adds
+// cost_[j] to its own metric and the complement to its partner's; which of the two sums is "candidate A" depends on
+// whether the lane held state j or j + 8 (`upper`, as a wave mask): dec = A > B, new metric = min (ties: equal values).
 template <int R>
-__device__ __forceinline__ void vit_step(const DecodeLds& L, int wl, int h, int32_t& m, bool c0neg, bool c1neg, bool bit, uint32_t& prev_bits)
+__device__ __forceinline__ uint32_t vit_step(uint32_t W, int wl, int32_t& m, uint32_t sh, unsigned long long upper)
 {
-    const int s0 = L.soft[2 * h], s1 = L.soft[2 * h + 1];
-    const int a = s0 ? abs(-7 - s0) : 0, b = s0 ? abs(7 - s0) : 0;  // |c - s0| for c = -7 / +7; an erased bit costs 0
-    const int d = s1 ? abs(-7 - s1) : 0, e = s1 ? abs(7 - s1) : 0;
-    const int cost0 = (c0neg ? a : b) + (c1neg ? d : e);            // Viterbi.h:190-199 for this lane's butterfly j
-    const int cost1 = (c0neg ? b : a) + (c1neg ? e : d);
+    const int32_t c_own = (int32_t)__builtin_amdgcn_ubfe(W, sh, 8u);
+    const int32_t c_oth = (int32_t)__builtin_amdgcn_ubfe(W, 24u - sh, 8u);
     const int32_t mp = vit_partner<R>(m, wl);
-    const int32_t mj = bit ? mp : m, mj8 = bit ? m : mp;            // this lane held j+8 if its position bit is set
-    const int32_t candA = mj + (bit ? cost1 : cost0);               // m0 / m1 (Viterbi.h:143-146)
-    const int32_t candB = mj8 + (bit ? cost0 : cost1);              // m2 / m3
-    const bool dec = candA > candB;
-    m = dec ? candB : candA;
-    const unsigned long long bal = __ballot(dec);                   // decision of the state now at position p is bit lane_of(p)
-    const uint32_t bits = (uint32_t)(bal & 0xFull) | ((uint32_t)(bal >> 12) & 0xF0u) | ((uint32_t)(bal >> 24) & 0xF00u) | ((uint32_t)(bal >> 36) & 0xF000u);
-    if (h & 1) L.hist[h >> 1] = prev_bits | (bits << 16);
-    else prev_bits = bits;
+    const int32_t own = m + c_own, oth = mp + c_oth;
+    const unsigned long long gt = __ballot(own > oth), lt = __ballot(oth > own);
+    m = min(own, oth);
+    const unsigned long long bal = (gt & ~upper) | (lt & upper);   // decision of the state now at position p is bit lane_of(p)
+    // replica 0 = lanes 0-3, 16-19, 32-35, 48-51 -> a 16-bit decision set spread over bits 0-7 and 16-23 of a word:
+    // position p sits at bit vit_bit_of_pos(p); the odd step of a pair goes 8 bits higher into the same word
+    const unsigned long long rep0 = bal & 0x000F000F000F000Full;
+    return (uint32_t)rep0 | ((uint32_t)(rep0 >> 32) << 4);
 }
+// where the decision of the state at position p sits in a step's decision set (see vit_step)
+__device__ __forceinline__ uint32_t vit_bit_of_pos(uint32_t p) { return (p & 3u) | ((p & 8u) >> 1) | ((p & 4u) << 2); }
 
 __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int wl, int kind, int& stale_io)
 {
     const int IN = DEC_IN[kind & 3], OUT = DEC_OUT[kind & 3];
     const int steps = IN >> 1;
     constexpr int32_t MAXM = 0x7FFFFFFF / 2;
-    // depuncture / deinterleave / derandomise the whole frame once, 64 positions at a time
-    for (int i = wl; i < IN; i += 64) L.soft[i] = soft_at(L.src, L.llr, 1, 0, kind, i, stale_io);
+    const unsigned long long tp0 = L.prof ? wall_clock64() : 0ull;
+    // depuncture / deinterleave / derandomise the whole frame and form the branch-cost word of every trellis step, 64 steps
+    // at a time (lane = step); L.soft[h] = cost word of step h, L.soft[480] = depunctured position 401 (Q4)
+    M17_LDS uint32_t* cw = as_lds(reinterpret_cast<uint32_t*>(L.soft));
+    M17_LDS uint32_t* hist = as_lds(L.hist);
+    M17_LDS uint32_t* outb = as_lds(L.outb);
+    {
+        const M17_LDS uint16_t* src = as_lds(L.src) + kind * 488;
+        const M17_LDS uint32_t* llr = as_lds(L.llr);
+        auto soft = [&](int i) -> int {  // soft_at() on the wave's own LDS frame
+            const uint32_t e = src[i];
+            if (e & 0x8000u) return 0;
+            if (e & 0x4000u) return stale_io;
+            const uint32_t idx = e & 0x1FFu;
+            const int v = (int)(int8_t)(llr[idx >> 2] >> (8 * (idx & 3)));
+            return (e & 0x200u) ? -v : v;
+        };
+        for (int h = wl; h < steps; h += 64) {
+            const int s0 = soft(2 * h), s1 = soft(2 * h + 1);
+            const int a = s0 ? abs(-7 - s0) : 0, b = s0 ? abs(7 - s0) : 0;  // |c - s0| for c = -7 / +7
+            const int d = s1 ? abs(-7 - s1) : 0, e = s1 ? abs(7 - s1) : 0;
+            cw[h] = (uint32_t)(a + d) | ((uint32_t)(a + e) << 8) | ((uint32_t)(b + d) << 16) | ((uint32_t)(b + e) << 24);
+            if (h == 200) cw[480] = (uint32_t)s1;
+        }
+    }
+    for (int h = steps + wl; h < ((steps + 3) & ~3); h += 64) cw[h] = 0;  // the group load below reads whole groups of four
     wave_lds_sync();
-    if ((kind & 3) != 3 && IN > 401) stale_io = L.soft[401];  // this layout writes position 401
+    if ((kind & 3) != 3 && IN > 401) stale_io = (int)cw[480];  // this layout writes position 401
     const int pos = vit_pos_of_lane(wl);
-    // per phase r = h mod 4: which butterfly j this lane serves, whether it is the upper lane of its pair (bit), and the
-    // signs of cost_[j] (polys 031/027): cost_[j][0] == -7 <=> j < 4, cost_[j][1] == -7 <=> j in {0,3,4,7}
-    bool c0n[4], c1n[4], bt[4];
+    // per phase r = h mod 4: which butterfly j this lane serves, whether it is the upper lane of its pair, and where cost_[j]
+    // sits in the cost word (polys 031/027): cost_[j][0] == -7 <=> j < 4, cost_[j][1] == -7 <=> j in {0,3,4,7}
+    uint32_t sh[4];
+    unsigned long long upper[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int pb = 3 - r;
-        bt[r] = (pos >> pb) & 1;
+        upper[r] = __ballot((pos >> pb) & 1);
         const int j = rotl4(pos & ~(1 << pb), r);
-        c0n[r] = j < 4;
-        c1n[r] = (((j ^ (j >> 1)) & 1) == 0);
+        const bool c0neg = j < 4, c1neg = (((j ^ (j >> 1)) & 1) == 0);
+        sh[r] = 8u * ((c0neg ? 0u : 2u) | (c1neg ? 0u : 1u));
     }
     int32_t m = (pos == 0) ? 0 : MAXM;  // state 0 sits at position 0 before step 0
-    uint32_t prev_bits = 0;
-    int h = 0;
-    for (; h + 4 <= steps; h += 4) {
-        vit_step<0>(L, wl, h, m, c0n[0], c1n[0], bt[0], prev_bits);
-        vit_step<1>(L, wl, h + 1, m, c0n[1], c1n[1], bt[1], prev_bits);
-        vit_step<2>(L, wl, h + 2, m, c0n[2], c1n[2], bt[2], prev_bits);
-        vit_step<3>(L, wl, h + 3, m, c0n[3], c1n[3], bt[3], prev_bits);
+    const unsigned long long tp1 = L.prof ? wall_clock64() : 0ull;
+    const int groups = (steps + 3) >> 2;
+    v4u Wn = *reinterpret_cast<const M17_LDS v4u*>(cw);
+    for (int g = 0; g < groups; ++g) {
+        const v4u W = Wn;
+        if (g + 1 < groups) Wn = *reinterpret_cast<const M17_LDS v4u*>(cw + 4 * (g + 1));  // next group in flight
+        const int h = 4 * g;
+        const uint32_t b0 = vit_step<0>(W.x, wl, m, sh[0], upper[0]);
+        int32_t m1 = m, m2, m3;
+        const uint32_t b1 = vit_step<1>(W.y, wl, m1, sh[1], upper[1]);
+        m2 = m1;
+        const uint32_t b2 = vit_step<2>(W.z, wl, m2, sh[2], upper[2]);
+        m3 = m2;
+        const uint32_t b3 = vit_step<3>(W.w, wl, m3, sh[3], upper[3]);
+        // a trailing partial group computes steps that do not exist: keep the metric of the last real step
+        const int left = steps - h;
+        m = left >= 4 ? m3 : (left == 3 ? m2 : (left == 2 ? m1 : m));
+        hist[2 * g] = b0 | (b1 << 8);
+        hist[2 * g + 1] = b2 | (b3 << 8);
     }
-    if (h < steps) { vit_step<0>(L, wl, h, m, c0n[0], c1n[0], bt[0], prev_bits); ++h; }
-    if (h < steps) { vit_step<1>(L, wl, h, m, c0n[1], c1n[1], bt[1], prev_bits); ++h; }
-    if (h < steps) { vit_step<2>(L, wl, h, m, c0n[2], c1n[2], bt[2], prev_bits); ++h; }
-    if (steps & 1) L.hist[steps >> 1] = prev_bits;
+    const unsigned long long tp2 = L.prof ? wall_clock64() : 0ull;
     // end state: first strict minimum scanning 0 -> 15 (Viterbi.h:211-221); state s now sits at position rotr4(s, steps)
     int best = 0;
-    int32_t best_cost = __shfl(m, vit_lane_of_pos(rotr4(0, steps)));
+    int32_t best_cost = __builtin_amdgcn_readlane(m, __builtin_amdgcn_readfirstlane(vit_lane_of_pos(rotr4(0, steps))));
+#pragma unroll
     for (int s = 1; s < 16; ++s) {
-        const int32_t v = __shfl(m, vit_lane_of_pos(rotr4(s, steps)));
+        const int32_t v = __builtin_amdgcn_readlane(m, __builtin_amdgcn_readfirstlane(vit_lane_of_pos(rotr4(s, steps))));
         if (v < best_cost) { best_cost = v; best = s; }
     }
     const uint32_t cost = (uint32_t)roundf((float)best_cost / 7.0f);
     wave_lds_sync();
-    for (int q = wl; q < 8; q += 64) L.outb[q] = 0;
+    for (int q = wl; q < 8; q += 64) outb[q] = 0;
     // decision words into registers: lane l holds words l and l + 64
-    const uint32_t hw0 = L.hist[wl];
-    const uint32_t hw1 = (wl + 64 < 122) ? L.hist[wl + 64] : 0u;
+    const uint32_t hw0 = hist[wl];
+    const uint32_t hw1 = (wl + 64 < 122) ? hist[wl + 64] : 0u;
     wave_lds_sync();
-    uint32_t state = (uint32_t)best;
-    uint32_t word = 0;
+    // chainback (Viterbi.h:226-236) fused with to_byte_array (Util.h:300-318); everything here is wave-uniform (scalar
+    // registers).  It walks in POSITION space: the current state after step hi sits at position P = rotr4(state, hi + 1).
+    // State bit 0 (the decoded bit) is position bit k = -(hi + 1) mod 4, and stepping back to (state >> 1) + 8 v replaces
+    // exactly that position bit by the decision v — no rotation per step.  The walk keeps I = vit_bit_of_pos(P), the bit
+    // index of P's decision inside a decision set; position bit k is bit KB[k] = {0, 1, 4, 2}[k] of I.
+    // The first steps - OUT (= 4) steps are the flush bits and decode nothing.
+    uint32_t I = (uint32_t)__builtin_amdgcn_readfirstlane((int)vit_bit_of_pos((uint32_t)rotr4(best, steps)));
+    uint32_t w = 0;   // decoded bits of the current 32-bit group, newest in bit 0: bit q of the group ends at position q
     int o = OUT;
-    int index = steps;
-    for (int hi = steps; hi > 0 && o > 0;) {
-        --hi;
-        const int wi = __builtin_amdgcn_readfirstlane(hi >> 1);
-        const uint32_t hw = (wi < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)hw0, wi) : (uint32_t)__builtin_amdgcn_readlane((int)hw1, wi - 64);
-        const uint32_t hb = (hi & 1) ? (hw >> 16) : (hw & 0xFFFFu);
-        const uint32_t v = (hb >> rotr4((int)state, hi + 1)) & 1u;  // the decision taken when `state` was entered at step hi
-        if (index-- <= OUT) {
-            --o;
-            const int byte = o >> 3;
-            word |= (state & 1u) << (8 * (byte & 3) + (7 - (o & 7)));
-            if ((o & 31) == 0) { L.outb[byte >> 2] = word; word = 0; }
-        }
-        state = (state >> 1) + (v ? 8u : 0u);  // prevState_[s] = (s>>1, (s>>1)+8)
+    auto fetch = [&](int hi) -> uint32_t {
+        const int wi = hi >> 1;
+        return (wi < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)hw0, wi) : (uint32_t)__builtin_amdgcn_readlane((int)hw1, wi - 64);
+    };
+    auto flush = [&] {   // message bit n -> byte n >> 3, bit 7 - (n & 7); four bytes per little-endian word
+        if ((o & 31) == 0) { outb[o >> 5] = __builtin_bswap32(__builtin_bitreverse32(w)); w = 0; }
+    };
+    int hi = steps - 1;
+    for (int n = 4 + (steps & 3); n > 0; --n, --hi) {  // generic steps down to a multiple of four
+        const uint32_t hw = fetch(hi);
+        const uint32_t k = (uint32_t)(~hi) & 3u;
+        const uint32_t kb = (0x2410u >> (4u * k)) & 15u;
+        const uint32_t v = (hw >> (I + ((uint32_t)(hi & 1) << 3))) & 1u;  // the decision taken when this state was entered at step hi
+        if (hi < OUT) { --o; w = (w << 1) | ((I >> kb) & 1u); flush(); }
+        I = (I & ~(1u << kb)) | (v << kb);
+    }
+    for (; hi >= 3; hi -= 4) {   // hi = 3 (mod 4): k = 0, 1, 2, 3 with constant bit numbers
+        const uint32_t ha = fetch(hi), hb = fetch(hi - 2);
+        uint32_t v;
+        v = (ha >> (I + 8u)) & 1u; w = (w << 1) | (I & 1u);          I = (I & ~1u) | v;           // step hi     (odd)
+        v = (ha >> I) & 1u;        w = (w << 1) | ((I >> 1) & 1u);   I = (I & ~2u) | (v << 1);    // step hi - 1 (even)
+        v = (hb >> (I + 8u)) & 1u; w = (w << 1) | ((I >> 4) & 1u);   I = (I & ~16u) | (v << 4);   // step hi - 2
+        v = (hb >> I) & 1u;        w = (w << 1) | ((I >> 2) & 1u);   I = (I & ~4u) | (v << 2);    // step hi - 3
+        o -= 4;
+        flush();
     }
     wave_lds_sync();
+    if (L.prof && wl == 0) {
+        const unsigned long long tp3 = wall_clock64();
+        L.prof[0] += tp1 - tp0; L.prof[1] += tp2 - tp1; L.prof[2] += tp3 - tp2;
+    }
     return cost;
 }
 

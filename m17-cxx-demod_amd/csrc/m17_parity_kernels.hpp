@@ -45,6 +45,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const int8_t* __restrict__ 
     L.outb = L.hist + 122 * 64;  // [8][64]
     L.lsf = L.outb + 8 * 64;
     L.stride = 64;
+    L.prof = nullptr;
     L.src = &ident->src[0][0];
     L.lich_src = ident->lich_src;
     const int lane = threadIdx.x;
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeFramesParams P)
     L.outb = L.hist + 122 * 64; // [8][64]
     L.lsf = L.outb + 8 * 64;    // [8][64]
     L.stride = 64;
+    L.prof = nullptr;
     L.src = &P.tables->src[0][0];
     L.lich_src = P.tables->lich_src;
     const int lane = threadIdx.x;

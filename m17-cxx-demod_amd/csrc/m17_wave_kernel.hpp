@@ -93,6 +93,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     DL.src = srcmap;
     DL.lich_src = lichmap;
     DL.stride = 1;
+    DL.prof = P.dbg ? P.dbg + (size_t)c * 24 + 9 : nullptr;
+    if (P.dbg && wl < 15) P.dbg[(size_t)c * 24 + 9 + wl] = 0;
     uint16_t* llr16 = reinterpret_cast<uint16_t*>(DL.llr);
 
     const bool invert = P.flags & 1u;

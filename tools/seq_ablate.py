@@ -13,8 +13,8 @@ for wpb in [int(v) for v in sys.argv[3].split(',')]:
     print(f"wpb={wpb} ms: fir={ctx.timing_get('fir_rrc150')[0]:.2f} dcd={ctx.timing_get('dcd')[0]:.2f} seq={ctx.timing_get('demod_seq')[0]:.2f} frames={int(d['n_frames'].sum())}")
     print('   per-channel ticks(10ns) median: total %.3g bulk %.3g scalar %.3g decode %.3g | n_bulk %d n_scalar %d bulk_samples %d flips %d decodes %d | max total %.3g'
           % (m[0], m[1], m[2], m[3], m[4], m[5], m[6], int(m[7]) & 0xFFFFFFFF, int(m[7]) >> 32, mx[0]), flush=True)
+    print('   decode sections per frame (us, median channel): depuncture %.1f trellis %.1f chainback %.1f | whole decode %.1f' % tuple(m[k] / max(int(m[7]) >> 32, 1) / 100 for k in (9, 10, 11, 3)), flush=True)
     tot = dc.sum(axis=0)
-    print('   single-sample steps by state (all channels): ' + ' '.join(f'st{q}: n={int(tot[16+q])} us/step={tot[8+q]/max(tot[16+q],1)/100:.2f}' for q in range(7)), flush=True)
     order = np.argsort(-dc[:, 0])
     print('   slowest channels: ' + ' | '.join(f"ch{int(i)} tot={dc[i,0]/1e5:.1f}ms bulk={dc[i,1]/1e5:.1f} scal={dc[i,2]/1e5:.1f} dec={dc[i,3]/1e5:.1f} nb={int(dc[i,4])} ns={int(dc[i,5])} fl={int(dc[i,7])&0xFFFFFFFF} nd={int(dc[i,7])>>32} frames={int(d['n_frames'][i])} st={int(d['demod_state'][i])}" for i in order[:6]))
     pct = np.percentile(dc[:, 0], [50, 90, 99, 100]) / 1e5
