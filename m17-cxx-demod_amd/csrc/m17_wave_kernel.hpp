@@ -57,7 +57,9 @@ __device__ __noinline__ uint2 nf_decode_wave(const DecodeTables* tb, DecodeLds L
     return make_uint2(cost, D.state);
 }
 
-template <int WPB>
+// PROF: compile the 100 MHz section timers and counters in (diagnostics, tools/seq_ablate.py); the production
+// instantiation carries none of them.
+template <int WPB, bool PROF = false>
 __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(SeqParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -93,8 +95,11 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     DL.src = srcmap;
     DL.lich_src = lichmap;
     DL.stride = 1;
-    DL.prof = P.dbg ? P.dbg + (size_t)c * 24 + 9 : nullptr;
-    if (P.dbg && wl < 15) P.dbg[(size_t)c * 24 + 9 + wl] = 0;
+    DL.prof = nullptr;
+    if constexpr (PROF) {
+        DL.prof = P.dbg + (size_t)c * 24 + 9;
+        if (wl < 15) P.dbg[(size_t)c * 24 + 9 + wl] = 0;
+    }
     uint16_t* llr16 = reinterpret_cast<uint16_t*>(DL.llr);
 
     const bool invert = P.flags & 1u;
@@ -260,8 +265,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     };
 
     unsigned long long n_bulk = 0, n_bulk_samples = 0, n_scalar = 0, n_flip = 0, n_decode = 0;
-    const bool prof = P.dbg != nullptr;
-    auto now = [&]() -> unsigned long long { return prof ? wall_clock64() : 0ull; };
+    auto now = [&]() -> unsigned long long { if constexpr (PROF) return wall_clock64(); else return 0ull; };
     const unsigned long long tk0 = now();
     unsigned long long tk_bulk = 0, tk_scalar = 0, tk_decode = 0, tk_patch = 0;
 
@@ -405,11 +409,12 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             if (wl < n) W[80u + wl] = ywin[(t + wl) & (WV_WIN - 1)];
             {
                 float h0 = s.h0, h1 = s.h1;
+                float m2 = IirCoef::a2 * h1;
                 hb[0] = s.h2; hb[1] = h1; hb[2] = h0;
                 wave_lds_sync();
                 for (uint32_t k = 0; k < n; ++k) {
-                    const float hn = iir_advance(fabsf(W[80u + k]), h0, h1);
-                    h1 = h0; h0 = hn;
+                    const float hn = iir_advance_pk(fabsf(W[80u + k]), h0, m2);
+                    h0 = hn;
                     hb[3u + k] = hn;
                 }
             }
@@ -486,9 +491,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             }
             {   // Correlator::sample x n: the limit IIR is one dependent chain; the ring keeps the last 80 samples
                 float h0 = s.h0, h1 = s.h1, h2 = s.h2;
+                float m2 = IirCoef::a2 * h1;   // a2 * (second-newest history value), carried by iir_advance_pk
                 uint32_t k = 0;
                 for (; k < n && ((t + k) & 3u); ++k) {  // head: up to a 16-byte boundary of the window
-                    const float hn = iir_advance(fabsf(ywin[(t + k) & (WV_WIN - 1)]), h0, h1);
+                    const float hn = iir_advance_pk(fabsf(ywin[(t + k) & (WV_WIN - 1)]), h0, m2);
                     h2 = h1; h1 = h0; h0 = hn;
                 }
                 if (k + 4 <= n) {
@@ -497,15 +503,15 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                         const uint32_t kn = (k + 8 <= n) ? k + 4 : k;  // next group in flight
                         const float4 nx = *reinterpret_cast<const float4*>(ywin + ((t + kn) & (WV_WIN - 1)));
                         float hn;
-                        hn = iir_advance(fabsf(v.x), h0, h1); h2 = h1; h1 = h0; h0 = hn;
-                        hn = iir_advance(fabsf(v.y), h0, h1); h2 = h1; h1 = h0; h0 = hn;
-                        hn = iir_advance(fabsf(v.z), h0, h1); h2 = h1; h1 = h0; h0 = hn;
-                        hn = iir_advance(fabsf(v.w), h0, h1); h2 = h1; h1 = h0; h0 = hn;
+                        hn = iir_advance_pk(fabsf(v.x), h0, m2); h2 = h1; h1 = h0; h0 = hn;
+                        hn = iir_advance_pk(fabsf(v.y), h0, m2); h2 = h1; h1 = h0; h0 = hn;
+                        hn = iir_advance_pk(fabsf(v.z), h0, m2); h2 = h1; h1 = h0; h0 = hn;
+                        hn = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = hn;
                         v = nx;
                     }
                 }
                 for (; k < n; ++k) {
-                    const float hn = iir_advance(fabsf(ywin[(t + k) & (WV_WIN - 1)]), h0, h1);
+                    const float hn = iir_advance_pk(fabsf(ywin[(t + k) & (WV_WIN - 1)]), h0, m2);
                     h2 = h1; h1 = h0; h0 = hn;
                 }
                 s.h0 = h0; s.h1 = h1; s.h2 = h2;
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     for (int k = wl; k < 92; k += 64) gs->llr[k] = DL.llr[k];
     for (int k = wl; k < 8; k += 64) gs->lsf[k] = DL.lsf[k];
     P.rec_count[c] = cd->n_run;
-    if (P.dbg && wl == 0) {
+    if constexpr (PROF) if (wl == 0) {
         unsigned long long* o = P.dbg + (size_t)c * 24;
         o[8] = tk_patch;
         o[0] = now() - tk0; o[1] = tk_bulk; o[2] = tk_scalar; o[3] = tk_decode;

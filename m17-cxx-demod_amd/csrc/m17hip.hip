@@ -587,12 +587,13 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         P.tables = c->tables; P.taps = c->taps; P.llr_edges = c->llr_edges;
         P.C = C; P.T = T; P.pos0 = c->pos; P.flags = flags;
         // one wave per channel; `seq_lanes` (tuning knob 0) = waves per workgroup
-        const uint32_t wpb = c->seq_lanes ? c->seq_lanes : 4;
+        const uint32_t wpb = (c->seq_lanes && !c->profile) ? c->seq_lanes : 4;  // the profiling build exists for 4 waves per workgroup
         const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
         const size_t lds = (size_t)wave_lds_words((int)wpb) * 4;
         P.dbg = c->profile ? c->dbg : nullptr;
         c->dbg_waves = c->profile ? C : 0;
-        switch (wpb) {
+        if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P);
+        else switch (wpb) {
         case 1: hipLaunchKernelGGL(demod_wave_kernel<1>, grid, block, lds, c->stream, P); break;
         case 2: hipLaunchKernelGGL(demod_wave_kernel<2>, grid, block, lds, c->stream, P); break;
         case 8: hipLaunchKernelGGL(demod_wave_kernel<8>, grid, block, lds, c->stream, P); break;
