@@ -128,7 +128,8 @@ int m17hip_frames_compact_device(m17hip_ctx* ctx, m17_frame_rec* recs_dev, uint6
 int m17hip_diag_fetch(m17hip_ctx* ctx, m17_diag* diag_host, uint32_t channels);
 
 /* Tuning knobs (performance only, never results).  key 0: waves (= channels) per workgroup of the sequential kernel
- * (0 = default 4; 1, 2, 4, 8).  key 1: per-channel tick counters of that kernel on/off (m17hip_debug_counters). */
+ * (0 = default 4; 1, 2, 4, 8).  key 1: per-channel tick counters of that kernel on/off (m17hip_debug_counters).
+ * key 2: run the correlator's limit filter ahead of the sequential kernel (default 1) or inside it (0). */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 
 /* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][24] =
@@ -141,7 +142,8 @@ int m17hip_debug_counters(m17hip_ctx* ctx, uint64_t* host, uint32_t max_waves, u
 /* When enabled, every kernel launch of the context is bracketed by HIP events on the context's stream. */
 int m17hip_timing_enable(m17hip_ctx* ctx, int on);
 /* Accumulated device time (ms) and launch count per kernel since the last m17hip_timing_reset:
- * which: 0 = fir_rrc150, 1 = dcd, 2 = demod_seq, 3 = viterbi/decode_frames, 4 = correlator, 5 = compaction. */
+ * which: 0 = fir_rrc150, 1 = dcd, 2 = demod_seq, 3 = viterbi/decode_frames, 4 = correlator, 5 = compaction,
+ * 6 = limit_track (the limit filter run ahead of demod_seq). */
 int m17hip_timing_get(m17hip_ctx* ctx, int which, double* total_ms, uint64_t* launches);
 int m17hip_timing_reset(m17hip_ctx* ctx);
 

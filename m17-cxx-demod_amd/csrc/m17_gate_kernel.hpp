@@ -1,0 +1,248 @@
+// K2: limit_track_kernel — the correlator's limit filter (reference a4: Correlator::sample, Correlator.h:43-49,
+// BaseIirFilter<float,3>, IirFilter.h:26-42) run AHEAD of the state machine.
+//
+// The limit IIR is a float recurrence over every sample the correlator is fed: 3 dependent VALU instructions per
+// sample that cannot be parallelised in time, and in K5 (one wave per channel) they cost a whole wave instruction
+// each — 43 % of K5's time.  Which samples are fed is decided by the carrier-detect gate, and the gate
+// follows the DCD table (K3) alone EXCEPT when the demodulator forces dcd.unlock() after losing sync
+// (M17Demodulator.h:396-404, 470-478 ...).  So this kernel replays the gate from the table under the assumption "no
+// forced unlock happens in this run", advances the IIR over exactly the samples the gate lets through — FOUR CHANNELS
+// PER WAVE instruction — and leaves the filter history after every fed sample in hbuf.  K5 starts every run trusting
+// hbuf; the moment it forces an unlock while the gate trigger was set it drops the speculation for the rest of the
+// run, picks the filter state up from hbuf at that sample and carries the recurrence itself (the pre-existing path).
+// Every run starts from K5's own saved state, so a dropped speculation never outlives its run.
+//
+// Indexing: hbuf[c][YPRE + t] = h0 after sample t was fed (same pitch and prefix as ybuf).  Where a gated run starts
+// the three slots before its first sample are overwritten with the history the run inherits (h0, h1, h2 of the
+// previous run's end), so that for EVERY fed sample t: (hbuf[t], hbuf[t-1], hbuf[t-2]) is the filter history.
+// The first 148 matched-filter outputs of a run see the previous run's tail (Q2): they are recomputed here exactly
+// as K5's patch_run_start does, into LDS only — ybuf is never written by this kernel.
+//
+// Mapping: 16 lanes per channel, 4 channels per wave: loads, stores and the FIR patch are cooperative, the recurrence
+// itself runs on lane 0 of each 16-lane group.
+#pragma once
+
+#include "m17_common.hpp"
+#include "m17_decode_device.hpp"
+#include "m17_frontend_kernels.hpp"
+#include "m17_state.hpp"
+
+namespace m17 {
+
+struct GateParams {
+    const int16_t* x;
+    size_t xpitch;
+    const float* y;           // K1 output, read-only here
+    size_t ypitch;
+    float* h;                 // hbuf, same pitch as y
+    const float* dcd_table;   // [C][ticks_cap][12]
+    uint32_t ticks_cap;
+    const SeqState* state;    // K5's state at the end of the previous run (authoritative start of the replay)
+    float* final_h;           // [C][4]: h0, h1, h2 after the last fed sample of this run
+    const float* taps;        // 149 floats
+    uint32_t C, T;
+    uint64_t pos0;            // absolute index of sample 0 of this (segment of a) run
+    uint64_t tick_row0;       // absolute tick stored in row 0 of the DCD table
+    uint32_t flags;
+};
+
+constexpr int GT_CPW = 4;  // channels per wave
+
+__global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
+{
+    __shared__ __attribute__((aligned(16))) float yl[GT_CPW][TICK];   // matched-filter samples of the current piece
+    __shared__ __attribute__((aligned(16))) float hl[GT_CPW][TICK];   // h0 after each of them
+    __shared__ float pl[GT_CPW][148];                                   // patched first outputs of the current run
+    __shared__ float pw[298];                                           // patch window: 149 snapshot + 148 run samples
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, r = lane & 15;
+    uint32_t c = blockIdx.x * GT_CPW + g;
+    const bool valid = c < P.C;
+    if (!valid) c = P.C - 1;  // shadow the last channel, never store
+    const bool invert = P.flags & 1u;
+    const SeqState* gs = P.state + c;
+    const int16_t* xr = P.x + (size_t)c * P.xpitch + XPRE;
+    const float* yr = P.y + (size_t)c * P.ypitch + YPRE;
+    float* hr = P.h + (size_t)c * P.ypitch + YPRE;
+    const float* tab = P.dcd_table + (size_t)c * P.ticks_cap * 12;
+
+    // the gate's state as K5 left it (M17Demodulator members dcd_, count_, initializing; DataCarrierDetect level/trigger)
+    int32_t init = gs->hot.initializing;
+    uint32_t on = gs->hot.dcd_on, trig = gs->hot.dcd_trig, count = gs->hot.count;
+    int32_t run_pos = gs->hot.run_pos;
+    float h0 = gs->hot.h0, h1 = gs->hot.h1, h2 = gs->hot.h2;
+    float level = gs->cold.dcd_level;
+    uint32_t seg = gs->cold.seg_start_tick;
+    bool end_in_run = false;   // the previous gated run ended inside this launch, at relative sample end_t
+    int32_t end_t = 0;
+    bool pl_valid = false;     // pl[g] holds the patched outputs of the current run
+    int32_t pl_rs = 0;         // relative index of that run's first sample
+
+    auto lds_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // DataCarrierDetect::update (:63-69) on the sums K3 left for the segment that ends with tick k (same arithmetic as
+    // nf_dcd_update in m17_state.hpp)
+    auto dcd_update = [&](uint64_t k, float l1, float l2) {
+        level = (float)((double)level * 0.8 + 0.2 * (double)(l1 / l2));
+        seg = (uint32_t)(k + 1);
+        trig = trig ? (level > 0.1f) : (level > 4.0f);
+    };
+
+    uint32_t t = 0;
+    uint32_t phase = (uint32_t)(P.pos0 % TICK);
+    float4 pre[3];             // this lane's share of a tick of matched-filter samples, loaded one tick ahead
+    uint32_t pre_t = 0xFFFFFFFFu;
+    while (t < P.T) {
+        const uint32_t n = min(TICK - phase, P.T - t);   // a piece never crosses a tick boundary
+        const bool feed = init > 0 || on;
+        // ---- first 148 outputs of a gated run: FIR over (snapshot of the previous run's tail | this run's samples) ------------
+        const bool need_patch = feed && run_pos < 148 && !pl_valid;
+        const unsigned long long pm = __ballot(need_patch);
+        if (pm) {
+            for (int gg = 0; gg < GT_CPW; ++gg) {
+                if (!((pm >> (16 * gg)) & 1ull)) continue;   // wave-uniform
+                const int src = 16 * gg;
+                const uint32_t cc = (uint32_t)__shfl((int)c, src);
+                const int32_t rp = __shfl(run_pos, src);
+                const int32_t rs = (int32_t)t - rp;           // relative index of the run's first sample (>= -148)
+                const bool eir = __shfl((int)end_in_run, src);
+                const int32_t et = __shfl(end_t, src);
+                const int16_t* xrc = P.x + (size_t)cc * P.xpitch + XPRE;
+                const int16_t* hist = P.state[cc].hist;
+                for (int k = lane; k < 149; k += 64) {
+                    const int sv = eir ? (int)xrc[(int64_t)et - 148 + k] : (int)hist[k];
+                    pw[k] = scale_sample(sv, invert);
+                }
+                for (int k = lane; k < 148; k += 64)
+                    if ((int64_t)rs + k < (int64_t)P.T) pw[149 + k] = scale_sample((int)xrc[(int64_t)rs + k], invert);
+                lds_sync();
+                for (int j = rp + lane; j < 148; j += 64) {
+                    if ((int64_t)rs + j >= (int64_t)P.T) break;
+                    float acc = 0.f;
+                    for (int i = 0; i < NTAPS; ++i) {          // FirFilter.h:36-40: newest sample first
+                        const float p = pw[149 + j - i] * P.taps[i];
+                        acc = acc + p;
+                    }
+                    pl[gg][j] = acc;
+                }
+                lds_sync();
+            }
+            if (need_patch) { pl_valid = true; pl_rs = (int32_t)t - run_pos; }
+        }
+        // ---- the DCD sums this piece's update point (if it ends on one) will need: in flight during the recurrence ---------------
+        const uint32_t te = t + n - 1u;                        // last sample of the piece
+        const uint64_t k = (P.pos0 + te + 1) / TICK - 1;       // tick that ends with it (if it ends a tick)
+        const bool upd = init <= 0 && count + n == (on ? 960u : 384u);
+        float l1 = 0.f, l2 = 1.f;
+        if (upd) {
+            const float* row = tab + (size_t)(k - P.tick_row0) * 12;
+            const uint32_t span = (uint32_t)(k + 1 - seg);
+            const int j = span > 5 ? 5 : (int)(seg % 5u);
+            l1 = row[j]; l2 = row[6 + j];
+        }
+        // ---- feed the piece -----------------------------------------------------------------------------------------------
+        if (__ballot(feed)) {
+            // whole aligned ticks without patched outputs: 16-byte loads, issued one tick ahead
+            const bool overlay = feed && pl_valid && (int32_t)t - pl_rs < 148;
+            const bool fast = n == TICK && ((P.pos0 + t) & 3u) == 0 && !__ballot(overlay);
+            if (fast) {
+                if (pre_t != t) {
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) pre[b] = *reinterpret_cast<const float4*>(yr + t + 64 * b + 4 * r);
+                }
+#pragma unroll
+                for (int b = 0; b < 3; ++b) *reinterpret_cast<float4*>(&yl[g][64 * b + 4 * r]) = pre[b];
+                if (t + 2 * TICK <= P.T) {
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) pre[b] = *reinterpret_cast<const float4*>(yr + t + TICK + 64 * b + 4 * r);
+                    pre_t = t + TICK;
+                }
+            } else {
+                for (uint32_t i = r; i < n; i += 16) {
+                    float v = 0.f;
+                    if (feed) {
+                        const int32_t j = (int32_t)(t + i) - pl_rs;   // position inside the run, meaningful while pl_valid
+                        v = (pl_valid && j < 148) ? pl[g][j] : yr[t + i];
+                    }
+                    yl[g][i] = v;
+                }
+            }
+            lds_sync();
+            if (r == 0 && feed) {
+                float m2 = IirCoef::a2 * h1;
+                uint32_t i = 0;
+                if ((n & 3u) == 0) {
+                    float4 v = *reinterpret_cast<const float4*>(&yl[g][0]);
+                    for (; i < n; i += 4) {
+                        const float4 nx = *reinterpret_cast<const float4*>(&yl[g][i + 4 < n ? i + 4 : i]);  // next group in flight
+                        float4 o;
+                        o.x = iir_advance_pk(fabsf(v.x), h0, m2); h2 = h1; h1 = h0; h0 = o.x;
+                        o.y = iir_advance_pk(fabsf(v.y), h0, m2); h2 = h1; h1 = h0; h0 = o.y;
+                        o.z = iir_advance_pk(fabsf(v.z), h0, m2); h2 = h1; h1 = h0; h0 = o.z;
+                        o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
+                        *reinterpret_cast<float4*>(&hl[g][i]) = o;
+                        v = nx;
+                    }
+                } else {
+                    for (; i < n; ++i) {
+                        const float hn = iir_advance_pk(fabsf(yl[g][i]), h0, m2);
+                        h2 = h1; h1 = h0; h0 = hn;
+                        hl[g][i] = hn;
+                    }
+                }
+            }
+            // the history lives on lane 0 of the group: hand it to the other 15 (they replay the gate redundantly)
+            h0 = __shfl(h0, 16 * g); h1 = __shfl(h1, 16 * g); h2 = __shfl(h2, 16 * g);
+            lds_sync();
+            if (feed && valid) {
+                if (fast) {
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        *reinterpret_cast<float4*>(hr + t + 64 * b + 4 * r) = *reinterpret_cast<const float4*>(&hl[g][64 * b + 4 * r]);
+                } else {
+                    for (uint32_t i = r; i < n; i += 16) hr[t + i] = hl[g][i];
+                }
+            }
+            lds_sync();
+            if (feed) run_pos = min(148, run_pos + (int32_t)n);
+        }
+        // ---- the gate: M17Demodulator::operator() :670-689 (carrier off) and :742-752 (carrier on) ----------------------------
+        if (init > 0) {
+            init -= (int32_t)n;
+            count = 0;
+            if (init == 0) { end_in_run = true; end_t = (int32_t)te; }   // the initialisation run ends; the carrier is off
+        } else if (!on) {
+            count += n;
+            if (count == 384u) {
+                if (trig) {   // update_dcd -> dcd_on: a new gated run starts with the next sample
+                    on = 1;
+                    run_pos = 0;
+                    pl_valid = false;
+                    if (r == 0 && valid) {   // the history the run inherits, where its first samples will look for it
+                        hr[(int64_t)te] = h0; hr[(int64_t)te - 1] = h1; hr[(int64_t)te - 2] = h2;
+                    }
+                }
+                dcd_update(k, l1, l2);
+                count = 0;
+            }
+        } else {
+            count += n;
+            if (count == 960u) {
+                if (!trig) { on = 0; end_in_run = true; end_t = (int32_t)te; }
+                count = 0;
+                dcd_update(k, l1, l2);
+            }
+        }
+        t += n;
+        phase = (phase + n == TICK) ? 0u : phase + n;
+    }
+    if (r == 0 && valid) {
+        float* f = P.final_h + (size_t)c * 4;
+        f[0] = h0; f[1] = h1; f[2] = h2;
+    }
+}
+
+}  // namespace m17

@@ -30,6 +30,7 @@ struct Hot {  // per-channel scalars kept in registers while the kernel runs
     uint32_t st, sync_word_type, sample_index, sync_sample_index;
     uint32_t need_clock_reset, need_clock_update, eot_flag, viterbi_cost;
     int32_t sync_count, missing_sync_count, initializing;
+    uint32_t spec_ok;           // this run still trusts K2's speculative limit-filter history (m17_gate_kernel.hpp)
 };
 struct Cold {  // per-channel state that stays in global memory (touched by out-of-line helpers only)
     Kal2 ck, kmin, kmax;
@@ -68,9 +69,12 @@ struct SeqParams {
     const float* taps;        // 149 floats
     const float* llr_edges;   // 43 floats (Util.h:63-104, float-accumulated; built on the host)
     uint32_t C, T;
-    uint64_t pos0;
-    uint32_t flags;
-    unsigned long long* dbg;  // optional [channels][8] counters (diagnostics)
+    uint64_t pos0;            // absolute index of sample 0 of this (segment of a) run
+    uint64_t tick_row0;       // absolute tick stored in row 0 of the DCD table
+    uint32_t flags;           // bit 0 invert, bit 1 continuation segment of a run
+    unsigned long long* dbg;  // optional [channels][24] counters (diagnostics)
+    const float* h;           // K2's limit-filter history, pitch ypitch (nullptr: no speculation, K5 runs the filter itself)
+    const float* final_h;     // [C][4] K2's filter history after the last fed sample of the run
 };
 
 // LDS words for a wave of `ls` channels: ring, sync samples, llr, hist, outb, lsf columns; edges, src maps, lich map

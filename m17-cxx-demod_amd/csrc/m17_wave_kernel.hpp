@@ -45,7 +45,7 @@ constexpr int WV_WAVE_WORDS = 80 + 40 + 92 + 122 + 8 + 8 + WV_WIN + 96 + 488 + 6
 constexpr int wave_lds_words(int waves_per_block) { return WV_TAB_WORDS + waves_per_block * WV_WAVE_WORDS; }
 
 // M17FrameDecoder::operator() on the wave's completed frame; returns (viterbi_cost, decoder state)
-__device__ __noinline__ uint2 nf_decode_wave(const DecodeTables* tb, DecodeLds L, int wl, uint32_t sync_type, Cold* cd, uint32_t cost_in,
+__device__ __forceinline__ uint2 nf_decode_wave(const DecodeTables* tb, DecodeLds L, int wl, uint32_t sync_type, Cold* cd, uint32_t cost_in,
                                              FrameRec* rec_base, uint32_t rec_cap, uint32_t channel, uint64_t pos, uint32_t* overflow)
 {
     DecoderRegs D{cd->dec_state, cd->lich_segments, cd->stale401};
@@ -114,12 +114,14 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         for (int k = wl; k < (int)(sizeof(Hot) / 4); k += 64) dst[k] = src[k];
     }
     Hot& s = *hot_lds;
+    const float* hrow = P.h ? P.h + (size_t)c * P.ypitch + YPRE : nullptr;  // K2's filter history for this channel
     for (int k = wl; k < 80; k += 64) ring[k] = gs->ring[k];
     for (int k = wl; k < 40; k += 64) swsm[k] = gs->sw_samples[k / 10][k % 10];
     for (int k = wl; k < 92; k += 64) DL.llr[k] = gs->llr[k];
     for (int k = wl; k < 8; k += 64) DL.lsf[k] = gs->lsf[k];
     wave_lds_sync();
-    cd->n_run = 0;
+    s.spec_ok = hrow != nullptr;  // every run starts trusting K2 (which started from this very state)
+    if (!(P.flags & 2u)) cd->n_run = 0;  // (flag bit 1: a later segment of the same run keeps counting its records)
     // Sample window: ybuf samples [t, avail) are in LDS; the next WV_PF samples are in flight in registers (pf) so that the
     // HBM/L2 latency of this channel's row is paid ~WV_PF samples ahead of its use instead of at the head of every step.
     float pf[WV_PF / 64];
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     const int16_t* xr = P.x + (size_t)c * P.xpitch + XPRE;
     float* yr = const_cast<float*>(P.y) + (size_t)c * P.ypitch + YPRE;  // K1's output; the first 148 samples of a gated run are patched in place
     const float* tab = P.dcd_table + (size_t)c * P.ticks_cap * 12;
-    const uint64_t tick0 = P.pos0 / TICK;
+    const uint64_t tick0 = P.tick_row0;
     FrameRec* rec_base = P.recs + (size_t)c * P.rec_cap;
     uint32_t t = 0;  // next sample (relative to this run)
     auto pf_issue = [&]() {   // start loading [avail, avail + WV_PF): 8 coalesced 256-byte rows
@@ -180,8 +182,33 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         }
         return r;
     };
+    // Correlator::limit() after the newest sample `tt` was fed.  While the run trusts K2 the history comes from hbuf through a
+    // 64-sample LDS window (the e2 array, idle outside payload chunks); otherwise from the filter K5 carries itself.
+    int32_t hw_base = 0x40000000;  // first hbuf index held in the window (invalid)
+    uint32_t cur_tt = 0;           // index of the newest fed sample (single-sample path)
+    auto cur_lim = [&]() -> float {
+        if (!s.spec_ok) return iir_output(s.h0, s.h1, s.h2);
+        const int32_t tt = (int32_t)cur_tt;
+        if (tt - 2 < hw_base || tt >= hw_base + 64) {
+            hw_base = tt - 2;
+            const int64_t i = (int64_t)hw_base + wl;
+            e2[wl] = i < (int64_t)P.T ? hrow[i] : 0.f;
+            wave_lds_sync();
+        }
+        const int o = tt - hw_base;
+        return iir_output(e2[o], e2[o - 1], e2[o - 2]);
+    };
+    // leave the speculation (a forced dcd.unlock() K2 could not foresee): pick the filter history up at sample `tt`
+    unsigned long long n_despec = 0;
+    auto despec = [&](uint32_t tt) {
+        if (s.spec_ok) {
+            ++n_despec;
+            s.h0 = hrow[(int64_t)tt]; s.h1 = hrow[(int64_t)tt - 1]; s.h2 = hrow[(int64_t)tt - 2];
+            s.spec_ok = 0;
+        }
+    };
     auto sw_triggered = [&](int w) -> float {  // Correlator.h:150-157
-        const float lim = iir_output(s.h0, s.h1, s.h2);
+        const float lim = cur_lim();
         const float l1 = lim * SW_MAG1[w];
         const float l2 = lim * SW_MAG2[w];
         const float v = correlate(w);
@@ -232,8 +259,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         }
     };
     auto corr_sample = [&](float v) {  // Correlator::sample :43-49
-        const float h0n = iir_advance(fabsf(v), s.h0, s.h1);  // history shifts: h2 <- h1, h1 <- h0
-        s.h2 = s.h1; s.h1 = s.h0; s.h0 = h0n;
+        if (!s.spec_ok) {
+            const float h0n = iir_advance(fabsf(v), s.h0, s.h1);  // history shifts: h2 <- h1, h1 <- h0
+            s.h2 = s.h1; s.h1 = s.h0; s.h0 = h0n;
+        }
         ring[s.ring_pos] = v;
         s.prev_pos = s.ring_pos;
         if (++s.ring_pos == 80u) s.ring_pos = 0;
@@ -267,7 +296,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     unsigned long long n_bulk = 0, n_bulk_samples = 0, n_scalar = 0, n_flip = 0, n_decode = 0;
     auto now = [&]() -> unsigned long long { if constexpr (PROF) return wall_clock64(); else return 0ull; };
     const unsigned long long tk0 = now();
-    unsigned long long tk_bulk = 0, tk_scalar = 0, tk_decode = 0, tk_patch = 0;
+    unsigned long long tk_bulk = 0, tk_scalar = 0, tk_decode = 0, tk_patch = 0, tk_ens = 0, tk_sym = 0, tk_iir = 0, tk_search = 0, tk_off = 0;
 
     // The first 148 FIR outputs of a gated run still see the tail of the previous run (Q2): recompute them from the
     // 149-sample snapshot + the run's own samples and patch ybuf in place, 64 outputs at a time, so that every later
@@ -301,8 +330,11 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
 
     // ---------------- main loop (wave-uniform control flow) ------------------------------------------------------------
     while (t < P.T) {
+        bool decode_due = false, tail_dcd = false;
+        uint32_t te = 0;
         // ---- carrier off: nothing happens until the next DCD update point (:675-689) -> jump there ----------------------
         if (!s.initializing && !s.dcd_on) {
+            const unsigned long long f0 = now();
             const uint32_t n = min(384u - s.count, P.T - t);
             s.count += n;
             t += n;
@@ -328,6 +360,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                              s.sync_sample_index, s.ck_sample_index, s.viterbi_cost);
                 s.count = 0;
             }
+            tk_off += now() - f0;
             continue;
         }
 
@@ -407,7 +440,9 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             float* hb = W + 160;                            // [3 + 64] h0 trajectory: hb[2], hb[1], hb[0] = h0, h1, h2 before the chunk
             for (uint32_t k = wl; k < 80u; k += 64) W[k] = ring[(s.prev_pos + 1u + k) % 80u];   // oldest first
             if (wl < n) W[80u + wl] = ywin[(t + wl) & (WV_WIN - 1)];
-            {
+            if (s.spec_ok) {   // the trajectory is in hbuf: hb[k] = history after sample t - 3 + k
+                for (uint32_t k = wl; k < n + 3u; k += 64) hb[k] = hrow[(int64_t)t - 3 + k];
+            } else {
                 float h0 = s.h0, h1 = s.h1;
                 float m2 = IirCoef::a2 * h1;
                 hb[0] = s.h2; hb[1] = h1; hb[2] = h0;
@@ -450,17 +485,20 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 t += f;
                 if (s.count == 960u) dcd_point_on(t - 1u);
                 ++n_bulk; n_bulk_samples += f;
-                tk_bulk += now() - b0;
+                tk_search += now() - b0;
                 continue;
             }
             mode = BULK_NONE;  // the very next sample triggers: single-sample path
-            tk_bulk += now() - b0;
+            tk_search += now() - b0;
         }
         if (mode != BULK_NONE) {
             const unsigned long long b0 = now();
             ensure(n);
+            const unsigned long long b1 = now();
+            tk_ens += b1 - b0;
 
             if (mode == BULK_FRAME) {
+                hw_base = 0x40000000;  // e2 is about to hold EVM terms
                 const uint32_t m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;  // payload symbols inside the chunk (<= 96)
                 for (uint32_t k = wl; k < m; k += 64) {
                     float err;
@@ -489,7 +527,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     if (a1 < n) s.ck_sample_index = (int32_t)s.sample_index;
                 }
             }
+            const unsigned long long b2 = now();
+            tk_sym += b2 - b1;
             {   // Correlator::sample x n: the limit IIR is one dependent chain; the ring keeps the last 80 samples
+                if (!s.spec_ok) {   // (a run that trusts K2 finds the filter history in hbuf when it needs it)
                 float h0 = s.h0, h1 = s.h1, h2 = s.h2;
                 float m2 = IirCoef::a2 * h1;   // a2 * (second-newest history value), carried by iir_advance_pk
                 uint32_t k = 0;
@@ -515,6 +556,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     h2 = h1; h1 = h0; h0 = hn;
                 }
                 s.h0 = h0; s.h1 = h1; s.h2 = h2;
+                }
+                tk_iir += now() - b2;
                 const uint32_t first = n > 80u ? n - 80u : 0u;
                 for (uint32_t o = first + wl; o < n; o += 64) ring[(s.ring_pos + o) % 80u] = ywin[(t + o) & (WV_WIN - 1)];
                 s.prev_pos = (s.ring_pos + n - 1u) % 80u;
@@ -535,26 +578,22 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             }
             wave_lds_sync();
             t += n;
-            if (mode == BULK_FRAME && completes) {  // the last sample of the chunk completed the frame: decoder(...) (:619-642)
+            te = t - 1u;
+            tail_dcd = mode != BULK_INIT;
+            if (mode == BULK_FRAME && completes) {  // the last sample of the chunk completed the frame
                 s.framer_idx = 0;
                 s.sync_count = 0;
-                const unsigned long long d0 = now();
-                const uint2 r = nf_decode_wave(P.tables, DL, wl, s.sync_word_type, cd, s.viterbi_cost, rec_base, P.rec_cap, c, P.pos0 + t - 1u, P.overflow);
-                s.viterbi_cost = r.x;
-                s.st = (r.y == 1u || r.y == 0u) ? ST_STREAM_SYNC : (r.y == 4u ? ST_BERT_SYNC : ST_PACKET_SYNC);
-                ++n_decode;
-                tk_decode += now() - d0;
+                decode_due = true;
             }
-            if (mode != BULK_INIT && s.count == 960u) dcd_point_on(t - 1u);
             ++n_bulk; n_bulk_samples += n;
             tk_bulk += now() - b0;
-            continue;
-        }
+        } else {
 
         // ---- one input sample: M17Demodulator::operator() :657-753 -----------------------------------------------------------
         const unsigned long long c0 = now();
         ++n_scalar;
         const uint32_t tt = t;
+        cur_tt = tt;
         s.count++;
         ensure(1u);
         const float filtered = ywin[tt & (WV_WIN - 1)];
@@ -570,7 +609,6 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         }
         if (corr_index() == 0) clock_flags();
         s.ck_count++;
-        bool decode_due = false;
         if (s.st <= ST_BERT_SYNC && !(s.st >= ST_STREAM_SYNC && s.sync_count + 1 < 78)) load_r8();  // states that correlate
         switch (s.st) {
         case ST_UNLOCKED: {  // do_unlocked :289-342
@@ -617,7 +655,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 s.sync_word_type = sync_triggered > 0.f ? 0u : 1u;
             } else if (++s.missing_sync_count > 192) {
                 if (s.sync_count >= 10) { s.missing_sync_count = 0; s.need_clock_update = 1; }
-                else { s.sync_count = 0; s.st = ST_UNLOCKED; s.missing_sync_count = 0; s.dcd_trig = 0; }
+                else { s.sync_count = 0; s.st = ST_UNLOCKED; s.missing_sync_count = 0; if (s.dcd_trig) despec(tt); s.dcd_trig = 0; }
             } else {
                 update_values(s.sample_index);
             }
@@ -649,11 +687,11 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     if (!s.missing_sync_count) s.missing_sync_count = 1;
                     s.sync_word_type = swt; s.st = ST_FRAME;
                 } else if (mode_st == ST_STREAM_SYNC && s.eot_flag) {
-                    s.st = ST_UNLOCKED; s.dcd_trig = 0;
+                    s.st = ST_UNLOCKED; if (s.dcd_trig) despec(tt); s.dcd_trig = 0;
                 } else if (s.missing_sync_count < 10) {
                     s.missing_sync_count += 1; s.sync_word_type = swt; s.st = ST_FRAME;
                 } else {
-                    s.st = ST_UNLOCKED; s.dcd_trig = 0;
+                    s.st = ST_UNLOCKED; if (s.dcd_trig) despec(tt); s.dcd_trig = 0;
                 }
                 if (mode_st == ST_STREAM_SYNC) s.eot_flag = 0;
             }
@@ -686,20 +724,25 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         }
         }
         wave_lds_sync();
-        if (decode_due) {  // decoder(...) and the rest of do_frame (:623-642)
+        te = tt;
+        tail_dcd = true;
+        ++t;
+        tk_scalar += now() - c0;
+        }
+        // ---- common tail: frame decode and the carrier-on update point ----------------------------------------------------
+        if (decode_due) {  // decoder(...) and the rest of do_frame (:619-642)
             const unsigned long long d0 = now();
-            const uint2 r = nf_decode_wave(P.tables, DL, wl, s.sync_word_type, cd, s.viterbi_cost, rec_base, P.rec_cap, c, P.pos0 + tt, P.overflow);
+            const uint2 r = nf_decode_wave(P.tables, DL, wl, s.sync_word_type, cd, s.viterbi_cost, rec_base, P.rec_cap, c, P.pos0 + te, P.overflow);
             s.viterbi_cost = r.x;
             s.st = (r.y == 1u || r.y == 0u) ? ST_STREAM_SYNC : (r.y == 4u ? ST_BERT_SYNC : ST_PACKET_SYNC);
             ++n_decode;
             tk_decode += now() - d0;
         }
-        if (s.count == 960u) dcd_point_on(tt);
-        ++t;
-        tk_scalar += now() - c0;
+        if (tail_dcd && s.count == 960u) dcd_point_on(te);
     }
 
     // ---------------- save state ------------------------------------------------------------------------------
+    if (s.spec_ok) { const float* f = P.final_h + (size_t)c * 4; s.h0 = f[0]; s.h1 = f[1]; s.h2 = f[2]; }
     wave_lds_sync();
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(hot_lds);
@@ -717,7 +760,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     P.rec_count[c] = cd->n_run;
     if constexpr (PROF) if (wl == 0) {
         unsigned long long* o = P.dbg + (size_t)c * 24;
-        o[8] = tk_patch;
+        o[8] = tk_patch; o[12] = tk_ens; o[13] = tk_sym; o[14] = tk_iir; o[15] = tk_search; o[16] = tk_off; o[17] = n_despec;
         o[0] = now() - tk0; o[1] = tk_bulk; o[2] = tk_scalar; o[3] = tk_decode;
         o[4] = n_bulk; o[5] = n_scalar; o[6] = n_bulk_samples; o[7] = n_flip | (n_decode << 32);
     }

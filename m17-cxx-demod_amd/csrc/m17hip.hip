@@ -8,6 +8,7 @@
 #include "m17_frontend_kernels.hpp"
 #include "m17_state.hpp"
 #include "m17_wave_kernel.hpp"
+#include "m17_gate_kernel.hpp"
 #include "m17_parity_kernels.hpp"
 
 #include <algorithm>
@@ -22,7 +23,7 @@ using namespace m17;
 
 namespace {
 
-enum { KT_FIR = 0, KT_DCD, KT_SEQ, KT_DEC, KT_CORR, KT_COMPACT, KT_N };
+enum { KT_FIR = 0, KT_DCD, KT_SEQ, KT_DEC, KT_CORR, KT_COMPACT, KT_GATE, KT_N };
 
 struct TimedLaunch { hipEvent_t a, b; int which; };
 
@@ -32,13 +33,19 @@ struct m17hip_ctx {
     int device = 0;
     int last_hip = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;        // K3 runs here, concurrently with K1
+    hipStream_t side = nullptr;        // K3 runs here, concurrently with K1 (side2) and with K2/K5 of earlier segments (stream)
+    hipStream_t side2 = nullptr;       // K1 of the segments of a run
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_fir, ev_dcd;  // per segment: K1 / K3 done
     uint32_t maxC = 0, maxT = 0;
     size_t xpitch = 0, ypitch = 0;
     uint32_t ticks_cap = 0, rec_cap = 0;
     int16_t* xbuf = nullptr;
     float* ybuf = nullptr;
+    float* hbuf = nullptr;            // K2's limit-filter history, same pitch as ybuf
+    float* final_h = nullptr;         // [maxC][4]
+    bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
+    uint32_t seg_len = 96000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     float* dcd_table = nullptr;
     DcdState* dcd_state = nullptr;
     SeqState* seq_state = nullptr;
@@ -229,6 +236,15 @@ __global__ void carry_tail_kernel(int16_t* x, size_t xpitch, float* y, size_t yp
     for (int k = threadIdx.x; k < YPRE; k += blockDim.x) yr[k] = ys[k];
 }
 
+__global__ void carry_tail_f32_kernel(float* y, size_t ypitch, uint32_t T)
+{
+    __shared__ float ys[YPRE];
+    float* yr = y + (size_t)blockIdx.x * ypitch;
+    for (int k = threadIdx.x; k < YPRE; k += blockDim.x) ys[k] = yr[(size_t)T + k];
+    __syncthreads();
+    for (int k = threadIdx.x; k < YPRE; k += blockDim.x) yr[k] = ys[k];
+}
+
 __global__ void copy_rows_i16_kernel(const int16_t* src, size_t spitch, int16_t* dst, size_t dpitch, uint32_t T)
 {
     const uint32_t c = blockIdx.y;
@@ -275,19 +291,22 @@ __global__ void compact_kernel(const FrameRec* recs, uint32_t rec_cap, const uin
         if (offsets[c] + k / 4 < out_cap) dst[k] = src[k];
 }
 
-int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
+// t0: first sample of the slab to process (segment of a run); the kernels see the slab from there on
+int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0)
 {
-    Timed tm(c, KT_FIR);
+    Timed tm(c, KT_FIR, st);
     dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C);
-    hipLaunchKernelGGL(fir_rrc150_kernel, grid, dim3(FIR_THREADS), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, T, flags);
+    hipLaunchKernelGGL(fir_rrc150_kernel, grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
-int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st)
+int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0)
 {
     Timed tm(c, KT_DCD, st);
-    hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW - 1) / DCD_CPW), dim3(64), 0, st, c->xbuf, c->xpitch, c->dcd_state, c->dcd_table,
-                       c->ticks_cap, C, T, c->pos, c->coef, flags);
+    // table rows are numbered from the first tick of the RUN: a later segment continues where the previous one stopped
+    const uint64_t row0 = (c->pos + t0) / TICK - c->pos / TICK;
+    hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW - 1) / DCD_CPW), dim3(64), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+                       c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
@@ -333,6 +352,8 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     } while (0)
     ALLOC(c->xbuf, C * c->xpitch * sizeof(int16_t));
     ALLOC(c->ybuf, C * c->ypitch * sizeof(float));
+    ALLOC(c->hbuf, C * c->ypitch * sizeof(float));
+    ALLOC(c->final_h, C * 4 * sizeof(float));
     ALLOC(c->dcd_table, C * c->ticks_cap * 12 * sizeof(float));
     ALLOC(c->dcd_state, C * sizeof(DcdState));
     ALLOC(c->seq_state, C * sizeof(SeqState));
@@ -360,6 +381,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     }
     c->coef = build_coef();
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
+    if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)demod_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, wave_lds_words(8) * 4) != hipSuccess)
@@ -383,8 +405,11 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->side) hipStreamDestroy(c->side);
+    if (c->side2) hipStreamDestroy(c->side2);
+    for (auto e : c->ev_fir) hipEventDestroy(e);
+    for (auto e : c->ev_dcd) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg};
+                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -423,7 +448,7 @@ int m17hip_fir_rrc150(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, flo
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
     if (!c->uploaded) return M17HIP_ESTATE;
-    int r = launch_fir(c, C, T, flags);
+    int r = launch_fir(c, C, T, flags, c->stream);
     if (r) return r;
     if (out_host) {
         HIPCHK(c, hipMemcpy2DAsync(out_host, (size_t)T * sizeof(float), c->ybuf + YPRE, c->ypitch * sizeof(float), (size_t)T * sizeof(float), C,
@@ -558,6 +583,7 @@ int m17hip_demod_reset(m17hip_ctx* c)
     hipLaunchKernelGGL(seq_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->dcd_state, c->maxC);
     hipLaunchKernelGGL(zero_prefix_kernel, dim3(c->maxC), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, c->maxC);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemset2DAsync(c->hbuf, c->ypitch * sizeof(float), 0, YPRE * sizeof(float), c->maxC, c->stream));
     HIPCHK(c, hipMemsetAsync(c->rec_count, 0, (size_t)c->maxC * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->overflow, 0, 4, c->stream));
     c->pos = 0;
@@ -571,27 +597,56 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     if (!c->uploaded) return M17HIP_ESTATE;
     if (c->have_run && C != c->lastC) return M17HIP_EINVAL;  // a continued stream keeps its channel count
     int r;
-    // K3 (128 latency-bound waves) runs beside K1 (the whole chip) on a side stream; K5 needs both
+    // The run is processed in segments.  K1 (throughput-bound, the whole chip) and K3 (latency-bound lone waves) of ALL segments
+    // are queued on two side streams; the main stream runs K2 -> K5 per segment as soon as that segment's K1 and K3 are done,
+    // so the front end of segment k+1 fills the issue slots K5 of segment k leaves idle (its tail above all).
+    // Every K2 starts a fresh speculation from K5's own state, so a channel that had to drop it (forced unlock) carries the
+    // limit filter itself only until the end of its segment.
+    const uint32_t seg_len = (!c->profile && c->seg_len) ? c->seg_len : T;
+    const uint32_t nseg = (T + seg_len - 1) / seg_len;
+    while (c->ev_fir.size() < nseg) {
+        hipEvent_t a, b;
+        HIPCHK(c, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        c->ev_fir.push_back(a); c->ev_dcd.push_back(b);
+    }
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    if ((r = launch_dcd(c, C, T, flags, c->side))) return r;
-    HIPCHK(c, hipEventRecord(c->ev_join, c->side));
-    if ((r = launch_fir(c, C, T, flags))) return r;
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    {
+    HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork, 0));
+    for (uint32_t k = 0; k < nseg; ++k) {
+        const uint32_t t0 = k * seg_len, len = std::min(seg_len, T - t0);
+        if ((r = launch_dcd(c, C, len, flags, c->side, t0))) return r;
+        HIPCHK(c, hipEventRecord(c->ev_dcd[k], c->side));
+        if ((r = launch_fir(c, C, len, flags, c->side2, t0))) return r;
+        HIPCHK(c, hipEventRecord(c->ev_fir[k], c->side2));
+    }
+    c->dbg_waves = c->profile ? C : 0;
+    for (uint32_t t0 = 0, k = 0; t0 < T; t0 += seg_len, ++k) {
+        const uint32_t len = std::min(seg_len, T - t0);
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fir[k], 0));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dcd[k], 0));
+        if (c->speculate) {   // K2: replay the carrier-detect gate and run the limit filter ahead of K5 (needs K1's and K3's output)
+            Timed tm(c, KT_GATE);
+            GateParams G{};
+            G.x = c->xbuf + t0; G.xpitch = c->xpitch; G.y = c->ybuf + t0; G.ypitch = c->ypitch; G.h = c->hbuf + t0;
+            G.dcd_table = c->dcd_table; G.ticks_cap = c->ticks_cap; G.state = c->seq_state; G.final_h = c->final_h;
+            G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags;
+            hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), 0, c->stream, G);
+            HIPCHK(c, hipGetLastError());
+        }
         Timed tm(c, KT_SEQ);
         SeqParams P{};
-        P.x = c->xbuf; P.xpitch = c->xpitch; P.y = c->ybuf; P.ypitch = c->ypitch;
+        P.h = c->speculate ? c->hbuf + t0 : nullptr; P.final_h = c->final_h;
+        P.x = c->xbuf + t0; P.xpitch = c->xpitch; P.y = c->ybuf + t0; P.ypitch = c->ypitch;
         P.dcd_table = c->dcd_table; P.ticks_cap = c->ticks_cap; P.state = c->seq_state;
         P.recs = c->recs; P.rec_cap = c->rec_cap; P.rec_count = c->rec_count; P.overflow = c->overflow;
         P.tables = c->tables; P.taps = c->taps; P.llr_edges = c->llr_edges;
-        P.C = C; P.T = T; P.pos0 = c->pos; P.flags = flags;
+        P.C = C; P.T = len; P.pos0 = c->pos + t0; P.tick_row0 = c->pos / TICK; P.flags = (flags & 1u) | (t0 ? 2u : 0u);
         // one wave per channel; `seq_lanes` (tuning knob 0) = waves per workgroup
         const uint32_t wpb = (c->seq_lanes && !c->profile) ? c->seq_lanes : 4;  // the profiling build exists for 4 waves per workgroup
         const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
         const size_t lds = (size_t)wave_lds_words((int)wpb) * 4;
         P.dbg = c->profile ? c->dbg : nullptr;
-        c->dbg_waves = c->profile ? C : 0;
         if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P);
         else switch (wpb) {
         case 1: hipLaunchKernelGGL(demod_wave_kernel<1>, grid, block, lds, c->stream, P); break;
@@ -599,9 +654,11 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         case 8: hipLaunchKernelGGL(demod_wave_kernel<8>, grid, block, lds, c->stream, P); break;
         default: hipLaunchKernelGGL(demod_wave_kernel<4>, grid, block, lds, c->stream, P); break;
         }
+        HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
+    if (c->speculate) hipLaunchKernelGGL(carry_tail_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->hbuf, c->ypitch, T);
     HIPCHK(c, hipGetLastError());
     c->pos += T;
     c->lastC = C; c->lastT = T;
@@ -683,6 +740,13 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         return M17HIP_OK;
     case 1:  // per-channel tick counters of the sequential kernel on/off (m17hip_debug_counters)
         c->profile = value != 0;
+        return M17HIP_OK;
+    case 2:  // K2 (speculative limit filter ahead of K5) on/off; off = K5 carries the filter itself
+        c->speculate = value != 0;
+        return M17HIP_OK;
+    case 3:  // samples per K2+K5 segment of a run (0 = whole run)
+        if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
+        c->seg_len = (uint32_t)value;
         return M17HIP_OK;
     default: return M17HIP_EINVAL;
     }

@@ -24,7 +24,7 @@ DIAG = np.dtype(
 assert FRAME_REC.itemsize == 64 and DIAG.itemsize == 64
 
 FLAG_INVERT = 1
-KERNELS = {"fir_rrc150": 0, "dcd": 1, "demod_seq": 2, "decode": 3, "correlator": 4, "compact": 5}
+KERNELS = {"fir_rrc150": 0, "dcd": 1, "demod_seq": 2, "decode": 3, "correlator": 4, "compact": 5, "limit_track": 6}
 VITERBI_SHAPES = {0: (488, 240), 1: (296, 144), 2: (420, 206), 3: (402, 197)}
 
 EXPORTS = [

@@ -23,9 +23,13 @@ def _oracle_records(x, invert=0):
     return flat, counts, diags
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=[1, 0], ids=["limit_ahead", "limit_inline"])
+def ctx(request):
+    """Every test runs twice: with the correlator's limit filter run ahead of the sequential kernel (K2, the default) and
+    with the sequential kernel carrying it itself (tuning knob 2 = 0, also the fallback of a dropped speculation)."""
     c = m17hip.Context(256, 96000)
+    c.tune(2, request.param)
+    c.limit_ahead = bool(request.param)
     yield c
     c.close()
 
@@ -270,6 +274,67 @@ def test_full_chain_ragged_chunks(ctx):
     for f in ("dcd", "locked", "sample_index", "viterbi_cost", "n_diag", "demod_state", "n_frames"):
         assert np.array_equal(d[f], diags[f]), f
     assert np.array_equal(d["dcd_level"], diags["dcd_level"], equal_nan=True)
+
+
+def test_full_chain_lost_sync_drops_limit_speculation(ctx):
+    """A burst followed by noise: the carrier detect stays on, sync is lost, the demodulator forces dcd.unlock() — the one
+    event K2's gate replay cannot foresee.  The run must drop the speculative filter history there and stay bit-exact."""
+    C, T = 32, 48000
+    p = ol.gen_params(seed=41, kind=-1, n_frames=6, lead_in=3072, noise_sigma=500.0, tail_sigma=3000.0, lead_sigma=40000.0, total=T)
+    x = ol.generate_batch(p, C, T, threads=8)
+    exp, counts, diags = _oracle_records(x)
+    ctx.tune(1, 1)
+    try:
+        ctx.upload(x)
+        ctx.reset()
+        ctx.run()
+        dropped = ctx.debug_counters(C)[:, 17]
+    finally:
+        ctx.tune(1, 0)
+    got = ctx.frames()
+    assert got.tobytes() == exp.tobytes() and got.size > C
+    d = ctx.diag()
+    for f in ("dcd", "locked", "viterbi_cost", "n_diag", "demod_state", "n_frames"):
+        assert np.array_equal(d[f], diags[f]), f
+    assert np.array_equal(d["dcd_level"], diags["dcd_level"], equal_nan=True)
+    if ctx.limit_ahead:
+        assert (dropped > 0).sum() >= C // 2, dropped   # the scenario does exercise the fallback
+    else:
+        assert (dropped == 0).all()
+    # ... and the next runs (fresh speculation from the saved state) continue bit-exact: same input as two chunks
+    ctx.reset()
+    parts = []
+    for a, b in ((0, 30000), (30000, T)):
+        ctx.upload(x[:, a:b])
+        ctx.run()
+        parts.append(ctx.frames().copy())
+    got2 = np.concatenate(parts)
+    order = np.lexsort((got2["seq"], got2["channel"]))
+    assert got2[order].tobytes() == exp.tobytes()
+
+
+@pytest.mark.parametrize("seg", [0, 7001, 19200])
+def test_full_chain_run_in_segments(ctx, seg):
+    """Tuning knob 3: a run is processed as K2+K5 segments (fresh limit-filter speculation per segment); any segment length,
+    aligned or not, gives the same records and diagnostics."""
+    C, T = 48, 60000
+    p = ol.gen_params(seed=52, kind=-1, n_frames=9, lead_in=3072, noise_sigma=700.0, tail_sigma=2500.0, lead_sigma=40000.0, total=T)
+    x = ol.generate_batch(p, C, T, threads=8)
+    exp, counts, diags = _oracle_records(x)
+    ctx.tune(3, seg)
+    try:
+        ctx.upload(x)
+        ctx.reset()
+        ctx.run()
+        got = ctx.frames()
+        d = ctx.diag()
+    finally:
+        ctx.tune(3, 96000)
+    assert got.tobytes() == exp.tobytes() and got.size > C
+    for f in ("dcd", "locked", "sample_index", "sync_index", "clock_index", "viterbi_cost", "n_diag", "demod_state", "n_frames"):
+        assert np.array_equal(d[f], diags[f]), f
+    for f in ("evm", "deviation", "offset", "clock", "dcd_level"):
+        assert np.array_equal(d[f], diags[f], equal_nan=True), f
 
 
 def test_edge_cases(ctx):

@@ -14,3 +14,4 @@ for rep in range(3):
     print('alone: fir %.2f dcd %.2f ms' % (ctx.timing_get('fir_rrc150')[0], ctx.timing_get('dcd')[0]), flush=True)
     ctx.timing_reset(); ctx.reset(); ctx.run()
     print('chain: fir %.2f dcd %.2f seq %.2f' % tuple(ctx.timing_get(k)[0] for k in ('fir_rrc150', 'dcd', 'demod_seq')), flush=True)
+print('limit_track %.2f ms' % ctx.timing_get('limit_track')[0])
