@@ -26,7 +26,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # algorithmic HBM bytes per input sample, per kernel and for the whole chain
-ALG_BYTES = {"fir_rrc150": 6.0, "dcd": 2.0 + 48.0 / 192.0, "demod_seq": 4.0 + 48.0 / 192.0 + 64.0 / 1920.0, "compact": 2 * 64.0 / 1920.0}
+ALG_BYTES = {"fir_rrc150": 6.0, "dcd": 2.0 + 48.0 / 192.0, "limit_track": 8.0 + 48.0 / 192.0, "demod_seq": 4.0 + 48.0 / 192.0 + 64.0 / 1920.0,
+             "compact": 2 * 64.0 / 1920.0}
 CHAIN_BYTES = 2.0 + 64.0 / 1920.0
 
 
@@ -115,9 +116,9 @@ def main():
     ctx.timing(False)
 
     kern = {}
-    for name in ("fir_rrc150", "dcd", "demod_seq", "compact"):
-        ms, n = ctx.timing_get(name)
-        kern[name] = {"ms_avg": (ms / n) if n else None, "launches": n}
+    for name in ("fir_rrc150", "dcd", "limit_track", "demod_seq", "compact"):
+        ms, n = ctx.timing_get(name)   # a run is processed in segments: several launches of each kernel per step
+        kern[name] = {"ms_avg": (ms / n) if n else None, "launches": n, "ms_per_step": ms / args.steps}
 
     # ---- parity spot check against the oracle (outside the timed region) ---------------------------------------------------
     parity = None
@@ -140,18 +141,21 @@ def main():
 
     samples_per_step = C * T * world
     value = samples_per_step * args.steps / dt / 1e6
-    dom = max((k for k in kern if kern[k]["ms_avg"]), key=lambda k: kern[k]["ms_avg"])
-    dom_s = kern[dom]["ms_avg"] / 1e3
-    achieved = ALG_BYTES[dom] * C * T / dom_s / 1e9
+    dom = max((k for k in kern if kern[k]["ms_avg"]), key=lambda k: kern[k]["ms_per_step"])
+    dom_s = kern[dom]["ms_avg"] / 1e3                                   # average duration of ONE launch of the dominant kernel
+    launches_per_step = kern[dom]["launches"] / args.steps
+    achieved = ALG_BYTES[dom] * C * T / launches_per_step / dom_s / 1e9   # algorithmic bytes of one launch / its duration
     traffic = None  # HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile_round.sh (profiles/)
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("channels") == C and tj.get("samples") == T and dom in tj.get("kernels", {}):
-            traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]   # per launch (= per segment), like `achieved`
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "alg_bytes_per_sample": ALG_BYTES[dom], "kernel_ms": {k: (round(v["ms_avg"], 4) if v["ms_avg"] else None) for k, v in kern.items()},
+                "alg_bytes_per_sample": ALG_BYTES[dom], "launches_per_step": launches_per_step,
+                "kernel_ms_per_launch": {k: (round(v["ms_avg"], 4) if v["ms_avg"] else None) for k, v in kern.items()},
+                "kernel_ms": {k: round(v["ms_per_step"], 4) for k, v in kern.items()},
                 "chain_achieved_GBs": round(CHAIN_BYTES * C * T * args.steps / dt / 1e9 / world, 2),
                 "chain_frac": round(CHAIN_BYTES * C * T * args.steps / dt / 1e9 / world / HBM_PEAK_GBS, 6)}
 

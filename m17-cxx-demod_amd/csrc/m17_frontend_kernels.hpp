@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64) void dcd_kernel(const int16_t* __restrict__ x, 
                                                  uint64_t pos0, DcdCoef k, uint32_t flags)
 {
     __shared__ __attribute__((aligned(16))) float dl[DCD_CPW][TICK];
-    __builtin_amdgcn_s_setprio(3);  // a long dependent chain: issue ahead of the throughput kernels sharing the SIMD
+    // (no s_setprio: later segments of this kernel have slack, the kernels it shares SIMDs with do not)
     const int lane = threadIdx.x;
     const int g = lane >> 4, r = lane & 15, bin = r >> 3, j = r & 7;
     uint32_t c = blockIdx.x * DCD_CPW + g;

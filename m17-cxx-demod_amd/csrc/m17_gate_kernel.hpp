@@ -19,7 +19,7 @@
 // as K5's patch_run_start does, into LDS only — ybuf is never written by this kernel.
 //
 // Mapping: 16 lanes per channel, 4 channels per wave: loads, stores and the FIR patch are cooperative, the recurrence
-// itself runs on lane 0 of each 16-lane group.
+// itself runs on lane 0 of each 16-lane group (the filter history lives there only).
 #pragma once
 
 #include "m17_common.hpp"
@@ -29,6 +29,18 @@
 
 namespace m17 {
 
+// The replay's own state at the end of a segment: start of the NEXT segment's replay, which runs while K5 is still busy with
+// this one (valid for every channel whose K5 did not drop the speculation; the others are redone from K5's state).
+struct GateExport {
+    int32_t init;
+    uint32_t on, trig, count;
+    int32_t run_pos;
+    float h0, h1, h2;
+    float level;
+    uint32_t seg;
+    int32_t end_in_run, end_t;   // end_t relative to the next segment's first sample (negative)
+};
+
 struct GateParams {
     const int16_t* x;
     size_t xpitch;
@@ -37,7 +49,10 @@ struct GateParams {
     float* h;                 // hbuf, same pitch as y
     const float* dcd_table;   // [C][ticks_cap][12]
     uint32_t ticks_cap;
-    const SeqState* state;    // K5's state at the end of the previous run (authoritative start of the replay)
+    const SeqState* state;    // K5's state at the end of the previous segment (authoritative start of the replay)
+    const GateExport* chain_in;   // non-null: start from the replay's own state instead (K5 has not finished the previous segment yet)
+    GateExport* chain_out;        // the replay's state at the end of this segment
+    const uint32_t* only;         // non-null: redo only the channels flagged here (K5 dropped the speculation in the previous segment)
     float* final_h;           // [C][4]: h0, h1, h2 after the last fed sample of this run
     const float* taps;        // 149 floats
     uint32_t C, T;
@@ -57,8 +72,12 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
     const int lane = threadIdx.x;
     const int g = lane >> 4, r = lane & 15;
     uint32_t c = blockIdx.x * GT_CPW + g;
-    const bool valid = c < P.C;
+    bool valid = c < P.C;
     if (!valid) c = P.C - 1;  // shadow the last channel, never store
+    if (P.only) {
+        valid = valid && P.only[c] != 0;
+        if (!__ballot(valid)) return;   // nothing to redo for these four channels
+    }
     const bool invert = P.flags & 1u;
     const SeqState* gs = P.state + c;
     const int16_t* xr = P.x + (size_t)c * P.xpitch + XPRE;
@@ -66,15 +85,25 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
     float* hr = P.h + (size_t)c * P.ypitch + YPRE;
     const float* tab = P.dcd_table + (size_t)c * P.ticks_cap * 12;
 
-    // the gate's state as K5 left it (M17Demodulator members dcd_, count_, initializing; DataCarrierDetect level/trigger)
-    int32_t init = gs->hot.initializing;
-    uint32_t on = gs->hot.dcd_on, trig = gs->hot.dcd_trig, count = gs->hot.count;
-    int32_t run_pos = gs->hot.run_pos;
-    float h0 = gs->hot.h0, h1 = gs->hot.h1, h2 = gs->hot.h2;
-    float level = gs->cold.dcd_level;
-    uint32_t seg = gs->cold.seg_start_tick;
-    bool end_in_run = false;   // the previous gated run ended inside this launch, at relative sample end_t
-    int32_t end_t = 0;
+    // the gate's state (M17Demodulator members dcd_, count_, initializing; DataCarrierDetect level/trigger) and the filter
+    // history: as K5 left them, or as the replay of the previous segment left them
+    int32_t init, run_pos, end_t = 0;
+    uint32_t on, trig, count, seg;
+    float h0, h1, h2, level;
+    bool end_in_run = false;   // the previous gated run ended inside this slab, at relative sample end_t
+    if (P.chain_in) {
+        const GateExport e = P.chain_in[c];
+        init = e.init; on = e.on; trig = e.trig; count = e.count; run_pos = e.run_pos;
+        h0 = e.h0; h1 = e.h1; h2 = e.h2; level = e.level; seg = e.seg;
+        end_in_run = e.end_in_run != 0; end_t = e.end_t;
+    } else {
+        init = gs->hot.initializing;
+        on = gs->hot.dcd_on; trig = gs->hot.dcd_trig; count = gs->hot.count;
+        run_pos = gs->hot.run_pos;
+        h0 = gs->hot.h0; h1 = gs->hot.h1; h2 = gs->hot.h2;
+        level = gs->cold.dcd_level;
+        seg = gs->cold.seg_start_tick;
+    }
     bool pl_valid = false;     // pl[g] holds the patched outputs of the current run
     int32_t pl_rs = 0;         // relative index of that run's first sample
 
@@ -93,7 +122,8 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
 
     uint32_t t = 0;
     uint32_t phase = (uint32_t)(P.pos0 % TICK);
-    float4 pre[3];             // this lane's share of a tick of matched-filter samples, loaded one tick ahead
+    uint64_t k_cur = P.pos0 / TICK;   // absolute index of the tick the current piece lies in
+    float4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = pre0, pre2 = pre0;   // this lane's share of a tick of matched-filter samples, loaded one tick ahead
     uint32_t pre_t = 0xFFFFFFFFu;
     while (t < P.T) {
         const uint32_t n = min(TICK - phase, P.T - t);   // a piece never crosses a tick boundary
@@ -134,7 +164,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         }
         // ---- the DCD sums this piece's update point (if it ends on one) will need: in flight during the recurrence ---------------
         const uint32_t te = t + n - 1u;                        // last sample of the piece
-        const uint64_t k = (P.pos0 + te + 1) / TICK - 1;       // tick that ends with it (if it ends a tick)
+        const uint64_t k = k_cur;                              // tick that ends with it (if it ends a tick)
         const bool upd = init <= 0 && count + n == (on ? 960u : 384u);
         float l1 = 0.f, l2 = 1.f;
         if (upd) {
@@ -149,15 +179,12 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
             const bool overlay = feed && pl_valid && (int32_t)t - pl_rs < 148;
             const bool fast = n == TICK && ((P.pos0 + t) & 3u) == 0 && !__ballot(overlay);
             if (fast) {
-                if (pre_t != t) {
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) pre[b] = *reinterpret_cast<const float4*>(yr + t + 64 * b + 4 * r);
-                }
-#pragma unroll
-                for (int b = 0; b < 3; ++b) *reinterpret_cast<float4*>(&yl[g][64 * b + 4 * r]) = pre[b];
+                const float4* src = reinterpret_cast<const float4*>(yr + t + 4 * r);   // blocks of 64 samples: +16 float4
+                if (pre_t != t) { pre0 = src[0]; pre1 = src[16]; pre2 = src[32]; }
+                float4* dst = reinterpret_cast<float4*>(&yl[g][4 * r]);
+                dst[0] = pre0; dst[16] = pre1; dst[32] = pre2;
                 if (t + 2 * TICK <= P.T) {
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) pre[b] = *reinterpret_cast<const float4*>(yr + t + TICK + 64 * b + 4 * r);
+                    pre0 = src[48]; pre1 = src[64]; pre2 = src[80];
                     pre_t = t + TICK;
                 }
             } else {
@@ -173,29 +200,35 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
             lds_sync();
             if (r == 0 && feed) {
                 float m2 = IirCoef::a2 * h1;
-                uint32_t i = 0;
-                if ((n & 3u) == 0) {
-                    float4 v = *reinterpret_cast<const float4*>(&yl[g][0]);
-                    for (; i < n; i += 4) {
-                        const float4 nx = *reinterpret_cast<const float4*>(&yl[g][i + 4 < n ? i + 4 : i]);  // next group in flight
-                        float4 o;
-                        o.x = iir_advance_pk(fabsf(v.x), h0, m2); h2 = h1; h1 = h0; h0 = o.x;
-                        o.y = iir_advance_pk(fabsf(v.y), h0, m2); h2 = h1; h1 = h0; h0 = o.y;
-                        o.z = iir_advance_pk(fabsf(v.z), h0, m2); h2 = h1; h1 = h0; h0 = o.z;
-                        o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
-                        *reinterpret_cast<float4*>(&hl[g][i]) = o;
-                        v = nx;
+                auto four = [&](const float4 v) -> float4 {
+                    float4 o;
+                    o.x = iir_advance_pk(fabsf(v.x), h0, m2); h2 = h1; h1 = h0; h0 = o.x;
+                    o.y = iir_advance_pk(fabsf(v.y), h0, m2); h2 = h1; h1 = h0; h0 = o.y;
+                    o.z = iir_advance_pk(fabsf(v.z), h0, m2); h2 = h1; h1 = h0; h0 = o.z;
+                    o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
+                    return o;
+                };
+                if (n == TICK) {   // straight-line: 12 blocks of 16 samples, the next block's reads in flight
+                    const float4* yv = reinterpret_cast<const float4*>(&yl[g][0]);
+                    float4* hv = reinterpret_cast<float4*>(&hl[g][0]);
+                    float4 a0 = yv[0], a1 = yv[1], a2 = yv[2], a3 = yv[3];
+#pragma unroll
+                    for (int b = 0; b < TICK / 16; ++b) {
+                        float4 n0 = a0, n1 = a1, n2 = a2, n3 = a3;
+                        if (b + 1 < TICK / 16) { n0 = yv[4 * b + 4]; n1 = yv[4 * b + 5]; n2 = yv[4 * b + 6]; n3 = yv[4 * b + 7]; }
+                        hv[4 * b] = four(a0); hv[4 * b + 1] = four(a1); hv[4 * b + 2] = four(a2); hv[4 * b + 3] = four(a3);
+                        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
                     }
+                } else if ((n & 3u) == 0) {
+                    for (uint32_t i = 0; i < n; i += 4) *reinterpret_cast<float4*>(&hl[g][i]) = four(*reinterpret_cast<const float4*>(&yl[g][i]));
                 } else {
-                    for (; i < n; ++i) {
+                    for (uint32_t i = 0; i < n; ++i) {
                         const float hn = iir_advance_pk(fabsf(yl[g][i]), h0, m2);
                         h2 = h1; h1 = h0; h0 = hn;
                         hl[g][i] = hn;
                     }
                 }
             }
-            // the history lives on lane 0 of the group: hand it to the other 15 (they replay the gate redundantly)
-            h0 = __shfl(h0, 16 * g); h1 = __shfl(h1, 16 * g); h2 = __shfl(h2, 16 * g);
             lds_sync();
             if (feed && valid) {
                 if (fast) {
@@ -237,11 +270,16 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
             }
         }
         t += n;
-        phase = (phase + n == TICK) ? 0u : phase + n;
+        if (phase + n == TICK) { phase = 0; ++k_cur; } else phase += n;
     }
     if (r == 0 && valid) {
         float* f = P.final_h + (size_t)c * 4;
         f[0] = h0; f[1] = h1; f[2] = h2;
+        GateExport e;
+        e.init = init; e.on = on; e.trig = trig; e.count = count; e.run_pos = run_pos;
+        e.h0 = h0; e.h1 = h1; e.h2 = h2; e.level = level; e.seg = seg;
+        e.end_in_run = end_in_run ? 1 : 0; e.end_t = end_t - (int32_t)P.T;
+        P.chain_out[c] = e;
     }
 }
 

@@ -75,6 +75,7 @@ struct SeqParams {
     unsigned long long* dbg;  // optional [channels][24] counters (diagnostics)
     const float* h;           // K2's limit-filter history, pitch ypitch (nullptr: no speculation, K5 runs the filter itself)
     const float* final_h;     // [C][4] K2's filter history after the last fed sample of the run
+    uint32_t* dropped;        // [C] out: this segment dropped the speculation (K2 must redo the channel's next segment from K5's state)
 };
 
 // LDS words for a wave of `ls` channels: ring, sync samples, llr, hist, outb, lsf columns; edges, src maps, lich map

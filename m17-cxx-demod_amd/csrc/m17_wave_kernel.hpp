@@ -743,6 +743,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
 
     // ---------------- save state ------------------------------------------------------------------------------
     if (s.spec_ok) { const float* f = P.final_h + (size_t)c * 4; s.h0 = f[0]; s.h1 = f[1]; s.h2 = f[2]; }
+    if (P.dropped && wl == 0) P.dropped[c] = s.spec_ok ? 0u : 1u;
     wave_lds_sync();
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(hot_lds);

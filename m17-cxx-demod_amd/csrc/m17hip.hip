@@ -35,17 +35,20 @@ struct m17hip_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;        // K3 runs here, concurrently with K1 (side2) and with K2/K5 of earlier segments (stream)
     hipStream_t side2 = nullptr;       // K1 of the segments of a run
+    hipStream_t side3 = nullptr;       // K2 of segment k+1 while K5 works on segment k
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<hipEvent_t> ev_fir, ev_dcd;  // per segment: K1 / K3 done
+    std::vector<hipEvent_t> ev_fir, ev_dcd, ev_gate, ev_redo;  // per segment: K1 / K3 / K2 (ahead) done, K2 redo done
     uint32_t maxC = 0, maxT = 0;
     size_t xpitch = 0, ypitch = 0;
     uint32_t ticks_cap = 0, rec_cap = 0;
     int16_t* xbuf = nullptr;
     float* ybuf = nullptr;
     float* hbuf = nullptr;            // K2's limit-filter history, same pitch as ybuf
-    float* final_h = nullptr;         // [maxC][4]
+    float* final_h = nullptr;         // [2][maxC][4], by segment parity
+    GateExport* gate_exp = nullptr;   // [maxC] K2's own state at the end of a segment
+    uint32_t* dropped = nullptr;      // [maxC] K5: the segment dropped the speculation
     bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
-    uint32_t seg_len = 96000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
+    uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     float* dcd_table = nullptr;
     DcdState* dcd_state = nullptr;
     SeqState* seq_state = nullptr;
@@ -353,7 +356,9 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->xbuf, C * c->xpitch * sizeof(int16_t));
     ALLOC(c->ybuf, C * c->ypitch * sizeof(float));
     ALLOC(c->hbuf, C * c->ypitch * sizeof(float));
-    ALLOC(c->final_h, C * 4 * sizeof(float));
+    ALLOC(c->final_h, 2 * C * 4 * sizeof(float));
+    ALLOC(c->gate_exp, C * sizeof(GateExport));
+    ALLOC(c->dropped, C * sizeof(uint32_t));
     ALLOC(c->dcd_table, C * c->ticks_cap * 12 * sizeof(float));
     ALLOC(c->dcd_state, C * sizeof(DcdState));
     ALLOC(c->seq_state, C * sizeof(SeqState));
@@ -382,6 +387,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     c->coef = build_coef();
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
+    if (hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)demod_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, wave_lds_words(8) * 4) != hipSuccess)
@@ -406,10 +412,11 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->side) hipStreamDestroy(c->side);
     if (c->side2) hipStreamDestroy(c->side2);
-    for (auto e : c->ev_fir) hipEventDestroy(e);
-    for (auto e : c->ev_dcd) hipEventDestroy(e);
+    if (c->side3) hipStreamDestroy(c->side3);
+    for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo})
+        for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h};
+                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -605,10 +612,11 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     const uint32_t seg_len = (!c->profile && c->seg_len) ? c->seg_len : T;
     const uint32_t nseg = (T + seg_len - 1) / seg_len;
     while (c->ev_fir.size() < nseg) {
-        hipEvent_t a, b;
-        HIPCHK(c, hipEventCreateWithFlags(&a, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&b, hipEventDisableTiming));
-        c->ev_fir.push_back(a); c->ev_dcd.push_back(b);
+        for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo}) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            v->push_back(e);
+        }
     }
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
@@ -621,22 +629,45 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipEventRecord(c->ev_fir[k], c->side2));
     }
     c->dbg_waves = c->profile ? C : 0;
+    // K2 launch: the whole segment from K5's state (first segment), ahead of K5 from K2's own state (later segments, on side3),
+    // or the redo of the channels whose K5 dropped the speculation in the previous segment (from K5's state again)
+    auto launch_gate = [&](uint32_t k, hipStream_t st, bool ahead, bool redo) -> int {
+        const uint32_t t0 = k * seg_len, len = std::min(seg_len, T - t0);
+        Timed tm(c, KT_GATE, st);
+        GateParams G{};
+        G.x = c->xbuf + t0; G.xpitch = c->xpitch; G.y = c->ybuf + t0; G.ypitch = c->ypitch; G.h = c->hbuf + t0;
+        G.dcd_table = c->dcd_table; G.ticks_cap = c->ticks_cap; G.state = c->seq_state;
+        G.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
+        G.chain_in = ahead ? c->gate_exp : nullptr; G.chain_out = c->gate_exp; G.only = redo ? c->dropped : nullptr;
+        G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags;
+        hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), 0, st, G);
+        HIPCHK(c, hipGetLastError());
+        return M17HIP_OK;
+    };
     for (uint32_t t0 = 0, k = 0; t0 < T; t0 += seg_len, ++k) {
         const uint32_t len = std::min(seg_len, T - t0);
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fir[k], 0));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dcd[k], 0));
-        if (c->speculate) {   // K2: replay the carrier-detect gate and run the limit filter ahead of K5 (needs K1's and K3's output)
-            Timed tm(c, KT_GATE);
-            GateParams G{};
-            G.x = c->xbuf + t0; G.xpitch = c->xpitch; G.y = c->ybuf + t0; G.ypitch = c->ypitch; G.h = c->hbuf + t0;
-            G.dcd_table = c->dcd_table; G.ticks_cap = c->ticks_cap; G.state = c->seq_state; G.final_h = c->final_h;
-            G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags;
-            hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), 0, c->stream, G);
-            HIPCHK(c, hipGetLastError());
+        if (c->speculate) {
+            if (k == 0) {
+                if ((r = launch_gate(0, c->stream, false, false))) return r;
+            } else {
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gate[k], 0));
+                if ((r = launch_gate(k, c->stream, false, true))) return r;
+            }
+            if (k + 1 < nseg) {   // the next segment's replay starts from this one's (now final) end state, beside K5
+                HIPCHK(c, hipEventRecord(c->ev_redo[k], c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->side3, c->ev_redo[k], 0));
+                HIPCHK(c, hipStreamWaitEvent(c->side3, c->ev_fir[k + 1], 0));
+                HIPCHK(c, hipStreamWaitEvent(c->side3, c->ev_dcd[k + 1], 0));
+                if ((r = launch_gate(k + 1, c->side3, true, false))) return r;
+                HIPCHK(c, hipEventRecord(c->ev_gate[k + 1], c->side3));
+            }
         }
         Timed tm(c, KT_SEQ);
         SeqParams P{};
-        P.h = c->speculate ? c->hbuf + t0 : nullptr; P.final_h = c->final_h;
+        P.h = c->speculate ? c->hbuf + t0 : nullptr; P.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
+        P.dropped = c->speculate ? c->dropped : nullptr;
         P.x = c->xbuf + t0; P.xpitch = c->xpitch; P.y = c->ybuf + t0; P.ypitch = c->ypitch;
         P.dcd_table = c->dcd_table; P.ticks_cap = c->ticks_cap; P.state = c->seq_state;
         P.recs = c->recs; P.rec_cap = c->rec_cap; P.rec_count = c->rec_count; P.overflow = c->overflow;

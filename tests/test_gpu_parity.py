@@ -329,7 +329,7 @@ def test_full_chain_run_in_segments(ctx, seg):
         got = ctx.frames()
         d = ctx.diag()
     finally:
-        ctx.tune(3, 96000)
+        ctx.tune(3, 48000)
     assert got.tobytes() == exp.tobytes() and got.size > C
     for f in ("dcd", "locked", "sample_index", "sync_index", "clock_index", "viterbi_cost", "n_diag", "demod_state", "n_frames"):
         assert np.array_equal(d[f], diags[f]), f
