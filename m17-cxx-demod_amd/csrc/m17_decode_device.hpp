@@ -189,11 +189,13 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
 // a frame completes on one channel at a time): lane l owns trellis state l & 15 (the four 16-lane groups compute the
 // same thing), the 16 decision bits of a step are one ballot, and the add-compare-select exchanges metrics between lanes
 // with register-to-register lane swaps (see below).  Columns have stride 1 here (per-wave LDS arrays).  `wl` = lane id in the wave.
+// LDS-only ordering between the lanes of one wave: the fences are restricted to the local address space so that global
+// loads in flight (window prefetches) are NOT waited for here.
 __device__ __forceinline__ void wave_lds_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 // Lane <-> trellis state mapping of the wave decoder.  A 4-bit "position" p lives in lane bits (5,4,1,0) (bits 3,2 number
 // four identical replicas).  Before step h the metric of state s sits at position rotr4(s, h mod 4); the two predecessors

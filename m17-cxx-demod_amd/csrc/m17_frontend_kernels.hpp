@@ -25,7 +25,7 @@ constexpr int FIR_THREADS = 256;
 constexpr int FIR_TILE = FIR_R * FIR_THREADS;  // 3840 outputs per workgroup (480000 = 125 tiles)
 constexpr int FIR_WIN = FIR_TILE + NTAPS - 1;  // 3988 staged samples
 
-__global__ __launch_bounds__(FIR_THREADS) void fir_rrc150_kernel(const int16_t* __restrict__ x, size_t xpitch,
+__global__ __launch_bounds__(FIR_THREADS, 3) void fir_rrc150_kernel(const int16_t* __restrict__ x, size_t xpitch,
                                                                 float* __restrict__ y, size_t ypitch, uint32_t T,
                                                                 uint32_t flags)
 {
@@ -300,9 +300,9 @@ __global__ __launch_bounds__(64) void dcd_kernel(const int16_t* __restrict__ x, 
     uint64_t tick = pos0 / TICK;
     uint32_t row = 0;
     auto lds_sync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     };
     auto tick_begin = [&] { if ((uint32_t)j == (uint32_t)(tick % 5)) s.acc = 0.f; };  // the sum that restarts with this tick
     auto tick_end = [&] {

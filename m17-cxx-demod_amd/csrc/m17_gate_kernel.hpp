@@ -6,7 +6,7 @@
 // each — 43 % of K5's time.  Which samples are fed is decided by the carrier-detect gate, and the gate
 // follows the DCD table (K3) alone EXCEPT when the demodulator forces dcd.unlock() after losing sync
 // (M17Demodulator.h:396-404, 470-478 ...).  So this kernel replays the gate from the table under the assumption "no
-// forced unlock happens in this run", advances the IIR over exactly the samples the gate lets through — FOUR CHANNELS
+// forced unlock happens in this run", advances the IIR over exactly the samples the gate lets through — SIXTEEN CHANNELS
 // PER WAVE instruction — and leaves the filter history after every fed sample in hbuf.  K5 starts every run trusting
 // hbuf; the moment it forces an unlock while the gate trigger was set it drops the speculation for the rest of the
 // run, picks the filter state up from hbuf at that sample and carries the recurrence itself (the pre-existing path).
@@ -18,8 +18,10 @@
 // The first 148 matched-filter outputs of a run see the previous run's tail (Q2): they are recomputed here exactly
 // as K5's patch_run_start does, into LDS only — ybuf is never written by this kernel.
 //
-// Mapping: 16 lanes per channel, 4 channels per wave: loads, stores and the FIR patch are cooperative, the recurrence
-// itself runs on lane 0 of each 16-lane group (the filter history lives there only).
+// Mapping: 4 lanes per channel, 16 channels per wave: loads, stores and the FIR patch are cooperative, the recurrence
+// itself runs on lane 0 of each 4-lane group (the filter history lives there only) — one VALU instruction advances 16
+// channels.  The kernel is latency-bound (a lone wave per SIMD); few, fat waves keep the issue slots it takes from the
+// kernels running beside it small.
 #pragma once
 
 #include "m17_common.hpp"
@@ -61,7 +63,9 @@ struct GateParams {
     uint32_t flags;
 };
 
-constexpr int GT_CPW = 4;  // channels per wave
+constexpr int GT_LPC = 4;             // lanes per channel (cooperative loads / stores; the recurrence runs on lane 0 of them)
+constexpr int GT_CPW = 64 / GT_LPC;   // channels per wave
+constexpr int GT_F4 = TICK / 4 / GT_LPC;  // float4 per lane per tick
 
 __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
 {
@@ -69,8 +73,9 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
     __shared__ __attribute__((aligned(16))) float hl[GT_CPW][TICK];   // h0 after each of them
     __shared__ float pl[GT_CPW][148];                                   // patched first outputs of the current run
     __shared__ float pw[298];                                           // patch window: 149 snapshot + 148 run samples
+    __builtin_amdgcn_s_setprio(3);  // K5 of the next segment waits for this kernel: issue ahead of whatever shares the SIMD
     const int lane = threadIdx.x;
-    const int g = lane >> 4, r = lane & 15;
+    const int g = lane / GT_LPC, r = lane % GT_LPC;
     uint32_t c = blockIdx.x * GT_CPW + g;
     bool valid = c < P.C;
     if (!valid) c = P.C - 1;  // shadow the last channel, never store
@@ -108,9 +113,9 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
     int32_t pl_rs = 0;         // relative index of that run's first sample
 
     auto lds_sync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     };
     // DataCarrierDetect::update (:63-69) on the sums K3 left for the segment that ends with tick k (same arithmetic as
     // nf_dcd_update in m17_state.hpp)
@@ -123,7 +128,9 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
     uint32_t t = 0;
     uint32_t phase = (uint32_t)(P.pos0 % TICK);
     uint64_t k_cur = P.pos0 / TICK;   // absolute index of the tick the current piece lies in
-    float4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = pre0, pre2 = pre0;   // this lane's share of a tick of matched-filter samples, loaded one tick ahead
+    float4 pre[GT_F4];         // this lane's share of a tick of matched-filter samples, loaded one tick ahead
+#pragma unroll
+    for (int b = 0; b < GT_F4; ++b) pre[b] = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t pre_t = 0xFFFFFFFFu;
     while (t < P.T) {
         const uint32_t n = min(TICK - phase, P.T - t);   // a piece never crosses a tick boundary
@@ -133,8 +140,8 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         const unsigned long long pm = __ballot(need_patch);
         if (pm) {
             for (int gg = 0; gg < GT_CPW; ++gg) {
-                if (!((pm >> (16 * gg)) & 1ull)) continue;   // wave-uniform
-                const int src = 16 * gg;
+                if (!((pm >> (GT_LPC * gg)) & 1ull)) continue;   // wave-uniform
+                const int src = GT_LPC * gg;
                 const uint32_t cc = (uint32_t)__shfl((int)c, src);
                 const int32_t rp = __shfl(run_pos, src);
                 const int32_t rs = (int32_t)t - rp;           // relative index of the run's first sample (>= -148)
@@ -165,30 +172,32 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         // ---- the DCD sums this piece's update point (if it ends on one) will need: in flight during the recurrence ---------------
         const uint32_t te = t + n - 1u;                        // last sample of the piece
         const uint64_t k = k_cur;                              // tick that ends with it (if it ends a tick)
-        const bool upd = init <= 0 && count + n == (on ? 960u : 384u);
-        float l1 = 0.f, l2 = 1.f;
-        if (upd) {
-            const float* row = tab + (size_t)(k - P.tick_row0) * 12;
-            const uint32_t span = (uint32_t)(k + 1 - seg);
-            const int j = span > 5 ? 5 : (int)(seg % 5u);
-            l1 = row[j]; l2 = row[6 + j];
-        }
+        // (loaded unconditionally — a branch here would make the compiler wait for the loads at the join)
+        const uint64_t krow = min(k - P.tick_row0, (uint64_t)P.ticks_cap - 1);
+        const float* row = tab + (size_t)krow * 12;
+        const int jsum = (uint32_t)(k + 1 - seg) > 5 ? 5 : (int)(seg % 5u);
+        const float l1 = row[jsum], l2 = row[6 + jsum];
         // ---- feed the piece -----------------------------------------------------------------------------------------------
         if (__ballot(feed)) {
             // whole aligned ticks without patched outputs: 16-byte loads, issued one tick ahead
             const bool overlay = feed && pl_valid && (int32_t)t - pl_rs < 148;
             const bool fast = n == TICK && ((P.pos0 + t) & 3u) == 0 && !__ballot(overlay);
             if (fast) {
-                const float4* src = reinterpret_cast<const float4*>(yr + t + 4 * r);   // blocks of 64 samples: +16 float4
-                if (pre_t != t) { pre0 = src[0]; pre1 = src[16]; pre2 = src[32]; }
-                float4* dst = reinterpret_cast<float4*>(&yl[g][4 * r]);
-                dst[0] = pre0; dst[16] = pre1; dst[32] = pre2;
+                const float4* src = reinterpret_cast<const float4*>(yr + t) + r;   // lane r takes float4 r, r + GT_LPC, ...
+                if (pre_t != t) {
+#pragma unroll
+                    for (int b = 0; b < GT_F4; ++b) pre[b] = src[GT_LPC * b];
+                }
+                float4* dst = reinterpret_cast<float4*>(&yl[g][0]) + r;
+#pragma unroll
+                for (int b = 0; b < GT_F4; ++b) dst[GT_LPC * b] = pre[b];
                 if (t + 2 * TICK <= P.T) {
-                    pre0 = src[48]; pre1 = src[64]; pre2 = src[80];
+#pragma unroll
+                    for (int b = 0; b < GT_F4; ++b) pre[b] = src[TICK / 4 + GT_LPC * b];
                     pre_t = t + TICK;
                 }
             } else {
-                for (uint32_t i = r; i < n; i += 16) {
+                for (uint32_t i = r; i < n; i += GT_LPC) {
                     float v = 0.f;
                     if (feed) {
                         const int32_t j = (int32_t)(t + i) - pl_rs;   // position inside the run, meaningful while pl_valid
@@ -232,11 +241,12 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
             lds_sync();
             if (feed && valid) {
                 if (fast) {
+                    float4* o = reinterpret_cast<float4*>(hr + t) + r;
+                    const float4* i4 = reinterpret_cast<const float4*>(&hl[g][0]) + r;
 #pragma unroll
-                    for (int b = 0; b < 3; ++b)
-                        *reinterpret_cast<float4*>(hr + t + 64 * b + 4 * r) = *reinterpret_cast<const float4*>(&hl[g][64 * b + 4 * r]);
+                    for (int b = 0; b < GT_F4; ++b) o[GT_LPC * b] = i4[GT_LPC * b];
                 } else {
-                    for (uint32_t i = r; i < n; i += 16) hr[t + i] = hl[g][i];
+                    for (uint32_t i = r; i < n; i += GT_LPC) hr[t + i] = hl[g][i];
                 }
             }
             lds_sync();
