@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: Msamples/s demodulated (48 kSPS int16 4-FSK in -> decoded M17 frames) on MI355X.
 
-One "step" = one pass of the whole demodulation chain (K1 RRC FIR, K3 sliding-DFT carrier detect, K5 sequential
-demodulator with batched K4 Viterbi/frame decode, record compaction) over C channels x T samples of synthetic
+One "step" = one pass of the whole demodulation chain (K1 RRC FIR, K3 sliding-DFT carrier detect, K2 limit filter run
+ahead of K5, K5 sequential demodulator with K4 Viterbi/frame decode, record compaction) over C channels x T samples of synthetic
 baseband that is already resident in HBM.  N > 1: one process per GPU (torch.distributed / RCCL), channels sharded
 contiguously, no data-path collective; every step ends with the gather of the decoded frame records to all ranks.
 
@@ -149,7 +149,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get("channels") == C and tj.get("samples") == T and dom in tj.get("kernels", {}):
+        if tj.get("channels") == C and tj.get("samples") == T and tj.get("segment_samples") * launches_per_step == T and dom in tj.get("kernels", {}):
             traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]   # per launch (= per segment), like `achieved`
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
