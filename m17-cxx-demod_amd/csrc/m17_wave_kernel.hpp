@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
 
         // ---- bulk chunk: n samples during which the state machine only feeds the correlator (and, inside a frame, slices
         //      payload symbols at a fixed sample_index) ----------------------------------------------------------------------
-        enum { BULK_NONE, BULK_INIT, BULK_QUIET, BULK_FEED, BULK_FRAME, BULK_SEARCH };
+        enum { BULK_NONE, BULK_INIT, BULK_QUIET, BULK_FEED, BULK_FRAME, BULK_SEARCH, BULK_SYNCWIN };
         int mode = BULK_NONE;
         uint32_t n = 0, o1 = 0;
         bool completes = false;   // the chunk ends on the sample that completes the frame (BULK_FRAME) / leaves SYNC_WAIT (BULK_QUIET)
@@ -384,6 +384,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 const bool is_sync = s.st == ST_STREAM_SYNC || s.st == ST_PACKET_SYNC || s.st == ST_BERT_SYNC;
                 if (is_sync) {
                     if (s.sync_count < 77) { n = min((uint32_t)(77 - s.sync_count), lim); mode = BULK_QUIET; }
+                    else if (s.sync_count < 86) {   // the window where the next sync word is looked for (:420-574), up to the sample
+                        n = min(min(10u, (uint32_t)(86 - s.sync_count)), lim);   // before its trigger falls / EOT / the count runs out
+                        mode = BULK_SYNCWIN;
+                    }
                 } else if (s.st == ST_SYNC_WAIT) {  // do_sync_wait :583-593: count up to MAX_SYNC_COUNT, then one transition sample
                     const uint32_t q = s.sync_count < 86 ? (uint32_t)(86 - s.sync_count) : 0u;
                     n = min(q + 1u, lim);
@@ -430,10 +434,13 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             }
             if (n < 2u) mode = BULK_NONE;
         }
-        if (mode == BULK_SEARCH) {
-            // Up to 64 samples of sync-word search at once: the limit IIR is advanced as one chain (its trajectory kept in
-            // LDS), lane k then evaluates SyncWord::triggered (Correlator.h:150-157) for sample k; the samples before the
-            // first one that triggers are committed as quiet, the triggering one goes through the single-sample path.
+        if (mode == BULK_SEARCH || mode == BULK_SYNCWIN) {
+            // Up to 64 samples of sync-word search at once: the limit history of every sample is taken from hbuf (or, without
+            // K2, advanced as one chain into LDS), lane k then evaluates SyncWord::triggered (Correlator.h:150-157) for sample k.
+            // BULK_SEARCH (UNLOCKED): the samples before the first one that triggers are committed as quiet, the triggering one
+            // goes through the single-sample path.  BULK_SYNCWIN (*_SYNC states, sync_count 77..85): the quiet samples AND the
+            // samples of the trigger run (SyncWord::operator() :179-186 just stores them) are committed; the sample on which the
+            // trigger falls (peak search, state change), an EOT hit and the sample that exhausts the count stay single-sample.
             const unsigned long long b0 = now();
             ensure(n);
             float* W = reinterpret_cast<float*>(DL.soft);   // [80 + 64] correlator ring in time order, then the new samples
@@ -455,23 +462,40 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             }
             wave_lds_sync();
             const bool phase_a = s.missing_sync_count < 1920;
-            bool hit = false;
+            const int wd = (s.st == ST_STREAM_SYNC) ? 1 : 2;   // the word a *_SYNC state looks for
+            bool hit = false, trg = false;
+            float vk = 0.f;
             if (wl < n) {
                 const float lim_k = iir_output(hb[3u + wl], hb[2u + wl], hb[1u + wl]);
                 float r[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) r[i] = W[10u + wl + 10u * i];   // samples k-70, k-60, ..., k
-                auto trig = [&](int wd) {
+                auto corr = [&](int w_) {
                     float v = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { const float p = (float)SYNC_WORDS[wd][i] * r[i]; v = v + p; }
-                    return v > lim_k * SW_MAG1[wd] || v < lim_k * SW_MAG2[wd];
+                    for (int i = 0; i < 8; ++i) { const float p = (float)SYNC_WORDS[w_][i] * r[i]; v = v + p; }
+                    return v;
                 };
-                hit = phase_a ? trig(0) : (trig(1) || trig(2));
+                auto beyond = [&](int w_, float v) { return v > lim_k * SW_MAG1[w_] || v < lim_k * SW_MAG2[w_]; };
+                if (mode == BULK_SEARCH) {
+                    hit = phase_a ? beyond(0, corr(0)) : (beyond(1, corr(1)) || beyond(2, corr(2)));
+                } else {
+                    vk = corr(wd);
+                    trg = beyond(wd, vk);
+                    if (s.st == ST_STREAM_SYNC) { const float v3 = corr(3); hit = beyond(3, v3) && v3 > 0.1f; }   // EOT :424
+                }
             }
-            const unsigned long long mask = __ballot(hit);
-            const uint32_t f = mask ? (uint32_t)(__ffsll((long long)mask) - 1) : n;   // leading samples that stay quiet
+            unsigned long long mask = __ballot(hit);
+            const unsigned long long tmask = __ballot(trg);
+            const uint32_t was_trig = s.sw_trig[wd];
+            if (mode == BULK_SYNCWIN) {   // + the first sample on which the trigger falls
+                unsigned long long fall = ~tmask;
+                if (!was_trig) fall = tmask ? (fall & ~((2ull << (__ffsll((long long)tmask) - 1)) - 1ull)) : 0ull;
+                mask |= fall & ((1ull << n) - 1ull);
+            }
+            const uint32_t f = mask ? (uint32_t)(__ffsll((long long)mask) - 1) : n;   // leading samples that are committed here
             if (f > 0u) {
+                const uint32_t rp0 = s.ring_pos;
                 s.h0 = hb[2u + f]; s.h1 = hb[1u + f]; s.h2 = hb[f];
                 const uint32_t first = f > 80u ? f - 80u : 0u;
                 for (uint32_t o = first + wl; o < f; o += 64) ring[(s.ring_pos + o) % 80u] = W[80u + o];
@@ -480,7 +504,19 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 s.run_pos = min(148, s.run_pos + (int32_t)f);
                 s.count += f;
                 s.ck_count += f;
-                if (phase_a) s.missing_sync_count += (int32_t)f;
+                if (mode == BULK_SEARCH) {
+                    if (phase_a) s.missing_sync_count += (int32_t)f;
+                } else {
+                    s.sync_count += (int32_t)f;
+                    if (tmask & ((1ull << f) - 1ull)) {   // SyncWord::operator() on the triggered samples: (clear,) store at index()
+                        if (!was_trig) {
+                            if (wl < 10) swsm[wd * 10 + wl] = 0.f;
+                            wave_lds_sync();
+                            s.sw_trig[wd] = 1;
+                        }
+                        if (wl < f && trg) swsm[wd * 10 + (int)((rp0 + wl) % 10u)] = vk;
+                    }
+                }
                 wave_lds_sync();
                 t += f;
                 if (s.count == 960u) dcd_point_on(t - 1u);
@@ -488,7 +524,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 tk_search += now() - b0;
                 continue;
             }
-            mode = BULK_NONE;  // the very next sample triggers: single-sample path
+            mode = BULK_NONE;  // the very next sample needs the single-sample path
             tk_search += now() - b0;
         }
         if (mode != BULK_NONE) {
