@@ -196,21 +196,20 @@ __global__ __launch_bounds__(64) void limit_kernel(const float* __restrict__ y, 
 // them at the end of every tick: the state machine later picks the sum whose start matches its segment,
 // bit-exact with the reference's single accumulator whatever the cadence turned out to be.
 //
-// A float recurrence is sequential in time and a lone wave pays for every instruction it issues (~3 ns), so the kernel
-// is built around the fewest instructions per sample on the recurrence:
-//   * 16 LANES PER CHANNEL, 4 channels per wave.  Lane role (bin, j): the lane carries DFT bin `bin` (redundantly with
-//     the 7 other lanes of that bin — a VALU instruction costs the same for 1 or 64 lanes) and ONE of the six running
-//     sums, so a sample costs one accumulate instead of six.
+// A float recurrence is sequential in time, so a wave spends its life issuing one short instruction stream; what the
+// kernel costs the chip is (waves) x (instructions per sample), and a lone wave issues one instruction per ~2.6 ns
+// (tools/k3bench.hip).  Mapping: TWO LANES PER CHANNEL (lane parity = DFT bin), 32 channels per wave:
 //   * the complex recurrence on packed fp32 (v_pk_mul_f32 / v_pk_add_f32: IEEE mul/add on two floats per instruction,
 //     no contraction): t = Xr + delta; (ac, ad) = (t,t)*(cr,ci); (-bd, bc) = (Xi,Xi)*(-ci,cr); X = (ac + -bd, ad + bc);
-//     (p, q) = X*X; sum += p + q  — 7 VALU instructions per sample.
-//   * the time-parallel part (int16 -> float scaling of x[n] and x[n-120], delta) is done by the 16 lanes for a whole
-//     192-sample tick at once (8-byte loads, issued two ticks ahead of their use) and handed to the recurrence through
-//     LDS.  x[n-120] comes from the carried prefix of xbuf (XPRE >= 120), so there is no delay line to maintain.
-//   * the recurrence runs as straight-line 64-sample blocks in a pinned, software-pipelined issue order.
-// Measured (tools/k3bench.hip): a lone wave issues one VALU instruction per ~2.6 ns whether dependent or not, so the
-// time is instructions x 2.6 ns: 7 per sample on the recurrence + ~1 for conversion = 9.6 ms per 480 000 samples.
-// Sum 5 runs from the stream start (it is read at the first update point, sample 2303, only).
+//     (p, q) = X*X; n = p + q; the six running sums as three packed adds — 9 VALU instructions per sample for 32 channels.
+//   * the time-parallel part (int16 -> float scaling of x[n] and x[n-120], delta) is done for 64 samples of all 32
+//     channels at once (each lane converts half of its channel's block, 16-byte loads issued one block ahead) and handed
+//     to the recurrence through LDS (row pitch 68: conflict-free 16-byte reads).  x[n-120] comes from the carried prefix
+//     of xbuf (XPRE >= 120), so there is no delay line to maintain.
+// 128 waves for 4096 channels at ~0.42 wave-instructions per channel-sample: the kernel is latency-bound (~17 ms per
+// 480 000 samples) but leaves the SIMDs to the kernels it runs beside; earlier mappings with 16 lanes per channel were
+// faster alone (9.6 ms) and five times as expensive in issue slots.
+// Sum 5 runs from the stream start (it is read at the first update point only).
 // Table layout: [C][ticks][2 bins][6 sums].  Algorithmic bytes: 2 B/sample read (+ 48 B per 192 samples written).
 // =====================================================================================================
 struct DcdCoef { float c0r, c0i, c1r, c1i; };  // exp(-j 2 pi f/48000), f = 2400, 3600 — computed on the host
@@ -224,12 +223,13 @@ __device__ __forceinline__ float scale_sample_mul(int s, bool invert)
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int DCD_BLK = 64;  // samples per straight-line block of the recurrence = 16 lanes x 4
-constexpr int DCD_CPW = 4;   // channels per wave
+constexpr int DCD_BLK = 64;        // samples per block: conversion granule and straight-line length of the recurrence
+constexpr int DCD_CPW = 32;        // channels per wave
+constexpr int DCD_PITCH = DCD_BLK + 4;  // LDS row pitch in floats
 
-struct DcdLane {  // one (bin, sum) role of one channel
-    v2f X, cc, cs;  // DFT state (re, im); (cr, ci); (-ci, cr)
-    float acc;
+struct DcdLane {  // one bin of one channel
+    v2f X, cc, cs;        // DFT state (re, im); (cr, ci); (-ci, cr)
+    v2f a01, a23, a45;    // the six running sums
 };
 __device__ __forceinline__ void dcd_step(DcdLane& s, float delta)
 {
@@ -239,53 +239,21 @@ __device__ __forceinline__ void dcd_step(DcdLane& s, float delta)
     s.X = m1 + m2;                            // libstdc++ complex multiply: (ac - bd, ad + bc)
     const v2f p = s.X * s.X;
     const float nrm = p.x + p.y;
-    s.acc = s.acc + nrm;
-}
-// N steps as straight-line code in a pinned issue order.  A wave alone on its SIMD waits ~8 ns for the result of the
-// instruction it has just issued but can issue an independent one every ~3 ns, so the three-deep recurrence
-// (add -> mul -> add) is interleaved with the norm / accumulate work of the two previous samples: same operations on
-// the same values in the same order per variable, only the instruction order differs from dcd_step().
-#define M17_PIN() __builtin_amdgcn_sched_barrier(0)
-template <int N>
-__device__ __forceinline__ void dcd_steps_pipelined(DcdLane& s, const float (&d)[N])
-{
-    v2f P = {0.f, 0.f};   // X*X of the previous sample, norm not yet formed
-    float nrm = 0.f;      // norm of the sample before that, not yet accumulated
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        const float a = s.X.x + d[n];                M17_PIN();
-        v2f Pn = P;
-        if (n >= 1) { Pn = s.X * s.X;                M17_PIN(); }
-        const v2f m2 = v2f{s.X.y, s.X.y} * s.cs;     M17_PIN();
-        const v2f m1 = v2f{a, a} * s.cc;             M17_PIN();
-        if (n >= 3) { s.acc = s.acc + nrm;           M17_PIN(); }
-        if (n >= 2) { nrm = P.x + P.y;               M17_PIN(); }
-        s.X = m1 + m2;                               M17_PIN();
-        P = Pn;
-    }
-    // drain: norms of the last samples
-    if (N >= 3) { s.acc = s.acc + nrm; M17_PIN(); }
-    if (N >= 2) { nrm = P.x + P.y; M17_PIN(); }
-    const v2f Pl = s.X * s.X; M17_PIN();
-    if (N >= 2) { s.acc = s.acc + nrm; M17_PIN(); }
-    nrm = Pl.x + Pl.y; M17_PIN();
-    s.acc = s.acc + nrm; M17_PIN();
+    const v2f nn = {nrm, nrm};
+    s.a01 = s.a01 + nn; s.a23 = s.a23 + nn; s.a45 = s.a45 + nn;
 }
 
 // pos0: absolute index (since reset) of the first sample of this run — identical for every channel.
-constexpr int DCD_PF = 2;  // whole ticks of input in flight ahead of the recurrence (a tick is ~3 us of recurrence)
 __global__ __launch_bounds__(64) void dcd_kernel(const int16_t* __restrict__ x, size_t xpitch, DcdState* __restrict__ state,
                                                  float* __restrict__ table, uint32_t ticks_cap, uint32_t C, uint32_t T,
                                                  uint64_t pos0, DcdCoef k, uint32_t flags)
 {
-    __shared__ __attribute__((aligned(16))) float dl[DCD_CPW][TICK];
-    // (no s_setprio: later segments of this kernel have slack, the kernels it shares SIMDs with do not)
+    __shared__ __attribute__((aligned(16))) float dl[DCD_CPW][DCD_PITCH];
     const int lane = threadIdx.x;
-    const int g = lane >> 4, r = lane & 15, bin = r >> 3, j = r & 7;
+    const int g = lane >> 1, bin = lane & 1;
     uint32_t c = blockIdx.x * DCD_CPW + g;
-    const bool owner = c < C;
-    const bool live = owner && j < 6;  // lanes that own a sum of an existing channel (the others shadow and never store)
-    if (c >= C) c = C - 1;
+    const bool live = c < C;   // lanes beyond the last channel shadow it and never store
+    if (!live) c = C - 1;
     const bool invert = flags & 1u;
     const int16_t* xr = x + (size_t)c * xpitch + XPRE;
     DcdState* st = state + c;
@@ -293,9 +261,11 @@ __global__ __launch_bounds__(64) void dcd_kernel(const int16_t* __restrict__ x, 
     s.X = v2f{st->xr[bin], st->xi[bin]};
     s.cc = bin ? v2f{k.c1r, k.c1i} : v2f{k.c0r, k.c0i};
     s.cs = v2f{-s.cc.y, s.cc.x};
-    s.acc = st->acc[j < 6 ? j : 0][bin];
-    float* tab = table + (size_t)c * ticks_cap * 12 + bin * 6 + j;
-    float* mydl = dl[g];
+    s.a01 = v2f{st->acc[0][bin], st->acc[1][bin]};
+    s.a23 = v2f{st->acc[2][bin], st->acc[3][bin]};
+    s.a45 = v2f{st->acc[4][bin], st->acc[5][bin]};
+    float* tab = table + (size_t)c * ticks_cap * 12 + bin * 6;
+    const float* mydl = dl[g];
     uint32_t phase = (uint32_t)(pos0 % TICK);  // position inside the current tick (wave-uniform)
     uint64_t tick = pos0 / TICK;
     uint32_t row = 0;
@@ -304,96 +274,81 @@ __global__ __launch_bounds__(64) void dcd_kernel(const int16_t* __restrict__ x, 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     };
-    auto tick_begin = [&] { if ((uint32_t)j == (uint32_t)(tick % 5)) s.acc = 0.f; };  // the sum that restarts with this tick
+    auto tick_begin = [&] {  // the sum that restarts with this tick
+        const uint32_t j = (uint32_t)(tick % 5);
+        if (j == 0) s.a01.x = 0.f;
+        if (j == 1) s.a01.y = 0.f;
+        if (j == 2) s.a23.x = 0.f;
+        if (j == 3) s.a23.y = 0.f;
+        if (j == 4) s.a45.x = 0.f;
+    };
     auto tick_end = [&] {
-        if (live) tab[(size_t)row * 12] = s.acc;
+        if (live) {
+            float* o = tab + (size_t)row * 12;
+            *reinterpret_cast<float2*>(o) = make_float2(s.a01.x, s.a01.y);
+            *reinterpret_cast<float2*>(o + 2) = make_float2(s.a23.x, s.a23.y);
+            *reinterpret_cast<float2*>(o + 4) = make_float2(s.a45.x, s.a45.y);
+        }
         phase = 0; ++tick; ++row;
     };
-    // generic path (head / tail of a run, unaligned runs): up to 64 samples at a time, never across a tick boundary
-    auto slow_block = [&](uint32_t t0, uint32_t n) {
-        float4 dv;
-        float* d4 = &dv.x;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t i = 4u * r + q;
-            const bool in = i < n;
-            const int a = in ? (int)xr[(int64_t)t0 + i] : 0, b = in ? (int)xr[(int64_t)t0 + i - 120] : 0;
-            d4[q] = scale_sample_mul(a, invert) - scale_sample_mul(b, invert);
-        }
-        *reinterpret_cast<float4*>(mydl + 4 * r) = dv;
-        lds_sync();
+    auto conv = [&](int v) { return scale_sample_mul(v, invert); };
+    auto one_sample = [&](uint32_t t) {  // generic path: head / tail of a run
         if (phase == 0) tick_begin();
-        for (uint32_t i = 0; i < n; ++i) dcd_step(s, mydl[i]);
-        phase += n;
-        if (phase == TICK) tick_end();
-        lds_sync();
+        dcd_step(s, conv((int)xr[t]) - conv((int)xr[(int64_t)t - 120]));
+        if (++phase == TICK) tick_end();
     };
 
     uint32_t t = 0;
-    while (t < T && phase != 0) {  // head: up to the next tick boundary
-        const uint32_t n = min(min(64u, TICK - phase), T - t);
-        slow_block(t, n);
-        t += n;
-    }
-    // whole ticks: lane r of a channel converts samples 4r..4r+3 of each of the tick's three 64-sample blocks (8-byte loads)
-    if (((pos0 + t) & 3u) == 0 && (xpitch & 3u) == 0 && t + TICK <= T) {
-        int2 pa[DCD_PF][3], pb[DCD_PF][3];
-        auto issue = [&](int slot, uint32_t t0) {
+    while (t < T && (phase % DCD_BLK) != 0) { one_sample(t); ++t; }   // head: up to a block boundary of the tick
+    // whole blocks: lane (g, bin) converts samples [32 bin, 32 bin + 32) of its channel's block
+    if (t + DCD_BLK <= T) {
+        int4 pa[4], pb[4];
+        auto issue = [&](uint32_t t0) {
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int16_t* p = xr + (size_t)t0 + 64 * b + 4 * r;
-                pa[slot][b] = *reinterpret_cast<const int2*>(p);
-                pb[slot][b] = *reinterpret_cast<const int2*>(p - 120);
+            for (int q = 0; q < 4; ++q) {
+                const int16_t* p = xr + (size_t)t0 + 32 * bin + 8 * q;
+                pa[q] = *reinterpret_cast<const int4*>(p);
+                pb[q] = *reinterpret_cast<const int4*>(p - 120);
             }
         };
-        const uint32_t nt = (T - t) / TICK;
-#pragma unroll
-        for (int q = 0; q < DCD_PF; ++q)
-            if ((uint32_t)q < nt) issue(q, t + q * TICK);
-        auto conv = [&](int v) { return scale_sample_mul(v, invert); };
         auto lo = [](int w) { return (int)(int16_t)(w & 0xFFFF); };
         auto hi = [](int w) { return w >> 16; };
-        for (uint32_t it = 0; it < nt; it += DCD_PF) {
+        issue(t);
+        for (; t + DCD_BLK <= T; t += DCD_BLK) {
+            float* wrow = dl[g] + 32 * bin;
 #pragma unroll
-            for (int q = 0; q < DCD_PF; ++q) {
-                if (it + q < nt) {  // wave-uniform
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) {
-                        const int2 a = pa[q][b], d = pb[q][b];
-                        float4 dv;
-                        dv.x = conv(lo(a.x)) - conv(lo(d.x));
-                        dv.y = conv(hi(a.x)) - conv(hi(d.x));
-                        dv.z = conv(lo(a.y)) - conv(lo(d.y));
-                        dv.w = conv(hi(a.y)) - conv(hi(d.y));
-                        *reinterpret_cast<float4*>(mydl + 64 * b + 4 * r) = dv;
-                    }
-                    lds_sync();
-                    if (it + q + DCD_PF < nt) issue(q, t + DCD_PF * TICK);  // this slot's next tick: in flight for DCD_PF ticks
-                    tick_begin();
-#pragma unroll 1
-                    for (int b = 0; b < 3; ++b) {
-                        float d[DCD_BLK];
-#pragma unroll
-                        for (int u = 0; u < DCD_BLK / 4; ++u) {
-                            const float4 v = *reinterpret_cast<const float4*>(mydl + 64 * b + 4 * u);
-                            d[4 * u] = v.x; d[4 * u + 1] = v.y; d[4 * u + 2] = v.z; d[4 * u + 3] = v.w;
-                        }
-                        dcd_steps_pipelined<DCD_BLK>(s, d);
-                    }
-                    tick_end();
-                    lds_sync();
-                    t += TICK;
-                }
+            for (int q = 0; q < 4; ++q) {
+                const int4 a = pa[q], d = pb[q];
+                float4 u, v;
+                u.x = conv(lo(a.x)) - conv(lo(d.x)); u.y = conv(hi(a.x)) - conv(hi(d.x));
+                u.z = conv(lo(a.y)) - conv(lo(d.y)); u.w = conv(hi(a.y)) - conv(hi(d.y));
+                v.x = conv(lo(a.z)) - conv(lo(d.z)); v.y = conv(hi(a.z)) - conv(hi(d.z));
+                v.z = conv(lo(a.w)) - conv(lo(d.w)); v.w = conv(hi(a.w)) - conv(hi(d.w));
+                *reinterpret_cast<float4*>(wrow + 8 * q) = u;
+                *reinterpret_cast<float4*>(wrow + 8 * q + 4) = v;
             }
+            lds_sync();
+            if (t + 2 * DCD_BLK <= T) issue(t + DCD_BLK);   // in flight while the recurrence below runs
+            if (phase == 0) tick_begin();
+            float d[DCD_BLK];
+#pragma unroll
+            for (int u = 0; u < DCD_BLK / 4; ++u) {
+                const float4 v = *reinterpret_cast<const float4*>(mydl + 4 * u);
+                d[4 * u] = v.x; d[4 * u + 1] = v.y; d[4 * u + 2] = v.z; d[4 * u + 3] = v.w;
+            }
+#pragma unroll
+            for (int u = 0; u < DCD_BLK; ++u) dcd_step(s, d[u]);
+            phase += DCD_BLK;
+            if (phase == TICK) tick_end();
+            lds_sync();
         }
     }
-    while (t < T) {  // tail (or a whole unaligned run)
-        const uint32_t n = min(min(64u, TICK - phase), T - t);
-        slow_block(t, n);
-        t += n;
+    for (; t < T; ++t) one_sample(t);  // tail
+    if (live) {
+        st->xr[bin] = s.X.x; st->xi[bin] = s.X.y;
+        st->acc[0][bin] = s.a01.x; st->acc[1][bin] = s.a01.y; st->acc[2][bin] = s.a23.x;
+        st->acc[3][bin] = s.a23.y; st->acc[4][bin] = s.a45.x; st->acc[5][bin] = s.a45.y;
     }
-    if (live) st->acc[j][bin] = s.acc;
-    if (owner && j == 0) { st->xr[bin] = s.X.x; st->xi[bin] = s.X.y; }
 }
 
 }  // namespace m17

@@ -623,6 +623,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork, 0));
     for (uint32_t k = 0; k < nseg; ++k) {
         const uint32_t t0 = k * seg_len, len = std::min(seg_len, T - t0);
+        if (k == 1) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fir[0], 0));   // segment 0's front end first: K2/K5 wait for it
         if ((r = launch_dcd(c, C, len, flags, c->side, t0))) return r;
         HIPCHK(c, hipEventRecord(c->ev_dcd[k], c->side));
         if ((r = launch_fir(c, C, len, flags, c->side2, t0))) return r;
