@@ -387,7 +387,11 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     c->coef = build_coef();
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
-    if (hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
+    {   // the replay stream outranks the others: its few workgroups must not queue behind K5's thousand
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return fail(M17HIP_EHIP);
+        if (hipStreamCreateWithPriority(&c->side3, hipStreamNonBlocking, greatest) != hipSuccess) return fail(M17HIP_EHIP);
+    }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)demod_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, wave_lds_words(8) * 4) != hipSuccess)
