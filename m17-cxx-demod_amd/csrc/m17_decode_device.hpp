@@ -47,6 +47,25 @@ struct DecodeLds {
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 template <typename T> __device__ __forceinline__ M17_LDS T* as_lds(T* p) { return (M17_LDS T*)p; }
 template <typename T> __device__ __forceinline__ const M17_LDS T* as_lds(const T* p) { return (const M17_LDS T*)p; }
+// whole-struct copies out of / into LDS (C++ copy constructors do not take address-space qualified objects)
+template <typename T> __device__ __forceinline__ T lds_get(const M17_LDS T* p)
+{
+    static_assert(sizeof(T) % 4 == 0, "word-sized structs only");
+    T v;
+    const M17_LDS uint32_t* s = reinterpret_cast<const M17_LDS uint32_t*>(p);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 4); ++k) d[k] = s[k];
+    return v;
+}
+template <typename T> __device__ __forceinline__ void lds_put(M17_LDS T* p, const T& v)
+{
+    static_assert(sizeof(T) % 4 == 0, "word-sized structs only");
+    M17_LDS uint32_t* d = reinterpret_cast<M17_LDS uint32_t*>(p);
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 4); ++k) d[k] = s[k];
+}
 
 __device__ __forceinline__ int llr_at(const uint32_t* llr, int stride, int lane, int idx)
 {

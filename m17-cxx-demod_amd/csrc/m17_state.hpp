@@ -32,7 +32,7 @@ struct Hot {  // per-channel scalars kept in registers while the kernel runs
     int32_t sync_count, missing_sync_count, initializing;
     uint32_t spec_ok;           // this run still trusts K2's speculative limit-filter history (m17_gate_kernel.hpp)
 };
-struct Cold {  // per-channel state that stays in global memory (touched by out-of-line helpers only)
+struct Cold {  // per-channel state touched a few times per frame (out-of-line helpers); lives in LDS while K5 runs, like Hot
     Kal2 ck, kmin, kmax;
     uint32_t dev_reset;
     float dcd_level;
@@ -90,9 +90,9 @@ __device__ __forceinline__ void kal_reset(Kal2& k, float z)
     k.p00 = 4.f; k.p01 = 0.f; k.p10 = 0.f; k.p11 = (float)0.00000025;
 }
 // wrap != 0: KalmanFilter<float,SPS> (index filter, modulo SPS); 0: SymbolKalmanFilter.  State in global memory.
-__device__ __noinline__ void kal_update(Kal2* kp, float z, uint32_t dt_u, int wrap)
+__device__ __noinline__ void kal_update(M17_LDS Kal2* kp, float z, uint32_t dt_u, int wrap)
 {
-    Kal2 k = *kp;
+    Kal2 k = lds_get(kp);
     const float F00 = 1.f, F01 = (float)dt_u, F10 = 0.f, F11 = 1.f;
     const float Q00 = (float)6.25e-13, Q01 = (float)1.25e-12, Q10 = (float)1.25e-12, Q11 = (float)2.50e-12;
     const float nx0 = F00 * k.x0 + F01 * k.x1;
@@ -128,7 +128,7 @@ __device__ __noinline__ void kal_update(Kal2* kp, float z, uint32_t dt_u, int wr
     const float n10 = (float)((double)k.p10 - (KH10 * (double)k.p00 + KH11 * (double)k.p10));
     const float n11 = (float)((double)k.p11 - (KH10 * (double)k.p01 + KH11 * (double)k.p11));
     k.p00 = n00; k.p01 = n01; k.p10 = n10; k.p11 = n11;
-    *kp = k;
+    lds_put(kp, k);
 }
 
 __device__ __forceinline__ int32_t wrap10(int32_t v)
@@ -184,7 +184,7 @@ __device__ __forceinline__ int32_t clock_predict(float sample_est, float clock_e
 // ---- out-of-line helpers on COLD state ------------------------------------------------------------------------------
 // M17Demodulator::update_values (:233-241) = Correlator::outer_symbol_levels (Correlator.h:81-114) +
 // FreqDevEstimator::update (FreqDevEstimator.h:31-48).  Returns (idev, offset).
-__device__ __noinline__ float2 nf_update_values(Cold* cd, const float* ring, int stride, int lane, uint32_t si)
+__device__ __noinline__ float2 nf_update_values(M17_LDS Cold* cd, const float* ring, int stride, int lane, uint32_t si)
 {
     float min_sum = 0.f, max_sum = 0.f;
     uint32_t min_count = 0, max_count = 0;
@@ -206,15 +206,15 @@ __device__ __noinline__ float2 nf_update_values(Cold* cd, const float* ring, int
     const float mx = max_count > 0 ? max_sum / (float)max_count : hi;
     kal_update(&cd->kmin, mn, 192u, 0);
     kal_update(&cd->kmax, mx, 192u, 0);
-    const Kal2 a = cd->kmin, b = cd->kmax;
+    const Kal2 a = lds_get(&cd->kmin), b = lds_get(&cd->kmax);
     float offset = (float)((double)(b.x0 + a.x0) / 2.);
     float idev = (float)(6.0 / (double)(b.x0 - a.x0));
     uint32_t rst = cd->dev_reset;
     if (isnan(a.x0) || isnan(a.x1) || isnan(b.x0) || isnan(b.x1)) rst = 1;
     if (rst) {
         Kal2 k;
-        kal_reset(k, mn); cd->kmin = k;
-        kal_reset(k, mx); cd->kmax = k;
+        kal_reset(k, mn); lds_put(&cd->kmin, k);
+        kal_reset(k, mx); lds_put(&cd->kmax, k);
         offset = (mn + mx) / 2.f;
         idev = (float)(6.0 / (double)(mx - mn));
     }
@@ -223,7 +223,7 @@ __device__ __noinline__ float2 nf_update_values(Cold* cd, const float* ring, int
 }
 struct ClockOut { float sample_est, clock_est; int32_t sample_index; };
 // ClockRecovery::update(uint8_t) (ClockRecovery.h:54-67)
-__device__ __noinline__ ClockOut nf_clock_update_idx(Cold* cd, uint32_t index, uint32_t ck_count)
+__device__ __noinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32_t index, uint32_t ck_count)
 {
     kal_update(&cd->ck, (float)index, ck_count, 10);
     ClockOut o;
@@ -233,7 +233,7 @@ __device__ __noinline__ ClockOut nf_clock_update_idx(Cold* cd, uint32_t index, u
     return o;
 }
 // DataCarrierDetect::update (:63-69) with the sums K3 produced for the segment [seg_start_tick, k]; returns the trigger.
-__device__ __noinline__ uint32_t nf_dcd_update(Cold* cd, const float* tab, uint64_t tick0, uint64_t k, uint32_t trig)
+__device__ __noinline__ uint32_t nf_dcd_update(M17_LDS Cold* cd, const float* tab, uint64_t tick0, uint64_t k, uint32_t trig)
 {
     const float* row = tab + (size_t)(k - tick0) * 12;
     const uint32_t span = (uint32_t)(k + 1 - cd->seg_start_tick);
@@ -245,32 +245,19 @@ __device__ __noinline__ uint32_t nf_dcd_update(Cold* cd, const float* tab, uint6
     return trig ? (level > 0.1f) : (level > 4.0f);
 }
 // arguments of the diagnostic callback (M17Demodulator.h:681-685, 746-750)
-__device__ __noinline__ void nf_fire_diag(Cold* cd, uint32_t dcd_on, float evm_arg, float idev, float offset, uint32_t locked, float clock,
+__device__ __noinline__ void nf_fire_diag(M17_LDS Cold* cd, uint32_t dcd_on, float evm_arg, float idev, float offset, uint32_t locked, float clock,
                                           uint32_t sample_index, uint32_t sync_index, int32_t clock_index, uint32_t vcost)
 {
-    Diag d = cd->diag;
+    Diag d = lds_get(&cd->diag);
     d.dcd = (int32_t)dcd_on; d.evm = evm_arg; d.deviation = 2400.f / idev; d.offset = offset;
     d.locked = (int32_t)locked; d.clock = clock; d.sample_index = (int32_t)sample_index;
     d.sync_index = (int32_t)sync_index; d.clock_index = (int32_t)(uint8_t)clock_index;
     d.viterbi_cost = (int32_t)vcost; d.dcd_level = cd->dcd_level; d.n_diag++;
-    cd->diag = d;
+    lds_put(&cd->diag, d);
 }
 __device__ __noinline__ void nf_snapshot_hist(int16_t* hist, const int16_t* xr, uint32_t te)
 {
     for (int k = 0; k < 149; ++k) hist[k] = xr[(int64_t)te - 148 + k];
 }
-// M17FrameDecoder::operator() on the lane's parked frame; returns (viterbi_cost, decoder state)
-__device__ __noinline__ uint2 nf_decode(const DecodeTables* tb, DecodeLds L, int lane, uint32_t sync_type, Cold* cd, uint32_t cost_in,
-                                        FrameRec* rec_base, uint32_t rec_cap, uint32_t channel, uint64_t pos, uint32_t* overflow)
-{
-    DecoderRegs D{cd->dec_state, cd->lich_segments, cd->stale401};
-    RecSink S{rec_base, rec_cap, nullptr, nullptr, channel, pos, sync_type, overflow};
-    uint32_t n_run = cd->n_run, seq = cd->seq;
-    const uint32_t cost = decode_frame(tb, L, lane, sync_type, D, cost_in, S, n_run, seq);
-    cd->dec_state = D.state; cd->lich_segments = D.lich_segments; cd->stale401 = D.stale401;
-    cd->n_run = n_run; cd->seq = seq;
-    return make_uint2(cost, D.state);
-}
-
 // =====================================================================================================
 }  // namespace m17

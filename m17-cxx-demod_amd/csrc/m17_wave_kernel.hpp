@@ -41,11 +41,11 @@ constexpr int WV_WIN = 1024;                                            // LDS w
 constexpr int WV_PF = 512;                                              // prefetch granule: 8 samples per lane in flight
 constexpr int WV_YCH = 480;                                             // largest bulk chunk (<= WV_PF)
 constexpr int WV_TAB_WORDS = 64 + 4 * 244 + 48 + 152;                   // per block: llr edges, source maps, lich map, FIR taps
-constexpr int WV_WAVE_WORDS = 80 + 40 + 92 + 122 + 8 + 8 + WV_WIN + 96 + 488 + 64; // per wave: ring, sync samples, llr, hist, outb, lsf, sample window, evm terms, decoder soft bits, hot state
+constexpr int WV_WAVE_WORDS = 80 + 40 + 92 + 122 + 8 + 8 + WV_WIN + 96 + 488 + 64 + 48; // per wave: ring, sync samples, llr, hist, outb, lsf, sample window, evm terms, decoder soft bits, hot state, cold state
 constexpr int wave_lds_words(int waves_per_block) { return WV_TAB_WORDS + waves_per_block * WV_WAVE_WORDS; }
 
 // M17FrameDecoder::operator() on the wave's completed frame; returns (viterbi_cost, decoder state)
-__device__ __forceinline__ uint2 nf_decode_wave(const DecodeTables* tb, DecodeLds L, int wl, uint32_t sync_type, Cold* cd, uint32_t cost_in,
+__device__ __forceinline__ uint2 nf_decode_wave(const DecodeTables* tb, DecodeLds L, int wl, uint32_t sync_type, M17_LDS Cold* cd, uint32_t cost_in,
                                              FrameRec* rec_base, uint32_t rec_cap, uint32_t channel, uint64_t pos, uint32_t* overflow)
 {
     DecoderRegs D{cd->dec_state, cd->lich_segments, cd->stale401};
@@ -104,7 +104,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
 
     const bool invert = P.flags & 1u;
     SeqState* gs = P.state + c;
-    Cold* cd = &gs->cold;  // touched a few times per frame only: stays in global memory
+    // ... and so does the cold state (Kalman filters, decoder registers, diagnostics): its users are out-of-line helpers whose
+    // global round trips (~1 us each, several in a row) made a single-sample step cost 6 us
+    static_assert(sizeof(Cold) <= 48 * 4, "Cold must fit its LDS slot");
+    M17_LDS Cold* cd = as_lds(reinterpret_cast<Cold*>(reinterpret_cast<uint32_t*>(hot_lds) + 64));
     // The hot scalars live in LDS, not in registers: every lane holds the same values anyway, and with a 128-VGPR budget
     // (4 waves per SIMD) keeping ~45 of them live across the whole loop spills to scratch (= HBM latency); an LDS word is
     // 64 cycles away and costs no register between uses.
@@ -112,6 +115,11 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&gs->hot);
         uint32_t* dst = reinterpret_cast<uint32_t*>(hot_lds);
         for (int k = wl; k < (int)(sizeof(Hot) / 4); k += 64) dst[k] = src[k];
+    }
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&gs->cold);
+        M17_LDS uint32_t* dst = reinterpret_cast<M17_LDS uint32_t*>(cd);
+        for (int k = wl; k < (int)(sizeof(Cold) / 4); k += 64) dst[k] = src[k];
     }
     Hot& s = *hot_lds;
     const float* hrow = P.h ? P.h + (size_t)c * P.ypitch + YPRE : nullptr;  // K2's filter history for this channel
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         if (s.need_clock_reset) {
             Kal2 k;
             kal_reset(k, (float)s.sync_sample_index);  // ClockRecovery::reset :33-39
-            cd->ck = k;
+            lds_put(&cd->ck, k);
             s.ck_count = 0;
             s.ck_sample_index = (int32_t)(int8_t)(float)s.sync_sample_index;
             s.ck_clock_est = 0.f;
@@ -786,10 +794,16 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         uint32_t* dst = reinterpret_cast<uint32_t*>(&gs->hot);
         for (int k = wl; k < (int)(sizeof(Hot) / 4); k += 64) dst[k] = src[k];
     }
-    Diag d = cd->diag;
+    Diag d = lds_get(&cd->diag);
     d.demod_state = s.st;
     d.n_frames = cd->seq;
-    cd->diag = d;
+    lds_put(&cd->diag, d);
+    wave_lds_sync();
+    {
+        const M17_LDS uint32_t* src = reinterpret_cast<const M17_LDS uint32_t*>(cd);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&gs->cold);
+        for (int k = wl; k < (int)(sizeof(Cold) / 4); k += 64) dst[k] = src[k];
+    }
     for (int k = wl; k < 80; k += 64) gs->ring[k] = ring[k];
     for (int k = wl; k < 40; k += 64) gs->sw_samples[k / 10][k % 10] = swsm[k];
     for (int k = wl; k < 92; k += 64) gs->llr[k] = DL.llr[k];
