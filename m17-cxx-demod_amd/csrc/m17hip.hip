@@ -37,7 +37,8 @@ struct m17hip_ctx {
     hipStream_t side2 = nullptr;       // K1 of the segments of a run
     hipStream_t side3 = nullptr;       // K2 of segment k+1 while K5 works on segment k
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<hipEvent_t> ev_fir, ev_dcd, ev_gate, ev_redo;  // per segment: K1 / K3 / K2 (ahead) done, K2 redo done
+    std::vector<hipEvent_t> ev_fir, ev_dcd, ev_gate, ev_redo, ev_seq;  // per segment: K1 / K3 / K2 (ahead) done, K2 redo done, K5 done
+    uint32_t front_ahead = 0;         // tuning knob 5: segments the front end (K1, K3) may run ahead of K5 (0 = unlimited, measured best)
     uint32_t maxC = 0, maxT = 0;
     size_t xpitch = 0, ypitch = 0;
     uint32_t ticks_cap = 0, rec_cap = 0;
@@ -49,6 +50,7 @@ struct m17hip_ctx {
     uint32_t* dropped = nullptr;      // [maxC] K5: the segment dropped the speculation
     bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
+    uint32_t seg0_len = 11520;        // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others)
     float* dcd_table = nullptr;
     DcdState* dcd_state = nullptr;
     SeqState* seq_state = nullptr;
@@ -417,7 +419,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     if (c->side) hipStreamDestroy(c->side);
     if (c->side2) hipStreamDestroy(c->side2);
     if (c->side3) hipStreamDestroy(c->side3);
-    for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo})
+    for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo, &c->ev_seq})
         for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
                     c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped};
@@ -614,9 +616,12 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     // Every K2 starts a fresh speculation from K5's own state, so a channel that had to drop it (forced unlock) carries the
     // limit filter itself only until the end of its segment.
     const uint32_t seg_len = (!c->profile && c->seg_len) ? c->seg_len : T;
-    const uint32_t nseg = (T + seg_len - 1) / seg_len;
+    // segment k covers [seg_t0(k), seg_t0(k + 1)): a short first one (its front end and K2 are all K5 has to wait for), then equal ones
+    const uint32_t seg0 = (seg_len < T && c->seg0_len && c->seg0_len < seg_len) ? c->seg0_len : seg_len;
+    const uint32_t nseg = T <= seg0 ? 1u : 1u + (T - seg0 + seg_len - 1) / seg_len;
+    auto seg_t0 = [&](uint32_t k) -> uint32_t { return k == 0 ? 0u : std::min(T, seg0 + (k - 1u) * seg_len); };
     while (c->ev_fir.size() < nseg) {
-        for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo}) {
+        for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo, &c->ev_seq}) {
             hipEvent_t e;
             HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             v->push_back(e);
@@ -625,19 +630,32 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork, 0));
-    for (uint32_t k = 0; k < nseg; ++k) {
-        const uint32_t t0 = k * seg_len, len = std::min(seg_len, T - t0);
+    // The front end of segment k may be held back until K5 of segment k - front_ahead is done (tuning knob 5), to spread it over
+    // the step; measured, letting it run ahead freely is faster (K3 is a latency chain of 1.7 ms per segment: held back, it is
+    // what K5 ends up waiting for).
+    const uint32_t ahead = c->front_ahead ? c->front_ahead : nseg;
+    auto launch_front = [&](uint32_t k) -> int {
+        if (k >= nseg) return M17HIP_OK;
+        const uint32_t t0 = seg_t0(k), len = seg_t0(k + 1) - t0;
+        if (k >= ahead) {
+            HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_seq[k - ahead], 0));
+            HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_seq[k - ahead], 0));
+        }
         if (k == 1) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fir[0], 0));   // segment 0's front end first: K2/K5 wait for it
-        if ((r = launch_dcd(c, C, len, flags, c->side, t0))) return r;
+        int r2;
+        if ((r2 = launch_dcd(c, C, len, flags, c->side, t0))) return r2;
         HIPCHK(c, hipEventRecord(c->ev_dcd[k], c->side));
-        if ((r = launch_fir(c, C, len, flags, c->side2, t0))) return r;
+        if ((r2 = launch_fir(c, C, len, flags, c->side2, t0))) return r2;
         HIPCHK(c, hipEventRecord(c->ev_fir[k], c->side2));
-    }
+        return M17HIP_OK;
+    };
+    for (uint32_t k = 0; k < ahead && k < nseg; ++k)
+        if ((r = launch_front(k))) return r;
     c->dbg_waves = c->profile ? C : 0;
     // K2 launch: the whole segment from K5's state (first segment), ahead of K5 from K2's own state (later segments, on side3),
     // or the redo of the channels whose K5 dropped the speculation in the previous segment (from K5's state again)
     auto launch_gate = [&](uint32_t k, hipStream_t st, bool ahead, bool redo) -> int {
-        const uint32_t t0 = k * seg_len, len = std::min(seg_len, T - t0);
+        const uint32_t t0 = seg_t0(k), len = seg_t0(k + 1) - t0;
         Timed tm(c, KT_GATE, st);
         GateParams G{};
         G.x = c->xbuf + t0; G.xpitch = c->xpitch; G.y = c->ybuf + t0; G.ypitch = c->ypitch; G.h = c->hbuf + t0;
@@ -649,8 +667,8 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipGetLastError());
         return M17HIP_OK;
     };
-    for (uint32_t t0 = 0, k = 0; t0 < T; t0 += seg_len, ++k) {
-        const uint32_t len = std::min(seg_len, T - t0);
+    for (uint32_t k = 0; k < nseg; ++k) {
+        const uint32_t t0 = seg_t0(k), len = seg_t0(k + 1) - t0;
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fir[k], 0));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dcd[k], 0));
         if (c->speculate) {
@@ -691,6 +709,8 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         default: hipLaunchKernelGGL(demod_wave_kernel<4>, grid, block, lds, c->stream, P); break;
         }
         HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev_seq[k], c->stream));
+        if ((r = launch_front(k + ahead))) return r;
     }
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
@@ -783,6 +803,14 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 3:  // samples per K2+K5 segment of a run (0 = whole run)
         if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
         c->seg_len = (uint32_t)value;
+        return M17HIP_OK;
+    case 5:  // segments the front end may run ahead of K5 (0 = unlimited)
+        if (value < 0 || value > 1000) return M17HIP_EINVAL;
+        c->front_ahead = (uint32_t)value;
+        return M17HIP_OK;
+    case 4:  // samples of the first segment of a run (0 = like the others)
+        if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
+        c->seg0_len = (uint32_t)value;
         return M17HIP_OK;
     default: return M17HIP_EINVAL;
     }

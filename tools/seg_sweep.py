@@ -10,8 +10,10 @@ ctx = m17hip.Context(C, T); ctx.upload(x)
 buf = torch.zeros(C * (2 * (T // 1920 + 2) + 4) * 64, dtype=torch.uint8, device='cuda')
 def step():
     ctx.reset(); ctx.run(); return ctx.frames_compact_device(buf.data_ptr(), buf.numel() // 64)
-for spec, seg in [(1, int(v)) for v in sys.argv[3].split(',')] + [(0, 0)]:
-    ctx.tune(2, spec); ctx.tune(3, seg)
+seg0s = [int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else [11520]
+if len(sys.argv) > 5: ctx.tune(5, int(sys.argv[5]))
+for spec, seg, seg0 in [(1, int(v), z) for v in sys.argv[3].split(',') for z in seg0s] + [(0, 0, 0)]:
+    ctx.tune(2, spec); ctx.tune(3, seg); ctx.tune(4, seg0)
     step(); torch.cuda.synchronize()
     ctx.timing(True); ctx.timing_reset()
     t0 = time.perf_counter()
@@ -20,4 +22,4 @@ for spec, seg in [(1, int(v)) for v in sys.argv[3].split(',')] + [(0, 0)]:
     dt = (time.perf_counter() - t0) / 3 * 1e3
     k = {name: ctx.timing_get(name)[0] / 3 for name in ('fir_rrc150', 'dcd', 'limit_track', 'demod_seq')}
     ctx.timing(False)
-    print(f'limit_ahead={spec} seg={seg}: {dt:.2f} ms/step  frames={n}  kernel ms/step: ' + ' '.join(f'{a}={b:.1f}' for a, b in k.items()), flush=True)
+    print(f'limit_ahead={spec} seg={seg} seg0={seg0}: {dt:.2f} ms/step  frames={n}  kernel ms/step: ' + ' '.join(f'{a}={b:.1f}' for a, b in k.items()), flush=True)
