@@ -132,7 +132,67 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
 #pragma unroll
     for (int b = 0; b < GT_F4; ++b) pre[b] = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t pre_t = 0xFFFFFFFFu;
+    // whole aligned tick, no patched outputs: lane r stages float4 r, r + GT_LPC, ... (16-byte loads issued one tick ahead)
+    auto stage_tick = [&]() {
+        const float4* src = reinterpret_cast<const float4*>(yr + t) + r;
+        if (pre_t != t) {
+#pragma unroll
+            for (int b = 0; b < GT_F4; ++b) pre[b] = src[GT_LPC * b];
+        }
+        float4* dst = reinterpret_cast<float4*>(&yl[g][0]) + r;
+#pragma unroll
+        for (int b = 0; b < GT_F4; ++b) dst[GT_LPC * b] = pre[b];
+        if (t + 2 * TICK <= P.T) {
+#pragma unroll
+            for (int b = 0; b < GT_F4; ++b) pre[b] = src[TICK / 4 + GT_LPC * b];
+            pre_t = t + TICK;
+        }
+    };
+    auto four = [&](const float4 v, float& m2) -> float4 {
+        float4 o;
+        o.x = iir_advance_pk(fabsf(v.x), h0, m2); h2 = h1; h1 = h0; h0 = o.x;
+        o.y = iir_advance_pk(fabsf(v.y), h0, m2); h2 = h1; h1 = h0; h0 = o.y;
+        o.z = iir_advance_pk(fabsf(v.z), h0, m2); h2 = h1; h1 = h0; h0 = o.z;
+        o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
+        return o;
+    };
+    auto iir_tick = [&]() {   // straight-line: 12 blocks of 16 samples, the next block's reads in flight
+        float m2 = IirCoef::a2 * h1;
+        const float4* yv = reinterpret_cast<const float4*>(&yl[g][0]);
+        float4* hv = reinterpret_cast<float4*>(&hl[g][0]);
+        float4 a0 = yv[0], a1 = yv[1], a2 = yv[2], a3 = yv[3];
+#pragma unroll
+        for (int b = 0; b < TICK / 16; ++b) {
+            float4 n0 = a0, n1 = a1, n2 = a2, n3 = a3;
+            if (b + 1 < TICK / 16) { n0 = yv[4 * b + 4]; n1 = yv[4 * b + 5]; n2 = yv[4 * b + 6]; n3 = yv[4 * b + 7]; }
+            hv[4 * b] = four(a0, m2); hv[4 * b + 1] = four(a1, m2); hv[4 * b + 2] = four(a2, m2); hv[4 * b + 3] = four(a3, m2);
+            a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+        }
+    };
+    auto store_tick = [&]() {
+        float4* o = reinterpret_cast<float4*>(hr + t) + r;
+        const float4* i4 = reinterpret_cast<const float4*>(&hl[g][0]) + r;
+#pragma unroll
+        for (int b = 0; b < GT_F4; ++b) o[GT_LPC * b] = i4[GT_LPC * b];
+    };
     while (t < P.T) {
+        // ---- steady state: every channel of the wave is inside a gated run, past its first 148 samples, and this tick holds
+        //      no update point — nothing but the filter -------------------------------------------------------------------------
+        {
+            const bool steady = init <= 0 && on != 0 && run_pos >= 148 && count + TICK < 960u;
+            if (phase == 0 && t + TICK <= P.T && ((P.pos0 + t) & 3u) == 0 && __ballot(!steady) == 0ull) {
+                stage_tick();
+                lds_sync();
+                if (r == 0) iir_tick();
+                lds_sync();
+                if (valid) store_tick();
+                lds_sync();
+                count += TICK;
+                t += TICK;
+                ++k_cur;
+                continue;
+            }
+        }
         const uint32_t n = min(TICK - phase, P.T - t);   // a piece never crosses a tick boundary
         const bool feed = init > 0 || on;
         // ---- first 148 outputs of a gated run: FIR over (snapshot of the previous run's tail | this run's samples) ------------
@@ -183,19 +243,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
             const bool overlay = feed && pl_valid && (int32_t)t - pl_rs < 148;
             const bool fast = n == TICK && ((P.pos0 + t) & 3u) == 0 && !__ballot(overlay);
             if (fast) {
-                const float4* src = reinterpret_cast<const float4*>(yr + t) + r;   // lane r takes float4 r, r + GT_LPC, ...
-                if (pre_t != t) {
-#pragma unroll
-                    for (int b = 0; b < GT_F4; ++b) pre[b] = src[GT_LPC * b];
-                }
-                float4* dst = reinterpret_cast<float4*>(&yl[g][0]) + r;
-#pragma unroll
-                for (int b = 0; b < GT_F4; ++b) dst[GT_LPC * b] = pre[b];
-                if (t + 2 * TICK <= P.T) {
-#pragma unroll
-                    for (int b = 0; b < GT_F4; ++b) pre[b] = src[TICK / 4 + GT_LPC * b];
-                    pre_t = t + TICK;
-                }
+                stage_tick();
             } else {
                 for (uint32_t i = r; i < n; i += GT_LPC) {
                     float v = 0.f;
@@ -208,43 +256,25 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
             }
             lds_sync();
             if (r == 0 && feed) {
-                float m2 = IirCoef::a2 * h1;
-                auto four = [&](const float4 v) -> float4 {
-                    float4 o;
-                    o.x = iir_advance_pk(fabsf(v.x), h0, m2); h2 = h1; h1 = h0; h0 = o.x;
-                    o.y = iir_advance_pk(fabsf(v.y), h0, m2); h2 = h1; h1 = h0; h0 = o.y;
-                    o.z = iir_advance_pk(fabsf(v.z), h0, m2); h2 = h1; h1 = h0; h0 = o.z;
-                    o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
-                    return o;
-                };
-                if (n == TICK) {   // straight-line: 12 blocks of 16 samples, the next block's reads in flight
-                    const float4* yv = reinterpret_cast<const float4*>(&yl[g][0]);
-                    float4* hv = reinterpret_cast<float4*>(&hl[g][0]);
-                    float4 a0 = yv[0], a1 = yv[1], a2 = yv[2], a3 = yv[3];
-#pragma unroll
-                    for (int b = 0; b < TICK / 16; ++b) {
-                        float4 n0 = a0, n1 = a1, n2 = a2, n3 = a3;
-                        if (b + 1 < TICK / 16) { n0 = yv[4 * b + 4]; n1 = yv[4 * b + 5]; n2 = yv[4 * b + 6]; n3 = yv[4 * b + 7]; }
-                        hv[4 * b] = four(a0); hv[4 * b + 1] = four(a1); hv[4 * b + 2] = four(a2); hv[4 * b + 3] = four(a3);
-                        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
-                    }
-                } else if ((n & 3u) == 0) {
-                    for (uint32_t i = 0; i < n; i += 4) *reinterpret_cast<float4*>(&hl[g][i]) = four(*reinterpret_cast<const float4*>(&yl[g][i]));
+                if (n == TICK) {
+                    iir_tick();
                 } else {
-                    for (uint32_t i = 0; i < n; ++i) {
-                        const float hn = iir_advance_pk(fabsf(yl[g][i]), h0, m2);
-                        h2 = h1; h1 = h0; h0 = hn;
-                        hl[g][i] = hn;
+                    float m2 = IirCoef::a2 * h1;
+                    if ((n & 3u) == 0) {
+                        for (uint32_t i = 0; i < n; i += 4) *reinterpret_cast<float4*>(&hl[g][i]) = four(*reinterpret_cast<const float4*>(&yl[g][i]), m2);
+                    } else {
+                        for (uint32_t i = 0; i < n; ++i) {
+                            const float hn = iir_advance_pk(fabsf(yl[g][i]), h0, m2);
+                            h2 = h1; h1 = h0; h0 = hn;
+                            hl[g][i] = hn;
+                        }
                     }
                 }
             }
             lds_sync();
             if (feed && valid) {
                 if (fast) {
-                    float4* o = reinterpret_cast<float4*>(hr + t) + r;
-                    const float4* i4 = reinterpret_cast<const float4*>(&hl[g][0]) + r;
-#pragma unroll
-                    for (int b = 0; b < GT_F4; ++b) o[GT_LPC * b] = i4[GT_LPC * b];
+                    store_tick();
                 } else {
                     for (uint32_t i = r; i < n; i += GT_LPC) hr[t + i] = hl[g][i];
                 }
