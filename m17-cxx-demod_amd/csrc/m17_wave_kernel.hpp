@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     DL.prof = nullptr;
     if constexpr (PROF) {
         DL.prof = P.dbg + (size_t)c * 24 + 9;
-        if (wl < 15) P.dbg[(size_t)c * 24 + 9 + wl] = 0;
+        if (wl < 15) P.dbg[(size_t)c * 24 + 9 + wl] = 0;   // slots 9..23
     }
     uint16_t* llr16 = reinterpret_cast<uint16_t*>(DL.llr);
 
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     mode = BULK_FRAME;
                 }
             }
-            if (n < 2u) mode = BULK_NONE;
+            if (n < 1u) mode = BULK_NONE;
         }
         if (mode == BULK_FRAME) {
             // every anti-phase clock_recovery.update() of the chunk (:601-606) must leave sample_index where it is
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     break;
                 }
             }
-            if (n < 2u) mode = BULK_NONE;
+            if (n < 1u) mode = BULK_NONE;
         }
         if (mode == BULK_SEARCH || mode == BULK_SYNCWIN) {
             // Up to 64 samples of sync-word search at once: the limit history of every sample is taken from hbuf (or, without
@@ -636,6 +636,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         // ---- one input sample: M17Demodulator::operator() :657-753 -----------------------------------------------------------
         const unsigned long long c0 = now();
         ++n_scalar;
+        if constexpr (PROF) { if (wl == 0) P.dbg[(size_t)c * 24 + 17 + 1 + min(s.st, 5u)] += 1; }
         const uint32_t tt = t;
         cur_tt = tt;
         s.count++;

@@ -17,6 +17,7 @@ for wpb in [int(v) for v in sys.argv[3].split(',')]:
     print('   ms (median channel): chunks %.2f [window %.2f symbols %.2f iir %.2f rest %.2f] search %.2f scalar %.2f decode %.2f patch %.2f carrier-off %.2f | unaccounted %.2f' % (m[1]/1e5, m[12]/1e5, m[13]/1e5, m[14]/1e5, (m[1]-m[12]-m[13]-m[14])/1e5, m[15]/1e5, m[2]/1e5, m[3]/1e5, m[8]/1e5, m[16]/1e5, (m[0]-m[1]-m[2]-m[3]-m[15]-m[16]-m[8])/1e5), flush=True)
     dr = dc[:, 17] > 0
     print('   channels that dropped the limit speculation: %d of %d; their total ms median %.1f max %.1f; others median %.1f max %.1f' % (dr.sum(), len(dr), np.median(dc[dr, 0]) / 1e5 if dr.any() else 0, dc[dr, 0].max() / 1e5 if dr.any() else 0, np.median(dc[~dr, 0]) / 1e5, dc[~dr, 0].max() / 1e5), flush=True)
+    print('   single-sample steps by state (median channel): UNLOCKED %d LSF_SYNC %d STREAM_SYNC %d PACKET_SYNC %d BERT_SYNC %d SYNC_WAIT/FRAME %d' % tuple(int(m[18 + q]) for q in range(6)), flush=True)
     tot = dc.sum(axis=0)
     order = np.argsort(-dc[:, 0])
     print('   slowest channels: ' + ' | '.join(f"ch{int(i)} tot={dc[i,0]/1e5:.1f}ms bulk={dc[i,1]/1e5:.1f} scal={dc[i,2]/1e5:.1f} dec={dc[i,3]/1e5:.1f} nb={int(dc[i,4])} ns={int(dc[i,5])} fl={int(dc[i,7])&0xFFFFFFFF} nd={int(dc[i,7])>>32} frames={int(d['n_frames'][i])} st={int(d['demod_state'][i])}" for i in order[:6]))
