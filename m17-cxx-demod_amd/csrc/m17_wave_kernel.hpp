@@ -337,6 +337,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     if (s.run_pos < 148 && (s.initializing || s.dcd_on)) patch_run_start(0);
 
     // ---------------- main loop (wave-uniform control flow) ------------------------------------------------------------
+    uint32_t flags_t = 0xFFFFFFFFu;   // sample whose index-0 prologue (:695-709) has already run during chunk selection
     while (t < P.T) {
         bool decode_due = false, tail_dcd = false;
         uint32_t te = 0;
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 uint32_t lim = min(room, 960u - s.count);
                 const uint32_t idx0 = s.ring_pos % 10u;  // correlator index of sample t
                 // the index-0 prologue (:695-709) does not depend on the sample values: run it now if sample t is an index-0 sample
-                if (idx0 == 0u && (s.need_clock_reset | s.need_clock_update)) clock_flags();
+                if (idx0 == 0u && (s.need_clock_reset | s.need_clock_update)) { clock_flags(); flags_t = t; }
                 if (s.need_clock_reset | s.need_clock_update) lim = min(lim, 10u - idx0);  // stop before the next index-0 sample
                 const bool is_sync = s.st == ST_STREAM_SYNC || s.st == ST_PACKET_SYNC || s.st == ST_BERT_SYNC;
                 if (is_sync) {
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             tk_scalar += now() - c0;
             continue;
         }
-        if (corr_index() == 0) clock_flags();
+        if (corr_index() == 0 && flags_t != tt) clock_flags();   // (once per index-0 sample: a pending reset AND update take two of them)
         s.ck_count++;
         if (s.st <= ST_BERT_SYNC && !(s.st >= ST_STREAM_SYNC && s.sync_count + 1 < 78)) load_r8();  // states that correlate
         switch (s.st) {
@@ -798,6 +799,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     Diag d = lds_get(&cd->diag);
     d.demod_state = s.st;
     d.n_frames = cd->seq;
+    d.pad[0] = s.ck_count;   // live counters at the end of the run (debugging aid, same words as the oracle's)
+    d.pad[1] = ((uint32_t)s.sync_count & 0xFFFFu) | ((uint32_t)s.missing_sync_count << 16);
     lds_put(&cd->diag, d);
     wave_lds_sync();
     {

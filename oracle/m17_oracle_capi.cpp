@@ -263,6 +263,9 @@ static size_t run_channel(const int16_t* s, size_t n, int invert, uint32_t chann
         diag->sync_index = g.sync_index; diag->clock_index = g.clock_index; diag->viterbi_cost = g.viterbi_cost;
         diag->dcd_level = g.dcd_level; diag->n_diag = g.n_diag; diag->demod_state = (uint32_t)d->st;
         diag->n_frames = (uint32_t)cnt;
+        // live counters at the end of the run (debugging aid; the HIP path fills the same words)
+        diag->pad[0] = (uint32_t)d->clock.count;
+        diag->pad[1] = ((uint32_t)d->sync_count & 0xFFFFu) | ((uint32_t)d->missing_sync_count << 16);
     }
     if (n_sym) *n_sym = ns;
     return cnt;
