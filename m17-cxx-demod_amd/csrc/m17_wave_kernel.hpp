@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     hit = phase_a ? beyond(0, corr(0)) : (beyond(1, corr(1)) || beyond(2, corr(2)));
                 } else {
                     vk = corr(wd);
-                    trg = beyond(wd, vk);
+                    trg = beyond(wd, vk) && vk != 0.f;   // SyncWord::operator() tests the RETURNED value: an exact 0 beyond a negative limit is no trigger
                     if (s.st == ST_STREAM_SYNC) { const float v3 = corr(3); hit = beyond(3, v3) && v3 > 0.1f; }   // EOT :424
                 }
             }

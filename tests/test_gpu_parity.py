@@ -364,6 +364,48 @@ def test_full_chain_two_bursts_across_segments(ctx):
     assert np.array_equal(d["dcd_level"], diags["dcd_level"], equal_nan=True)
 
 
+@pytest.mark.parametrize("seed", [101, 202, 303])
+def test_full_chain_random_scenarios(ctx, seed):
+    """Randomised streams: every channel is two or three bursts of a random kind (BERT / voice / packet), length, noise level,
+    lead-in loudness, DC offset, gain and symbol phase, separated by noise of random strength — acquisitions, lost syncs, carrier
+    drops and re-acquisitions at uncorrelated positions.  Run in 19 200-sample segments; records and diagnostics bit-exact."""
+    rng = np.random.default_rng(seed)
+    C, T = 48, 96000
+    x = np.zeros((C, T), dtype=np.int16)
+    for c in range(C):
+        pos = 0
+        while pos < T - 8000:
+            n = int(rng.integers(8000, 40000))
+            n = min(n, T - pos)
+            p = ol.gen_params(seed=int(rng.integers(1, 1 << 30)), kind=int(rng.integers(0, 3)), n_frames=int(rng.integers(2, 14)),
+                              lead_in=int(rng.integers(0, 4000)), lead_sigma=float(rng.choice([0.0, 300.0, 3000.0, 40000.0])),
+                              noise_sigma=float(rng.choice([0.0, 200.0, 800.0, 2000.0])), tail_sigma=float(rng.choice([0.0, 300.0, 3000.0])),
+                              dc_offset=float(rng.choice([0.0, 0.0, 500.0, -1500.0])), gain=float(rng.choice([1.0, 0.5, 1.5])),
+                              phase=int(rng.integers(-1, 10)), total=n)
+            x[c, pos:pos + n] = ol.generate(p)[:n]
+            pos += n
+    exp, counts, diags = _oracle_records(x)
+    assert exp.size > 4 * C
+    ctx.tune(3, 19200)
+    try:
+        ctx.upload(x)
+        ctx.reset()
+        ctx.run()
+        got = ctx.frames()
+        d = ctx.diag()
+    finally:
+        ctx.tune(3, 48000)
+    if got.tobytes() != exp.tobytes():
+        n = min(got.size, exp.size)
+        bad = sorted(set(int(exp[i]["channel"]) for i in range(n) if got[i].tobytes() != exp[i].tobytes()))
+        raise AssertionError(f"records differ: sizes {got.size}/{exp.size}, channels {bad[:16]}")
+    for f in ("dcd", "locked", "sample_index", "sync_index", "clock_index", "viterbi_cost", "n_diag", "demod_state", "n_frames"):
+        assert np.array_equal(d[f], diags[f]), f
+    for f in ("evm", "deviation", "offset", "clock", "dcd_level"):
+        assert np.array_equal(d[f], diags[f], equal_nan=True), f
+    assert np.array_equal(d["pad"], diags["pad"])   # live clock / sync counters at the end of the run
+
+
 def test_edge_cases(ctx):
     # silence with +-1 dither, pure loud noise, DC, a stream cut in the middle of a frame, an all-zero window (NaN poisoning, Q1)
     T = 20000

@@ -1,0 +1,33 @@
+"""Randomised parity sweep on the GPU box: the scenario generator of tests/test_gpu_parity.py::test_full_chain_random_scenarios over
+many seeds, both limit-filter modes, several segment lengths; prints the channels whose records or diagnostics differ from the oracle.
+Usage: parity_sweep.py <first seed> <n seeds>"""
+import sys, os, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import m17hip, oracle_lib as ol
+C, T = 64, 96000
+ctx = m17hip.Context(C, T)
+total_bad = 0
+for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
+    rng = np.random.default_rng(seed)
+    x = np.zeros((C, T), dtype=np.int16)
+    for c in range(C):
+        pos = 0
+        while pos < T - 8000:
+            n = min(int(rng.integers(6000, 40000)), T - pos)
+            p = ol.gen_params(seed=int(rng.integers(1, 1 << 30)), kind=int(rng.integers(0, 3)), n_frames=int(rng.integers(1, 16)),
+                              lead_in=int(rng.integers(0, 5000)), lead_sigma=float(rng.choice([0.0, 100.0, 1000.0, 10000.0, 40000.0])),
+                              noise_sigma=float(rng.choice([0.0, 100.0, 500.0, 1200.0, 2500.0])), tail_sigma=float(rng.choice([0.0, 100.0, 1000.0, 5000.0])),
+                              dc_offset=float(rng.choice([0.0, 0.0, 300.0, -2000.0, 6000.0])), gain=float(rng.choice([1.0, 0.3, 0.7, 1.6])),
+                              phase=int(rng.integers(-1, 10)), invert=0, total=n)
+            x[c, pos:pos + n] = ol.generate(p)[:n]; pos += n
+    inv = seed & 1
+    recs, counts, diags = ol.demod_batch(x, invert=inv, cap=2 * (T // 1920 + 2) + 4, threads=os.cpu_count())
+    for spec, seg in ((1, 19200), (1, int(rng.integers(3000, 30000))), (0, 0)):
+        ctx.tune(2, spec); ctx.tune(3, seg); ctx.upload(x); ctx.reset(); ctx.run(flags=inv)
+        got = ctx.frames(); d = ctx.diag()
+        bad = [c for c in range(C) if got[got['channel'] == c].tobytes() != recs[c, :counts[c]].tobytes()
+               or any(not np.array_equal(d[f][c:c + 1], diags[f][c:c + 1], equal_nan=True) for f in d.dtype.names if f in diags.dtype.names)]
+        total_bad += len(bad)
+        print(f'seed {seed} invert={inv} limit_ahead={spec} seg={seg}: frames {int(counts.sum())}, bad channels {bad}', flush=True)
+print('TOTAL bad channel-runs:', total_bad)
