@@ -109,6 +109,10 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         level = gs->cold.dcd_level;
         seg = gs->cold.seg_start_tick;
     }
+    // Started from K5's state: the three slots in front of the segment get the history it starts with.  (What is there is the
+    // previous segment's or run's tail, which is void if K5 had dropped the speculation there; a replay that continues from its own
+    // state finds its own output there.)
+    if (!P.chain_in && r == 0 && valid) { hr[-1] = h0; hr[-2] = h1; hr[-3] = h2; }
     bool pl_valid = false;     // pl[g] holds the patched outputs of the current run
     int32_t pl_rs = 0;         // relative index of that run's first sample
 

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 s.count += n;
                 s.ck_count += n;
                 if (mode == BULK_QUIET) {
-                    if (s.st == ST_SYNC_WAIT && completes) { s.sync_count = 86; s.need_clock_update = 1; s.st = ST_FRAME; }
+                    if (s.st == ST_SYNC_WAIT && completes) { s.sync_count = max(s.sync_count, 86); s.need_clock_update = 1; s.st = ST_FRAME; }
                     else s.sync_count += (int32_t)n;
                 }
             }

@@ -1,18 +1,22 @@
 """Debugging aid: first prefix length at which the HIP chain and the oracle disagree on one channel's live state (demod state, clock
-count, sync counters, frame count, last diagnostics) — usage: dbg_bisect.py <x.npy> <channel> [lo hi]"""
+count, sync counters, frame count, last diagnostics) — usage: [SPEC=0|1 SEG=n INV=0|1] dbg_bisect.py <x.npy> <channel> [lo hi]"""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import m17hip, oracle_lib as ol
-x = np.load(sys.argv[1])[int(sys.argv[2]):int(sys.argv[2]) + 1].copy()
-x = np.concatenate([x, x])  # two identical rows (a context wants >= 1 channel; keeps shapes simple)
-ctx = m17hip.Context(2, x.shape[1]); ctx.tune(2, 0); ctx.tune(3, 0)
+CH = int(sys.argv[2])
+FULL = int(os.environ.get('FULL', 0))   # 1: run the whole batch (neighbouring channels share waves), compare channel CH
+x = np.load(sys.argv[1])
+if not FULL:
+    x = np.concatenate([x[CH:CH + 1], x[CH:CH + 1]]); CH = 0
+SPEC, SEG, INV = int(os.environ.get('SPEC', 0)), int(os.environ.get('SEG', 0)), int(os.environ.get('INV', 0))
+ctx = m17hip.Context(x.shape[0], x.shape[1]); ctx.tune(2, SPEC); ctx.tune(3, SEG); ctx.tune(4, int(os.environ.get('SEG0', 0)))
 FIELDS = ('demod_state', 'n_frames', 'n_diag', 'dcd', 'locked', 'sample_index', 'sync_index', 'clock_index', 'viterbi_cost', 'clock', 'evm', 'offset', 'deviation', 'dcd_level')
 def live(n):
-    recs, counts, diags = ol.demod_batch(x[:, :n], cap=256, threads=2)
-    ctx.upload(x[:, :n]); ctx.reset(); ctx.run(); d = ctx.diag()
-    f = lambda q: tuple(np.asarray(q[k][0]).tobytes() for k in FIELDS) + (q['pad'][0].tobytes(),)
-    return f(d), f(diags), d, diags
+    recs, counts, diags = ol.demod_batch(x[CH:CH + 1, :n], invert=INV, cap=256, threads=1)
+    ctx.upload(x[:, :n]); ctx.reset(); ctx.run(flags=INV); d = ctx.diag()
+    f = lambda q, i: tuple(np.asarray(q[k][i]).tobytes() for k in FIELDS) + (q['pad'][i].tobytes(),)
+    return f(d, CH), f(diags, 0), d[CH:CH + 1], diags
 lo = int(sys.argv[3]) if len(sys.argv) > 3 else 500
 hi = int(sys.argv[4]) if len(sys.argv) > 4 else x.shape[1]
 g, o, _, _ = live(lo); assert g == o, 'already different at lo'

@@ -4,9 +4,12 @@ Usage: parity_sweep.py <first seed> <n seeds>"""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import m17hip, oracle_lib as ol
+import oracle_lib as ol
 C, T = 64, 96000
-ctx = m17hip.Context(C, T)
+DUMP = len(sys.argv) > 3 and sys.argv[3] == 'dump'   # write the input of the first seed to tools/x_dbg.npy (no GPU needed) and stop
+if not DUMP:
+    import m17hip
+    ctx = m17hip.Context(C, T)
 total_bad = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     rng = np.random.default_rng(seed)
@@ -22,6 +25,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
                               phase=int(rng.integers(-1, 10)), invert=0, total=n)
             x[c, pos:pos + n] = ol.generate(p)[:n]; pos += n
     inv = seed & 1
+    if DUMP:
+        np.save(os.path.join(ROOT, 'tools', 'x_dbg.npy'), x); print('wrote tools/x_dbg.npy, invert =', inv); sys.exit(0)
     recs, counts, diags = ol.demod_batch(x, invert=inv, cap=2 * (T // 1920 + 2) + 4, threads=os.cpu_count())
     for spec, seg in ((1, 19200), (1, int(rng.integers(3000, 30000))), (0, 0)):
         ctx.tune(2, spec); ctx.tune(3, seg); ctx.upload(x); ctx.reset(); ctx.run(flags=inv)
