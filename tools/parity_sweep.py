@@ -28,11 +28,20 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     if DUMP:
         np.save(os.path.join(ROOT, 'tools', 'x_dbg.npy'), x); print('wrote tools/x_dbg.npy, invert =', inv); sys.exit(0)
     recs, counts, diags = ol.demod_batch(x, invert=inv, cap=2 * (T // 1920 + 2) + 4, threads=os.cpu_count())
-    for spec, seg in ((1, 19200), (1, int(rng.integers(3000, 30000))), (0, 0)):
-        ctx.tune(2, spec); ctx.tune(3, seg); ctx.upload(x); ctx.reset(); ctx.run(flags=inv)
-        got = ctx.frames(); d = ctx.diag()
+    cuts = sorted(int(v) for v in rng.integers(1, T, size=2))
+    for spec, seg, pieces in ((1, 19200, None), (1, int(rng.integers(3000, 30000)), None), (0, 0, None), (1, 19200, [0] + cuts + [T]), (0, 0, [0] + cuts + [T])):
+        ctx.tune(2, spec); ctx.tune(3, seg); ctx.reset()
+        if pieces is None:
+            ctx.upload(x); ctx.run(flags=inv); got = ctx.frames()
+        else:   # the same stream as three runs (state, filter history and DCD sums carried between them)
+            parts = []
+            for a, b in zip(pieces[:-1], pieces[1:]):
+                if b > a:
+                    ctx.upload(x[:, a:b]); ctx.run(flags=inv); parts.append(ctx.frames().copy())
+            got = np.concatenate(parts); got = got[np.lexsort((got['seq'], got['channel']))]
+        d = ctx.diag()
         bad = [c for c in range(C) if got[got['channel'] == c].tobytes() != recs[c, :counts[c]].tobytes()
                or any(not np.array_equal(d[f][c:c + 1], diags[f][c:c + 1], equal_nan=True) for f in d.dtype.names if f in diags.dtype.names)]
         total_bad += len(bad)
-        print(f'seed {seed} invert={inv} limit_ahead={spec} seg={seg}: frames {int(counts.sum())}, bad channels {bad}', flush=True)
+        print(f'seed {seed} invert={inv} limit_ahead={spec} seg={seg} runs={"1" if pieces is None else pieces}: frames {int(counts.sum())}, bad channels {bad}', flush=True)
 print('TOTAL bad channel-runs:', total_bad)
