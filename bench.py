@@ -149,7 +149,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get("channels") == C and tj.get("samples") == T and tj.get("segment_samples") * launches_per_step == T and dom in tj.get("kernels", {}):
+        if tj.get("channels") == C and tj.get("samples") == T and tj.get("launches_per_step") == launches_per_step and dom in tj.get("kernels", {}):
             traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]   # per launch (= per segment), like `achieved`
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

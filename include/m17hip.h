@@ -131,7 +131,7 @@ int m17hip_diag_fetch(m17hip_ctx* ctx, m17_diag* diag_host, uint32_t channels);
  * (0 = default 4; 1, 2, 4, 8).  key 1: per-channel tick counters of that kernel on/off (m17hip_debug_counters).
  * key 2: run the correlator's limit filter ahead of the sequential kernel (default 1) or inside it (0).
  * key 3: samples per segment a run is processed in (default 48000; 0 = one segment).  key 4: samples of the first segment
- * (default 11520; 0 = like the others).  key 5: segments the front end (K1, K3) may run ahead of the sequential kernel
+ * (default 0 = like the others).  key 5: segments the front end (K1, K3) may run ahead of the sequential kernel
  * (default 0 = unlimited). */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 

@@ -50,7 +50,7 @@ struct m17hip_ctx {
     uint32_t* dropped = nullptr;      // [maxC] K5: the segment dropped the speculation
     bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
-    uint32_t seg0_len = 11520;        // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others)
+    uint32_t seg0_len = 0;            // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others; measured neutral)
     float* dcd_table = nullptr;
     DcdState* dcd_state = nullptr;
     SeqState* seq_state = nullptr;

@@ -2,17 +2,17 @@
 """profiles/traffic.json from the PMC passes of tools/profile_round.sh: HBM bytes per LAUNCH of each kernel
 = (2 * FETCH_SIZE + WRITE_SIZE) KB — FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of the
 coalesced streaming reads), counters are per-dispatch averages in KB.  A run of the bench is processed in
-segments, so a launch covers channels x segment samples.
-Usage: make_traffic.py <dir with fetch_summary.md, write_summary.md> <channels> <samples> <segment> <out.json>"""
+segments (a short first one, then equal ones), so a launch covers channels x samples / launches-per-step on average.
+Usage: make_traffic.py <dir with fetch_summary.md, write_summary.md> <channels> <samples> <launches per step> <out.json>"""
 import json, re, sys
-d, C, T, seg, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+d, C, T, lps, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 def val(path, kern, ctr):
     for l in open(path):
         if l.startswith('- ') and kern in l:
             return float(re.search(ctr + r'=([0-9.e+]+)', l).group(1))
     return None
 K = {'fir_rrc150': 'fir_rrc150_kernel', 'dcd': 'dcd_kernel', 'limit_track': 'limit_track_kernel', 'demod_seq': 'demod_wave_kernel'}
-j = {'channels': C, 'samples': T, 'segment_samples': seg,
+j = {'channels': C, 'samples': T, 'launches_per_step': lps,
      'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh); per-dispatch averages in KB; '
                'FETCH_SIZE doubled per MI355X_MICROARCH.md; limit_track averages include the near-empty redo launches', 'kernels': {}}
 for k, n in K.items():

@@ -12,6 +12,7 @@ def step():
     ctx.reset(); ctx.run(); return ctx.frames_compact_device(buf.data_ptr(), buf.numel() // 64)
 seg0s = [int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else [11520]
 if len(sys.argv) > 5: ctx.tune(5, int(sys.argv[5]))
+if len(sys.argv) > 6: ctx.tune(0, int(sys.argv[6]))
 for spec, seg, seg0 in [(1, int(v), z) for v in sys.argv[3].split(',') for z in seg0s] + [(0, 0, 0)]:
     ctx.tune(2, spec); ctx.tune(3, seg); ctx.tune(4, seg0)
     step(); torch.cuda.synchronize()
