@@ -1,5 +1,5 @@
-// K1 (RRC-150 matched filter), K2 (correlator limit + sync-word correlations), K3 (sliding-DFT carrier
-// detect accumulation).  gfx950 / CDNA4, wave64.  See DESIGN.md §3 for the roofline of each kernel.
+// K1 (RRC-150 matched filter), the stand-alone correlator operators (limit filter, sync-word correlations: parity
+// API), K3 (sliding-DFT carrier detect accumulation).  K2 of the chain is in m17_gate_kernel.hpp.  gfx950 / CDNA4, wave64.  See DESIGN.md §3 for the roofline of each kernel.
 #pragma once
 
 #include "m17_common.hpp"
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(FIR_THREADS, 3) void fir_rrc150_kernel(const int16_
 }
 
 // =====================================================================================================
-// K2a  correlate_kernel — reference a4: Correlator::correlate (Correlator.h:51-64) against the four M17
+// correlate_kernel — reference a4: Correlator::correlate (Correlator.h:51-64) against the four M17
 // sync words for every sample: corr[w][c][t] = sum_{i=0}^{7} word[i] * y[t - 70 + 10 i] (oldest symbol
 // first, fp32, mul then add).  Time-parallel, elementwise; the 8 taps are shared by the four words.
 // =====================================================================================================
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void correlate_kernel(const float* __restrict_
 }
 
 // =====================================================================================================
-// K2b  limit_kernel — reference a3: Correlator::sample's limit_ = BaseIirFilter<float,3>(|y|)
+// limit_kernel — reference a3: Correlator::sample's limit_ = BaseIirFilter<float,3>(|y|)
 // (Correlator.h:43-45, IirFilter.h:26-42, coefficients Correlator.h:38-39).  A float recurrence: strictly
 // sequential per channel, one lane per channel; each lane streams its own row with 16-byte accesses.
 // =====================================================================================================

@@ -4,24 +4,28 @@
 // M17Demodulator state machine (M17Demodulator.h:233-753) — plus K4 (frame decode, wave-cooperative).
 //
 // Mapping: ONE WAVE PER CHANNEL.  Everything here is a recurrence or a state machine per channel, so there is
-// no data parallelism across time; what the hardware punishes is (a) a lone wave's ~3 ns per dependent
-// instruction and (b) divergence.  With one wave per channel 4096 channels are 4096 waves = 4 per SIMD (the whole
-// chip busy, latencies of one wave hidden by its three neighbours), the state machine is wave-uniform (every
-// branch is taken by all lanes, untaken code is skipped), and the 64 lanes cooperate where a stretch of the
-// stream allows it:
-//   * "bulk chunks": while nothing but feeding happens (initialisation, the 77 quiet samples after a frame, the
-//     inside of a payload frame) up to 960 samples are loaded coalesced into LDS, the limit IIR runs over them as
-//     one tight dependent chain, the <= 96 payload symbols of the chunk are normalised / sliced by 64 lanes at once,
-//     the running EVM is folded sequentially, and the correlator ring is refilled from the chunk's tail;
+// no data parallelism across time; what the hardware charges for is wave instructions (four waves share a SIMD's
+// 1.85 ns per instruction, uniform "scalar" float work included) and divergence.  With one wave per channel 4096
+// channels are 4096 waves = 4 per SIMD (the whole chip busy, latencies of one wave hidden by its three neighbours),
+// the state machine is wave-uniform (every branch is taken by all lanes, untaken code is skipped), the channel's
+// state (Hot, Cold) lives in LDS, and the 64 lanes cooperate where a stretch of the stream allows it:
+//   * "bulk chunks" of up to 480 samples while nothing but feeding happens (initialisation, the 77 quiet samples
+//     after a frame, SYNC_WAIT, the inside of a payload frame): samples come from a coalesced LDS window prefetched
+//     512 samples ahead, the <= 48 payload symbols of the chunk are normalised / sliced by 64 lanes at once, the
+//     running EVM is folded sequentially, the correlator ring is refilled from the chunk's tail;
+//   * search chunks (UNLOCKED) and sync-window chunks (*_SYNC states): lane k evaluates the sync-word trigger of
+//     sample k, ballots find the first sample that needs the single-sample path;
 //   * the frame decode uses 16 lanes as the 16 trellis states (m17_decode_device.hpp, viterbi_decode_wave).
-// The massively parallel work (K1 FIR) and the state-machine-independent recurrence (K3 sliding DFT) have
-// already run as their own passes; this kernel consumes
+// The massively parallel work (K1 FIR), the state-machine-independent recurrence (K3 sliding DFT) and the
+// correlator's limit filter (K2, speculatively: m17_gate_kernel.hpp) run as their own passes; this kernel consumes
 //   ybuf[c][t]    the matched-filter output, valid wherever the last 149 FIR inputs were consecutive samples
 //   dcd table     the sequential carrier-detect sums for every possible segment (see K3)
+//   hbuf[c][t]    the limit-filter history after every fed sample — until this kernel forces an unlock K2 could not
+//                 foresee; from there to the end of the segment it carries the filter itself
 // The reference gates the FIR and the correlator with the carrier detect: their input is the
 // concatenation of gated-on runs.  Runs start and end on tick boundaries and last >= 960 samples, so only the
-// first 148 outputs of a run see samples of the previous run; for those the FIR is recomputed from a 149-sample
-// snapshot taken when the previous run ended ("slow FIR", rare).
+// first 148 outputs of a run see samples of the previous run; for those the FIR is recomputed cooperatively from a
+// 149-sample snapshot taken when the previous run ended and patched into ybuf in place (rare).
 //
 // All 64 lanes hold the same scalar state and execute the single-sample path redundantly; stores of state are
 // issued by every lane with identical values (no cross-lane ordering is relied on).
