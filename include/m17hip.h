@@ -127,11 +127,23 @@ int m17hip_frames_compact_device(m17hip_ctx* ctx, m17_frame_rec* recs_dev, uint6
 /* Per-channel diagnostics after the last run: diag_host[C]. */
 int m17hip_diag_fetch(m17hip_ctx* ctx, m17_diag* diag_host, uint32_t channels);
 
+/* Payload consumer: BERT statistics — decode_bert + PRBS9::validate (apps/m17-demod.cpp:286-304,
+ * Util.h:320-441: LFSR x^9 + x^5 + 1, lock after 18 good bits, unlock at 25 errors in the last 128 bits) over the BERT
+ * frame records of every run since the last m17hip_demod_reset, per channel.  Enabled with m17hip_tune(ctx, 6, 1) BEFORE the
+ * runs to be counted (the records of a run are accounted at its end); M17HIP_ESTATE otherwise. */
+typedef struct m17_bert_stat {
+    uint32_t bits;    /* PRBS9::bits()   */
+    uint32_t errors;  /* PRBS9::errors() */
+    uint32_t synced;  /* PRBS9::sync()   */
+    uint32_t frames;  /* BERT frames seen */
+} m17_bert_stat;
+int m17hip_bert_stats(m17hip_ctx* ctx, m17_bert_stat* stats_host, uint32_t channels);
+
 /* Tuning knobs (performance only, never results).  key 0: waves (= channels) per workgroup of the sequential kernel
  * (0 = default 4; 1, 2, 4, 8).  key 1: per-channel tick counters of that kernel on/off (m17hip_debug_counters).
  * key 2: run the correlator's limit filter ahead of the sequential kernel (default 1) or inside it (0).
  * key 3: samples per segment a run is processed in (default 48000; 0 = one segment).  key 4: samples of the first segment
- * (default 0 = like the others).  key 5: segments the front end (K1, K3) may run ahead of the sequential kernel
+ * (default 0 = like the others).  key 6: BERT statistics on/off (m17hip_bert_stats; default off).  key 5: segments the front end (K1, K3) may run ahead of the sequential kernel
  * (default 0 = unlimited). */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 

@@ -48,6 +48,8 @@ struct m17hip_ctx {
     float* final_h = nullptr;         // [2][maxC][4], by segment parity
     GateExport* gate_exp = nullptr;   // [maxC] K2's own state at the end of a segment
     uint32_t* dropped = nullptr;      // [maxC] K5: the segment dropped the speculation
+    void* bert_state = nullptr;       // [maxC] BertState (tuning knob 6)
+    bool bert = false;
     bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     uint32_t seg0_len = 0;            // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others; measured neutral)
@@ -241,6 +243,60 @@ __global__ void carry_tail_kernel(int16_t* x, size_t xpitch, float* y, size_t yp
     for (int k = threadIdx.x; k < YPRE; k += blockDim.x) yr[k] = ys[k];
 }
 
+// PRBS9 receiver state per channel (Util.h:320-441), carried between runs
+struct BertState {
+    uint32_t lfsr, synced, sync_count, bit_count, err_count, hist_count, hist_pos, frames;
+    uint32_t hist[4];   // error flags of the last 128 validated bits
+};
+// decode_bert (apps/m17-demod.cpp:286-304) over the BERT records of the run just finished: one lane per channel
+__global__ void bert_stats_kernel(const FrameRec* recs, uint32_t rec_cap, const uint32_t* rec_count, BertState* state, uint32_t C)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    BertState b = state[c];
+    const uint32_t n = min(rec_count[c], rec_cap);
+    for (uint32_t r = 0; r < n; ++r) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(recs + (size_t)c * rec_cap + r);
+        if ((w[5] & 0xFFu) != 5u) continue;   // frame_type BERT
+        ++b.frames;
+        for (int i = 0; i < 197; ++i) {       // 24 bytes MSB first + the top 5 bits of byte 24
+            const uint32_t byte = (w[6 + (i >> 5)] >> (8 * ((i >> 3) & 3))) & 0xFFu;
+            const uint32_t bit = (byte >> (7 - (i & 7))) & 1u;
+            if (!b.synced) {                  // PRBS9::syncronize
+                const uint32_t res = (bit ^ (b.lfsr >> 8) ^ (b.lfsr >> 4)) & 1u;
+                b.lfsr = ((b.lfsr << 1) | bit) & 0x1FFu;
+                if (res) b.sync_count = 0;
+                else if (++b.sync_count == 18u) {
+                    b.synced = 1; b.bit_count += 18u;
+                    b.hist[0] = b.hist[1] = b.hist[2] = b.hist[3] = 0; b.hist_count = 0; b.hist_pos = 0; b.sync_count = 0;
+                }
+            } else {                          // PRBS9::generate + count_errors
+                const uint32_t g = ((b.lfsr >> 8) ^ (b.lfsr >> 4)) & 1u;
+                b.lfsr = ((b.lfsr << 1) | g) & 0x1FFu;
+                const uint32_t err = bit ^ g;
+                b.bit_count += 1;
+                const uint32_t wi = b.hist_pos >> 5, m = 1u << (b.hist_pos & 31u);
+                uint32_t h = wi == 0 ? b.hist[0] : (wi == 1 ? b.hist[1] : (wi == 2 ? b.hist[2] : b.hist[3]));
+                b.hist_count -= (h & m) ? 1u : 0u;
+                if (err) { b.err_count += 1; b.hist_count += 1; h |= m; if (b.hist_count >= 25u) b.synced = 0; }
+                else h &= ~m;
+                if (wi == 0) b.hist[0] = h; else if (wi == 1) b.hist[1] = h; else if (wi == 2) b.hist[2] = h; else b.hist[3] = h;
+                if (++b.hist_pos == 128u) b.hist_pos = 0;
+            }
+        }
+    }
+    state[c] = b;
+}
+
+__global__ void bert_reset_kernel(BertState* state, uint32_t C)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    BertState b{};
+    b.lfsr = 1;
+    state[c] = b;
+}
+
 __global__ void carry_tail_f32_kernel(float* y, size_t ypitch, uint32_t T)
 {
     __shared__ float ys[YPRE];
@@ -361,6 +417,8 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->final_h, 2 * C * 4 * sizeof(float));
     ALLOC(c->gate_exp, C * sizeof(GateExport));
     ALLOC(c->dropped, C * sizeof(uint32_t));
+    ALLOC(c->bert_state, C * sizeof(BertState));
+    hipLaunchKernelGGL(bert_reset_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, 0, (BertState*)c->bert_state, (uint32_t)C);
     ALLOC(c->dcd_table, C * c->ticks_cap * 12 * sizeof(float));
     ALLOC(c->dcd_state, C * sizeof(DcdState));
     ALLOC(c->seq_state, C * sizeof(SeqState));
@@ -422,7 +480,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo, &c->ev_seq})
         for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped};
+                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -597,6 +655,7 @@ int m17hip_demod_reset(m17hip_ctx* c)
     hipLaunchKernelGGL(zero_prefix_kernel, dim3(c->maxC), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, c->maxC);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemset2DAsync(c->hbuf, c->ypitch * sizeof(float), 0, YPRE * sizeof(float), c->maxC, c->stream));
+    hipLaunchKernelGGL(bert_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, (BertState*)c->bert_state, c->maxC);
     HIPCHK(c, hipMemsetAsync(c->rec_count, 0, (size_t)c->maxC * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->overflow, 0, 4, c->stream));
     c->pos = 0;
@@ -713,6 +772,8 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         if ((r = launch_front(k + ahead))) return r;
     }
     HIPCHK(c, hipGetLastError());
+    if (c->bert)   // payload consumer: PRBS9 statistics over this run's BERT records
+        hipLaunchKernelGGL(bert_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->recs, c->rec_cap, c->rec_count, (BertState*)c->bert_state, C);
     hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
     if (c->speculate) hipLaunchKernelGGL(carry_tail_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->hbuf, c->ypitch, T);
     HIPCHK(c, hipGetLastError());
@@ -786,6 +847,20 @@ int m17hip_diag_fetch(m17hip_ctx* c, m17_diag* diag_host, uint32_t C)
     return M17HIP_OK;
 }
 
+int m17hip_bert_stats(m17hip_ctx* c, m17_bert_stat* stats_host, uint32_t C)
+{
+    if (!c || !stats_host || C == 0 || C > c->maxC) return M17HIP_EINVAL;
+    if (!c->bert) return M17HIP_ESTATE;
+    std::vector<BertState> tmp(C);
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->bert_state, (size_t)C * sizeof(BertState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < C; ++i) {
+        stats_host[i].bits = tmp[i].bit_count; stats_host[i].errors = tmp[i].err_count;
+        stats_host[i].synced = tmp[i].synced; stats_host[i].frames = tmp[i].frames;
+    }
+    return M17HIP_OK;
+}
+
 int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
 {
     if (!c) return M17HIP_EINVAL;
@@ -807,6 +882,9 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 5:  // segments the front end may run ahead of K5 (0 = unlimited)
         if (value < 0 || value > 1000) return M17HIP_EINVAL;
         c->front_ahead = (uint32_t)value;
+        return M17HIP_OK;
+    case 6:  // BERT statistics (m17hip_bert_stats) on/off
+        c->bert = value != 0;
         return M17HIP_OK;
     case 4:  // samples of the first segment of a run (0 = like the others)
         if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;

@@ -53,6 +53,14 @@ public:
         out.resize(got);
         return out;
     }
+    // BERT statistics per channel (apps/m17-demod.cpp:286-304 + PRBS9): counted over the runs made after enable_bert(true)
+    void enable_bert(bool on) { check(m17hip_tune(ctx_, 6, on ? 1 : 0), "m17hip_tune"); }
+    std::vector<m17_bert_stat> bert_stats()
+    {
+        std::vector<m17_bert_stat> st(channels_);
+        check(m17hip_bert_stats(ctx_, st.data(), channels_), "m17hip_bert_stats");
+        return st;
+    }
     std::vector<m17_diag> diagnostics()
     {
         std::vector<m17_diag> d(channels_);

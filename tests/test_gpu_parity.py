@@ -406,6 +406,34 @@ def test_full_chain_random_scenarios(ctx, seed):
     assert np.array_equal(d["pad"], diags["pad"])   # live clock / sync counters at the end of the run
 
 
+def test_bert_statistics_consumer(ctx):
+    """SURVEY §8f-3: decode_bert + PRBS9::validate on the device (m17hip_bert_stats) against the oracle's PRBS9 receiver fed with the
+    oracle's BERT frame payloads — noisy BERT bursts (bit errors, PRBS resynchronisations), the stream fed as two runs."""
+    C, T = 48, 60000
+    x = np.stack([ol.generate(ol.gen_params(seed=700 + c, kind=0, n_frames=24, lead_in=3072, lead_sigma=40000.0,
+                                            noise_sigma=[300.0, 1500.0, 2600.0, 3400.0][c % 4], tail_sigma=500.0, total=T))[:T] for c in range(C)])
+    recs, counts, _ = ol.demod_batch(x, cap=2 * (T // 1920 + 2) + 4, threads=8)
+    ctx.tune(6, 1)
+    try:
+        ctx.reset()
+        for a, b in ((0, 25000), (25000, T)):
+            ctx.upload(x[:, a:b])
+            ctx.run()
+        st = ctx.bert_stats(C)
+    finally:
+        ctx.tune(6, 0)
+    total_err = 0
+    for c in range(C):
+        r = recs[c, :counts[c]]
+        pay = r[r["frame_type"] == 5]["payload"][:, :25]
+        bits, errs, sync = ol.bert_count(pay) if pay.size else (0, 0, False)
+        assert (int(st["bits"][c]), int(st["errors"][c]), bool(st["synced"][c]), int(st["frames"][c])) == (bits, errs, sync, pay.shape[0]), c
+        total_err += errs
+    assert total_err > 0 and int(st["frames"].sum()) > 10 * C   # the scenario has both decoded frames and bit errors
+    with pytest.raises(m17hip.M17HipError):
+        ctx.bert_stats(C)   # not enabled any more
+
+
 def test_edge_cases(ctx):
     # silence with +-1 dither, pure loud noise, DC, a stream cut in the middle of a frame, an all-zero window (NaN poisoning, Q1)
     T = 20000
