@@ -82,6 +82,12 @@ int m17hip_set_stream(m17hip_ctx* ctx, void* hip_stream);
 int m17hip_upload_i16(m17hip_ctx* ctx, const int16_t* host, uint32_t channels, uint32_t samples, size_t pitch);
 /* Same, from a DEVICE pointer (e.g. a tensor that already lives in HBM). */
 int m17hip_upload_i16_device(m17hip_ctx* ctx, const int16_t* dev, uint32_t channels, uint32_t samples, size_t pitch);
+/* Streaming ingest: stage the input of the NEXT m17hip_demod_run in a second slab while the current run is
+ * computing.  The copy is queued on the context's own copy stream and starts as soon as the run before the current one has
+ * released that slab; host memory must stay valid until the next m17hip_demod_run has been called, and should be pinned
+ * (hipHostMalloc / hipHostRegister) for the copy to overlap.  The next m17hip_demod_run (same channel / sample counts) waits for
+ * the copy, swaps the slabs (the carried 152-sample tail is moved over) and runs on the staged input. */
+int m17hip_upload_i16_async(m17hip_ctx* ctx, const int16_t* host, uint32_t channels, uint32_t samples, size_t pitch);
 
 /* ---- per-operator batched entry points (config 2 parity) ---------------------------------------- */
 /* K1: sample scaling + BaseFirFilter<float,150> with the RRC taps, ungated, over the uploaded slab

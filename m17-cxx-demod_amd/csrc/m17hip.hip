@@ -43,6 +43,11 @@ struct m17hip_ctx {
     size_t xpitch = 0, ypitch = 0;
     uint32_t ticks_cap = 0, rec_cap = 0;
     int16_t* xbuf = nullptr;
+    int16_t* xstage = nullptr;        // second input slab: the next run's samples are copied here while the current run computes
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_copy = nullptr, ev_run_begin = nullptr;
+    bool staged = false, run_begun = false;
+    uint32_t stagedC = 0, stagedT = 0;
     float* ybuf = nullptr;
     float* hbuf = nullptr;            // K2's limit-filter history, same pitch as ybuf
     float* final_h = nullptr;         // [2][maxC][4], by segment parity
@@ -297,6 +302,11 @@ __global__ void bert_reset_kernel(BertState* state, uint32_t C)
     state[c] = b;
 }
 
+__global__ void copy_prefix_i16_kernel(const int16_t* src, int16_t* dst, size_t xpitch)
+{
+    for (int k = threadIdx.x; k < XPRE; k += blockDim.x) dst[(size_t)blockIdx.x * xpitch + k] = src[(size_t)blockIdx.x * xpitch + k];
+}
+
 __global__ void carry_tail_f32_kernel(float* y, size_t ypitch, uint32_t T)
 {
     __shared__ float ys[YPRE];
@@ -477,10 +487,13 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     if (c->side) hipStreamDestroy(c->side);
     if (c->side2) hipStreamDestroy(c->side2);
     if (c->side3) hipStreamDestroy(c->side3);
+    if (c->copy) hipStreamDestroy(c->copy);
+    if (c->ev_copy) hipEventDestroy(c->ev_copy);
+    if (c->ev_run_begin) hipEventDestroy(c->ev_run_begin);
     for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo, &c->ev_seq})
         for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state};
+                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -501,6 +514,26 @@ int m17hip_upload_i16(m17hip_ctx* c, const int16_t* host, uint32_t C, uint32_t T
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->uploaded = true;
     c->lastC = C; c->lastT = T;
+    return M17HIP_OK;
+}
+
+int m17hip_upload_i16_async(m17hip_ctx* c, const int16_t* host, uint32_t C, uint32_t T, size_t pitch)
+{
+    if (!c || !host || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
+    if (!c->xstage) {
+        hipError_t e = hipMalloc((void**)&c->xstage, (size_t)c->maxC * c->xpitch * sizeof(int16_t));
+        if (e != hipSuccess) { c->last_hip = (int)e; return e == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP; }
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_run_begin, hipEventDisableTiming));
+    }
+    // the staging slab was the input of the run BEFORE the one now queued / running: free once that run's work is done,
+    // which is where the current run began
+    if (c->run_begun) HIPCHK(c, hipStreamWaitEvent(c->copy, c->ev_run_begin, 0));
+    HIPCHK(c, hipMemcpy2DAsync(c->xstage + XPRE, c->xpitch * sizeof(int16_t), host, pitch * sizeof(int16_t), (size_t)T * sizeof(int16_t), C,
+                               hipMemcpyHostToDevice, c->copy));
+    HIPCHK(c, hipEventRecord(c->ev_copy, c->copy));
+    c->staged = true; c->stagedC = C; c->stagedT = T;
     return M17HIP_OK;
 }
 
@@ -666,9 +699,19 @@ int m17hip_demod_reset(m17hip_ctx* c)
 int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    if (c->staged) {   // input staged by m17hip_upload_i16_async: swap the slabs, move the carried tail over
+        if (C != c->stagedC || T != c->stagedT) return M17HIP_EINVAL;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+        hipLaunchKernelGGL(copy_prefix_i16_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xstage, c->xpitch);
+        HIPCHK(c, hipGetLastError());
+        std::swap(c->xbuf, c->xstage);
+        c->staged = false;
+        c->uploaded = true;
+    }
     if (!c->uploaded) return M17HIP_ESTATE;
     if (c->have_run && C != c->lastC) return M17HIP_EINVAL;  // a continued stream keeps its channel count
     int r;
+    if (c->ev_run_begin) { HIPCHK(c, hipEventRecord(c->ev_run_begin, c->stream)); c->run_begun = true; }
     // The run is processed in segments.  K1 (throughput-bound, the whole chip) and K3 (latency-bound lone waves) of ALL segments
     // are queued on two side streams; the main stream runs K2 -> K5 per segment as soon as that segment's K1 and K3 are done,
     // so the front end of segment k+1 fills the issue slots K5 of segment k leaves idle (its tail above all).

@@ -30,7 +30,7 @@ VITERBI_SHAPES = {0: (488, 240), 1: (296, 144), 2: (420, 206), 3: (402, 197)}
 
 EXPORTS = [
     "m17hip_strerror", "m17hip_last_hip_error", "m17hip_version", "m17hip_ctx_create", "m17hip_ctx_destroy", "m17hip_set_stream",
-    "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_dcd", "m17hip_viterbi",
+    "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_upload_i16_async", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_dcd", "m17hip_viterbi",
     "m17hip_slice_llr", "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
 ]
@@ -97,6 +97,12 @@ class Context:
             s = s[None, :]
         self.C, self.T = s.shape
         self._chk(self.lib.m17hip_upload_i16(self.h, _ptr(s), C.c_uint32(self.C), C.c_uint32(self.T), C.c_size_t(self.T)))
+
+    def upload_async(self, host_ptr, channels, samples, pitch=None):
+        """Stage the input of the NEXT run (pinned host memory at `host_ptr`, kept alive by the caller) while the current run computes."""
+        self.C, self.T = int(channels), int(samples)
+        self._chk(self.lib.m17hip_upload_i16_async(self.h, C.c_void_p(int(host_ptr)), C.c_uint32(self.C), C.c_uint32(self.T),
+                                                   C.c_size_t(self.T if pitch is None else pitch)))
 
     def upload_device(self, dev_ptr, channels, samples, pitch=None):
         self.C, self.T = int(channels), int(samples)

@@ -406,6 +406,27 @@ def test_full_chain_random_scenarios(ctx, seed):
     assert np.array_equal(d["pad"], diags["pad"])   # live clock / sync counters at the end of the run
 
 
+def test_streaming_ingest_double_buffered(ctx):
+    """m17hip_upload_i16_async stages the next run's input in a second slab while the current run computes; the
+    carried tail moves with the swap.  Five runs fed that way == one run of the whole stream == the oracle."""
+    import torch
+    C, T, n = 64, 9600, 5
+    x = _signals(C, n * T, seed=77, sigma=600.0)
+    exp, counts, _ = _oracle_records(x)
+    pinned = [torch.from_numpy(np.ascontiguousarray(x[:, k * T:(k + 1) * T])).pin_memory() for k in range(n)]
+    ctx.reset()
+    ctx.upload_async(pinned[0].data_ptr(), C, T)
+    parts = []
+    for k in range(n):
+        ctx.run()                                   # consumes the staged slab (waits for its copy)
+        if k + 1 < n:
+            ctx.upload_async(pinned[k + 1].data_ptr(), C, T)   # overlaps with the run just queued
+        parts.append(ctx.frames().copy())
+    got = np.concatenate(parts)
+    order = np.lexsort((got["seq"], got["channel"]))
+    assert got[order].tobytes() == exp.tobytes() and got.size > C
+
+
 def test_bert_statistics_consumer(ctx):
     """SURVEY §8f-3: decode_bert + PRBS9::validate on the device (m17hip_bert_stats) against the oracle's PRBS9 receiver fed with the
     oracle's BERT frame payloads — noisy BERT bursts (bit errors, PRBS resynchronisations), the stream fed as two runs."""
