@@ -133,6 +133,27 @@ int m17hip_frames_compact_device(m17hip_ctx* ctx, m17_frame_rec* recs_dev, uint6
 /* Per-channel diagnostics after the last run: diag_host[C]. */
 int m17hip_diag_fetch(m17hip_ctx* ctx, m17_diag* diag_host, uint32_t channels);
 
+/* Synthetic input on the device: the framing of the reference's modulator CLI (apps/m17-mod.cpp:164-504,
+ * 628-677: preamble, LSF, stream / BERT / packet frames, EOT), its pulse shaping (one symbol per 10 samples through the 150-tap
+ * RRC in double, x 7168, truncation to int16, :204-224) and the impairments of BASELINE config 5, written straight into the
+ * context's input slab: [channels][samples], ready for m17hip_demod_run (no upload).  Channel c of the batch uses
+ * seed ^ splitmix64((chan0 + c) * 0x9E3779B97F4A7C15 + 1); kind < 0 = even channels BERT, odd channels voice-like streams.
+ * Reproducible bit for bit (integer-hash noise); the parity tests compare every int16 with the test generator. */
+typedef struct m17_synth_params {
+    uint64_t seed;
+    int32_t kind;          /* 0 BERT, 1 voice-like stream, 2 RAW packet, 3 noise only, < 0 mixed */
+    int32_t n_frames;      /* payload frames */
+    int32_t lead_in;       /* samples of lead-in noise (sigma lead_sigma) before the burst */
+    int32_t phase;         /* extra delay 0..9 samples, < 0 = derived from the seed */
+    int32_t tail, total;   /* unused here (the slab length is `samples`) */
+    int32_t invert;        /* transmit inverted polarity */
+    int32_t n_preamble;    /* 0 = as m17-mod does (2 for BERT, else 1) */
+    double lead_sigma, noise_sigma, dc_offset, gain, tail_sigma;   /* LSB */
+} m17_synth_params;
+int m17hip_synth_i16(m17hip_ctx* ctx, const m17_synth_params* params, uint32_t channels, uint32_t samples, uint32_t chan0);
+/* Read the input slab back: out[channels][samples] (row pitch in samples). */
+int m17hip_download_i16(m17hip_ctx* ctx, int16_t* host, uint32_t channels, uint32_t samples, size_t pitch);
+
 /* Payload consumer: BERT statistics — decode_bert + PRBS9::validate (apps/m17-demod.cpp:286-304,
  * Util.h:320-441: LFSR x^9 + x^5 + 1, lock after 18 good bits, unlock at 25 errors in the last 128 bits) over the BERT
  * frame records of every run since the last m17hip_demod_reset, per channel.  Enabled with m17hip_tune(ctx, 6, 1) BEFORE the

@@ -9,6 +9,7 @@
 #include "m17_state.hpp"
 #include "m17_wave_kernel.hpp"
 #include "m17_gate_kernel.hpp"
+#include "m17_mod_kernels.hpp"
 #include "m17_parity_kernels.hpp"
 
 #include <algorithm>
@@ -534,6 +535,38 @@ int m17hip_upload_i16_async(m17hip_ctx* c, const int16_t* host, uint32_t C, uint
                                hipMemcpyHostToDevice, c->copy));
     HIPCHK(c, hipEventRecord(c->ev_copy, c->copy));
     c->staged = true; c->stagedC = C; c->stagedT = T;
+    return M17HIP_OK;
+}
+
+int m17hip_synth_i16(m17hip_ctx* c, const m17_synth_params* params, uint32_t C, uint32_t T, uint32_t chan0)
+{
+    if (!c || !params || C == 0 || T == 0 || C > c->maxC || T > c->maxT || params->n_frames < 0 || params->kind > 3) return M17HIP_EINVAL;
+    static_assert(sizeof(ModParams) == sizeof(m17_synth_params), "parameter block layout");
+    ModParams mp;
+    std::memcpy(&mp, params, sizeof(mp));
+    const size_t sym_pitch = round_up((size_t)mod_max_symbols(mp.n_frames, mp.n_preamble), 16);
+    const size_t sym_bytes = round_up((size_t)C * sym_pitch, 256);
+    int r = ensure_scratch(c, sym_bytes + (size_t)C * 4);
+    if (r) return r;
+    int8_t* sym = reinterpret_cast<int8_t*>(c->scratch);
+    uint32_t* nsym = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->scratch) + sym_bytes);
+    hipLaunchKernelGGL(mod_symbols_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, mp, C, chan0, sym, sym_pitch, nsym);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(mod_shape_kernel, dim3((T + 255) / 256, C), dim3(256), 0, c->stream, mp, C, T, chan0, sym, sym_pitch, nsym, c->xbuf, c->xpitch);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->uploaded = true;
+    c->lastC = C; c->lastT = T;
+    return M17HIP_OK;
+}
+
+int m17hip_download_i16(m17hip_ctx* c, int16_t* host, uint32_t C, uint32_t T, size_t pitch)
+{
+    if (!c || !host || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
+    if (!c->uploaded) return M17HIP_ESTATE;
+    HIPCHK(c, hipMemcpy2DAsync(host, pitch * sizeof(int16_t), c->xbuf + XPRE, c->xpitch * sizeof(int16_t), (size_t)T * sizeof(int16_t), C,
+                               hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return M17HIP_OK;
 }
 

@@ -30,7 +30,7 @@ VITERBI_SHAPES = {0: (488, 240), 1: (296, 144), 2: (420, 206), 3: (402, 197)}
 
 EXPORTS = [
     "m17hip_strerror", "m17hip_last_hip_error", "m17hip_version", "m17hip_ctx_create", "m17hip_ctx_destroy", "m17hip_set_stream",
-    "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_upload_i16_async", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_dcd", "m17hip_viterbi",
+    "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_upload_i16_async", "m17hip_synth_i16", "m17hip_download_i16", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_dcd", "m17hip_viterbi",
     "m17hip_slice_llr", "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
 ]
@@ -103,6 +103,16 @@ class Context:
         self.C, self.T = int(channels), int(samples)
         self._chk(self.lib.m17hip_upload_i16_async(self.h, C.c_void_p(int(host_ptr)), C.c_uint32(self.C), C.c_uint32(self.T),
                                                    C.c_size_t(self.T if pitch is None else pitch)))
+
+    def synth(self, params, channels, samples, chan0=0):
+        """Generate the input slab on the device (m17-mod framing + impairments); `params` = a ctypes block laid out as m17_synth_params."""
+        self.C, self.T = int(channels), int(samples)
+        self._chk(self.lib.m17hip_synth_i16(self.h, C.byref(params), C.c_uint32(self.C), C.c_uint32(self.T), C.c_uint32(chan0)))
+
+    def download(self):
+        out = np.empty((self.C, self.T), dtype=np.int16)
+        self._chk(self.lib.m17hip_download_i16(self.h, _ptr(out), C.c_uint32(self.C), C.c_uint32(self.T), C.c_size_t(self.T)))
+        return out
 
     def upload_device(self, dev_ptr, channels, samples, pitch=None):
         self.C, self.T = int(channels), int(samples)

@@ -406,6 +406,32 @@ def test_full_chain_random_scenarios(ctx, seed):
     assert np.array_equal(d["pad"], diags["pad"])   # live clock / sync counters at the end of the run
 
 
+@pytest.mark.parametrize("kw", [
+    dict(seed=11, kind=-1, n_frames=20, lead_in=3072, noise_sigma=600.0, tail_sigma=600.0, lead_sigma=40000.0),
+    dict(seed=12, kind=0, n_frames=9, lead_in=0, noise_sigma=0.0, tail_sigma=0.0, phase=7),                       # zero noise: +-1 dither
+    dict(seed=13, kind=1, n_frames=14, lead_in=2000, noise_sigma=1500.0, tail_sigma=300.0, dc_offset=-1500.0, gain=0.6, invert=1),
+    dict(seed=14, kind=2, n_frames=11, lead_in=100, noise_sigma=200.0, tail_sigma=4000.0, dc_offset=2500.0, gain=1.4, n_preamble=3),
+    dict(seed=15, kind=3, n_frames=0, lead_in=500, noise_sigma=900.0, tail_sigma=100.0, lead_sigma=12000.0),
+])
+def test_device_synthesis_bit_exact(ctx, kw):
+    """m17hip_synth_i16 (m17-mod framing, RRC shaping in double, impairments) against the test generator: every
+    int16 of the slab, several channel offsets; and the synthesized slab demodulates to the same records."""
+    C, T = 40, 48000
+    p = ol.gen_params(total=T, **kw)
+    for chan0 in (0, 4093):
+        exp = ol.generate_batch(p, C, T, threads=8, chan0=chan0)
+        ctx.synth(p, C, T, chan0=chan0)
+        got = ctx.download()
+        assert np.array_equal(got, exp), (kw, chan0, int((got != exp).sum()))
+    ctx.reset()
+    ctx.run(flags=kw.get("invert", 0))
+    recs = ctx.frames()
+    e, counts, _ = _oracle_records(exp, invert=kw.get("invert", 0))
+    assert recs.tobytes() == e.tobytes()
+    if kw["kind"] != 3 and kw["noise_sigma"] <= 600.0:
+        assert recs.size >= C // 2
+
+
 def test_streaming_ingest_double_buffered(ctx):
     """m17hip_upload_i16_async stages the next run's input in a second slab while the current run computes; the
     carried tail moves with the swap.  Five runs fed that way == one run of the whole stream == the oracle."""
