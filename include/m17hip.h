@@ -166,6 +166,17 @@ typedef struct m17_bert_stat {
 } m17_bert_stat;
 int m17hip_bert_stats(m17hip_ctx* ctx, m17_bert_stat* stats_host, uint32_t channels);
 
+/* Payload consumer: link setup frames as text — LinkSetupFrame::decode_callsign (LinkSetupFrame.h:95-121: 6 bytes
+ * big-endian base 40 -> up to 9 characters, all ones = "BROADCAST"), the 16-bit type field and the CRC check of dump_lsf
+ * (apps/m17-demod.cpp:124-200), for a batch of n 30-byte LSFs (e.g. the payloads of the frame_type 0 records). */
+typedef struct m17_lsf_info {
+    char dst[10], src[10];   /* NUL-padded callsigns */
+    uint16_t type;           /* LSF bytes 12..13 */
+    uint8_t crc_ok;          /* CRC16 over the 30 bytes == 0 */
+    uint8_t reserved[9];
+} m17_lsf_info;
+int m17hip_lsf_info(m17hip_ctx* ctx, const uint8_t* lsf30_host, uint32_t n, m17_lsf_info* out_host);
+
 /* Tuning knobs (performance only, never results).  key 0: waves (= channels) per workgroup of the sequential kernel
  * (0 = default 4; 1, 2, 4, 8).  key 1: per-channel tick counters of that kernel on/off (m17hip_debug_counters).
  * key 2: run the correlator's limit filter ahead of the sequential kernel (default 1) or inside it (0).

@@ -294,6 +294,32 @@ __global__ void bert_stats_kernel(const FrameRec* recs, uint32_t rec_cap, const 
     state[c] = b;
 }
 
+// LinkSetupFrame::decode_callsign + type field + CRC of a batch of LSFs: one lane per frame
+struct LsfInfo { char dst[10], src[10]; uint16_t type; uint8_t crc_ok; uint8_t reserved[9]; };
+__global__ void lsf_info_kernel(const uint8_t* lsf, uint32_t n, LsfInfo* out)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const uint8_t* b = lsf + (size_t)f * 30;
+    LsfInfo o{};
+    for (int which = 0; which < 2; ++which) {
+        const uint8_t* e = b + 6 * which;
+        char* dst = which ? o.src : o.dst;
+        bool bc = true;
+        uint64_t v = 0;
+        for (int i = 0; i < 6; ++i) { bc = bc && e[i] == 0xFF; v = (v << 8) | e[i]; }
+        if (bc) { const char t[10] = {'B', 'R', 'O', 'A', 'D', 'C', 'A', 'S', 'T', 0}; for (int i = 0; i < 10; ++i) dst[i] = t[i]; continue; }
+        const char map[41] = "xABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789-/.";
+        int idx = 0;
+        while (v) { dst[idx++] = map[v % 40u]; v /= 40u; }   // at most 9 digits below 2^48
+    }
+    o.type = (uint16_t)((b[12] << 8) | b[13]);
+    uint8_t tmp[30];
+    for (int i = 0; i < 30; ++i) tmp[i] = b[i];
+    o.crc_ok = mod_crc16(tmp, 30) == 0u ? 1 : 0;
+    out[f] = o;
+}
+
 __global__ void bert_reset_kernel(BertState* state, uint32_t C)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -919,6 +945,23 @@ int m17hip_diag_fetch(m17hip_ctx* c, m17_diag* diag_host, uint32_t C)
     if (!c || !diag_host || C == 0 || C > c->maxC) return M17HIP_EINVAL;
     HIPCHK(c, hipMemcpy2DAsync(diag_host, sizeof(Diag), &c->seq_state[0].cold.diag, sizeof(SeqState), sizeof(Diag), C, hipMemcpyDeviceToHost,
                                c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M17HIP_OK;
+}
+
+int m17hip_lsf_info(m17hip_ctx* c, const uint8_t* lsf30_host, uint32_t n, m17_lsf_info* out_host)
+{
+    if (!c || !lsf30_host || !out_host || n == 0) return M17HIP_EINVAL;
+    static_assert(sizeof(LsfInfo) == sizeof(m17_lsf_info) && sizeof(LsfInfo) == 32, "m17_lsf_info layout");
+    const size_t in_b = round_up((size_t)n * 30, 256);
+    int r = ensure_scratch(c, in_b + (size_t)n * sizeof(LsfInfo));
+    if (r) return r;
+    uint8_t* din = reinterpret_cast<uint8_t*>(c->scratch);
+    LsfInfo* dout = reinterpret_cast<LsfInfo*>(din + in_b);
+    HIPCHK(c, hipMemcpyAsync(din, lsf30_host, (size_t)n * 30, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(lsf_info_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, din, n, dout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out_host, dout, (size_t)n * sizeof(LsfInfo), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return M17HIP_OK;
 }

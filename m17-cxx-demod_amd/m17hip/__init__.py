@@ -25,6 +25,7 @@ assert FRAME_REC.itemsize == 64 and DIAG.itemsize == 64
 
 FLAG_INVERT = 1
 KERNELS = {"fir_rrc150": 0, "dcd": 1, "demod_seq": 2, "decode": 3, "correlator": 4, "compact": 5, "limit_track": 6}
+LSF_INFO = np.dtype([("dst", "S10"), ("src", "S10"), ("type", "<u2"), ("crc_ok", "u1"), ("reserved", "u1", (9,))])
 BERT_STAT = np.dtype([("bits", "<u4"), ("errors", "<u4"), ("synced", "<u4"), ("frames", "<u4")])
 VITERBI_SHAPES = {0: (488, 240), 1: (296, 144), 2: (420, 206), 3: (402, 197)}
 
@@ -32,7 +33,7 @@ EXPORTS = [
     "m17hip_strerror", "m17hip_last_hip_error", "m17hip_version", "m17hip_ctx_create", "m17hip_ctx_destroy", "m17hip_set_stream",
     "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_upload_i16_async", "m17hip_synth_i16", "m17hip_download_i16", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_dcd", "m17hip_viterbi",
     "m17hip_slice_llr", "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
-    "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
+    "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
 ]
 
 
@@ -202,6 +203,13 @@ class Context:
         d = np.zeros(n, dtype=DIAG)
         self._chk(self.lib.m17hip_diag_fetch(self.h, _ptr(d), C.c_uint32(n)))
         return d
+
+    def lsf_info(self, lsf30):
+        """Callsigns, type field and CRC status of a batch of 30-byte link setup frames."""
+        a = np.ascontiguousarray(lsf30, dtype=np.uint8).reshape(-1, 30)
+        out = np.zeros(a.shape[0], dtype=LSF_INFO)
+        self._chk(self.lib.m17hip_lsf_info(self.h, _ptr(a), C.c_uint32(a.shape[0]), _ptr(out)))
+        return out
 
     def bert_stats(self, channels=None):
         """PRBS9 bit / error counts per channel over the BERT frames since reset (enable with tune(6, 1) before the runs)."""

@@ -165,6 +165,8 @@ void m17o_clock(const uint8_t* op, const uint8_t* index, const uint32_t* count, 
 
 // ---- FEC operators -----------------------------------------------------------
 uint16_t m17o_crc16(const uint8_t* d, size_t n) { return crc16_m17(d, n); }
+void m17o_decode_callsign(const uint8_t* enc6, char* out10) { decode_callsign(enc6, out10); }
+void m17o_encode_callsign(const char* call, uint8_t* out6) { encode_callsign(std::string(call), out6); }
 uint32_t m17o_golay_encode24(uint16_t v) { return golay::encode24(v); }
 int m17o_golay_decode(uint32_t in, uint32_t* out) { return golay::decode(in, *out) ? 1 : 0; }
 void m17o_interleave(int8_t* f368) { interleave(f368); }

@@ -94,6 +94,21 @@ inline void encode_callsign(const std::string& call, uint8_t out[6])  // LinkSet
     for (int i = 0; i < 6; ++i) out[5 - i] = (uint8_t)(enc >> (8 * i));
 }
 
+// LinkSetupFrame::decode_callsign (LinkSetupFrame.h:95-121): 6 bytes big-endian base 40 -> up to 9 characters, NUL padded;
+// the all-ones address is "BROADCAST"
+inline void decode_callsign(const uint8_t enc[6], char out[10])
+{
+    static const char map[] = "xABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789-/.";
+    std::memset(out, 0, 10);
+    bool bc = true;
+    for (int i = 0; i < 6; ++i) bc = bc && enc[i] == 0xFF;
+    if (bc) { std::memcpy(out, "BROADCAST", 9); return; }
+    uint64_t v = 0;
+    for (int i = 0; i < 6; ++i) v = (v << 8) | enc[i];
+    size_t idx = 0;
+    while (v) { out[idx++] = map[v % 40]; v /= 40; }
+}
+
 static const uint8_t SYNC_LSF[2] = {0x55, 0xF7}, SYNC_STREAM[2] = {0xFF, 0x5D}, SYNC_PACKET[2] = {0x75, 0xFF},
                      SYNC_BERT[2] = {0xDF, 0x55}, SYNC_EOT[2] = {0x55, 0x5D};
 

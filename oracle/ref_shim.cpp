@@ -28,6 +28,7 @@
 #include "CRC16.h"
 #include "Golay24.h"
 #include "M17FrameDecoder.h"
+#include "LinkSetupFrame.h"
 
 #include <cstring>
 #include <memory>
@@ -181,6 +182,21 @@ uint16_t ref_crc16(const uint8_t* d, size_t n)
     return c.get();
 }
 uint32_t ref_golay_encode24(uint16_t v) { return Golay24::encode24(v); }
+void ref_decode_callsign(const uint8_t* enc6, char* out10)
+{
+    LinkSetupFrame::encoded_call_t e;
+    for (int i = 0; i < 6; ++i) e[i] = enc6[i];
+    auto r = LinkSetupFrame::decode_callsign(e);
+    for (int i = 0; i < 10; ++i) out10[i] = r[i];
+}
+void ref_encode_callsign(const char* call, uint8_t* out6)
+{
+    LinkSetupFrame::call_t c;
+    c.fill(0);
+    for (int i = 0; i < 9 && call[i]; ++i) c[i] = call[i];
+    auto r = LinkSetupFrame::encode_callsign(c);
+    for (int i = 0; i < 6; ++i) out6[i] = r[i];
+}
 int ref_golay_decode(uint32_t in, uint32_t* out) { return Golay24::decode(in, *out) ? 1 : 0; }
 void ref_interleave(int8_t* f)
 {

@@ -283,6 +283,21 @@ def crc16(data, lib=None, prefix="m17o_"):
     return int(getattr(lib, prefix + "crc16")(_p(d) if d.size else None, C.c_size_t(d.size)))
 
 
+def decode_callsign(enc6, lib=None, prefix="m17o_"):
+    lib = lib or oracle()
+    e = np.ascontiguousarray(np.frombuffer(bytes(enc6), dtype=np.uint8))
+    out = np.zeros(10, dtype=np.uint8)
+    getattr(lib, prefix + "decode_callsign")(_p(e), _p(out))
+    return bytes(out)
+
+
+def encode_callsign(call, lib=None, prefix="m17o_"):
+    lib = lib or oracle()
+    out = np.zeros(6, dtype=np.uint8)
+    getattr(lib, prefix + "encode_callsign")(C.c_char_p(call.encode()), _p(out))
+    return bytes(out)
+
+
 def golay_encode24(v, lib=None, prefix="m17o_"):
     lib = lib or oracle()
     return int(getattr(lib, prefix + "golay_encode24")(C.c_uint16(v)))

@@ -453,6 +453,31 @@ def test_streaming_ingest_double_buffered(ctx):
     assert got[order].tobytes() == exp.tobytes() and got.size > C
 
 
+def test_lsf_presentation_consumer(ctx):
+    """SURVEY §8f-3: LinkSetupFrame::decode_callsign + type + CRC on the device for a batch of LSFs: the LSF records of decoded
+    voice / packet streams, plus random and corrupted frames, against the oracle."""
+    x = np.stack([ol.generate(ol.gen_params(seed=900 + c, kind=1 + (c & 1), n_frames=5, lead_in=3072, lead_sigma=40000.0, noise_sigma=300.0,
+                                            tail_sigma=300.0, total=24000))[:24000] for c in range(16)])
+    ctx.upload(x); ctx.reset(); ctx.run()
+    recs = ctx.frames()
+    lsf = recs[recs["frame_type"] == 0]["payload"][:, :30]
+    assert lsf.shape[0] >= 12
+    rng = np.random.default_rng(3)
+    rnd = rng.integers(0, 256, (500, 30), dtype=np.uint8)
+    rnd[:50, :6] = 0xFF                     # broadcast destination
+    bad = lsf.copy(); bad[:, 20] ^= 0x40    # CRC failures
+    batch = np.concatenate([lsf, rnd, bad])
+    info = ctx.lsf_info(batch)
+    for i, f in enumerate(batch):
+        assert bytes(info["dst"][i]).ljust(10, b"\0") == ol.decode_callsign(f[0:6]), i
+        assert bytes(info["src"][i]).ljust(10, b"\0") == ol.decode_callsign(f[6:12]), i
+        assert int(info["type"][i]) == (int(f[12]) << 8 | int(f[13]))
+        assert bool(info["crc_ok"][i]) == (ol.crc16(f.tobytes()) == 0)
+    n = lsf.shape[0]
+    assert info["crc_ok"][:n].all() and not info["crc_ok"][-n:].any()
+    assert bytes(info["src"][0]) == b"N0CALL" and bytes(info["dst"][0]) == b"BROADCAST"
+
+
 def test_bert_statistics_consumer(ctx):
     """SURVEY §8f-3: decode_bert + PRBS9::validate on the device (m17hip_bert_stats) against the oracle's PRBS9 receiver fed with the
     oracle's BERT frame payloads — noisy BERT bursts (bit errors, PRBS resynchronisations), the stream fed as two runs."""

@@ -301,3 +301,12 @@ def test_voice_stream_and_packet_end_to_end():
     streams = [r for r in recs if r["frame_type"] == 2 and r["cost"] < 10]
     sent = {bytes(x[:18]) for x in truth["payloads"]}
     assert len(streams) >= 7 and all(bytes(r["payload"][:18]) in sent for r in streams)
+
+
+def test_callsign_kat():
+    """reference tests/LinkSetupFrameTest.cpp:19-52: base-40 callsigns"""
+    assert ol.encode_callsign("WX9O") == bytes([0, 0, 0, 0x0F, 0x8A, 0xD7])
+    assert ol.decode_callsign(bytes([0, 0, 0, 0x0F, 0x8A, 0xD7])) == b"WX9O" + bytes(6)
+    assert ol.decode_callsign(bytes([0x00, 0x00, 0x5F, 0x1B, 0x66, 0x91])) == b"IU2KWO" + bytes(4)
+    assert ol.decode_callsign(bytes([0xFF] * 6)) == b"BROADCAST" + bytes(1)
+    assert ol.decode_callsign(ol.encode_callsign("N0CALL")) == b"N0CALL" + bytes(4)

@@ -93,3 +93,12 @@ def test_frame_decoder_random_walk_bit_exact():
         so, sr = ro[1:], rr[1:]
         assert (ro[1], ro[2], ro[3].tolist(), ro[4], ro[5]) == (rr[1], rr[2], rr[3].tolist(), rr[4], rr[5]), step
         assert ro[0].tobytes() == rr[0].tobytes(), step
+
+
+def test_callsign_vs_reference():
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        e = bytes(rng.integers(0, 256, 6, dtype=np.uint8))
+        assert ol.decode_callsign(e) == ol.decode_callsign(e, lib=R, prefix="ref_")
+    for call in ("N0CALL", "WX9O", "IU2KWO", "A", "AB1CDE-9", "K1/P.Q", "lower", ""):
+        assert ol.encode_callsign(call) == ol.encode_callsign(call, lib=R, prefix="ref_")
