@@ -141,7 +141,7 @@ int m17hip_diag_fetch(m17hip_ctx* ctx, m17_diag* diag_host, uint32_t channels);
  * Reproducible bit for bit (integer-hash noise); the parity tests compare every int16 with the test generator. */
 typedef struct m17_synth_params {
     uint64_t seed;
-    int32_t kind;          /* 0 BERT, 1 voice-like stream, 2 RAW packet, 3 noise only, < 0 mixed */
+    int32_t kind;          /* 0 BERT, 1 voice-like stream, 2 RAW packet, 3 noise only, 4 RAW packet closed by a CRC-16/X.25 FCS (1..33 frames), < 0 mixed */
     int32_t n_frames;      /* payload frames */
     int32_t lead_in;       /* samples of lead-in noise (sigma lead_sigma) before the burst */
     int32_t phase;         /* extra delay 0..9 samples, < 0 = derived from the seed */
@@ -166,6 +166,33 @@ typedef struct m17_bert_stat {
 } m17_bert_stat;
 int m17hip_bert_stats(m17hip_ctx* ctx, m17_bert_stat* stats_host, uint32_t channels);
 
+/* Payload consumer: packet reassembly — decode_packet (apps/m17-demod.cpp:207-253) with the per-transmission
+ * reset of dump_lsf (:154-155), per channel, over the packet frame records of every run since the last m17hip_demod_reset:
+ * an LSF record starts a new packet; numbered frames (payload[25] = frame number << 2) must arrive in sequence, one that does
+ * not is dropped and counted; the frame with the EOF bit (payload[25] & 0x80) contributes its first min(count, 25) bytes and
+ * closes the packet, whose CRC-16/X.25 over contents + FCS must leave 0x0f47 (boost::crc_optimal<16, 0x1021, 0xFFFF, 0xFFFF,
+ * true, true>, :218-222).  dump_lsf's ENCAPSULATED branch reads lsf[109..111] of a 30-byte array (:157-171, out of bounds);
+ * that prefix is not reproduced — every packet is assembled as RAW.  Enabled with m17hip_tune(ctx, 7, capacity) BEFORE the
+ * runs; m17hip_packets_fetch returns the packets the LAST run completed, ordered by (channel, seq); *count = how many
+ * there were (M17HIP_EOVERFLOW if more than the capacity set by m17hip_tune). */
+typedef struct m17_packet_rec {
+    uint32_t channel;
+    uint32_t seq;          /* packets this channel completed before this one, since reset */
+    uint64_t sample_pos;   /* of the closing frame's callback */
+    uint16_t size;         /* bytes in data, FCS included */
+    uint16_t checksum;     /* CRC-16/X.25 of data[0..size): 0x0f47 for an intact packet */
+    uint8_t crc_ok;
+    uint8_t frames;        /* packet frames accepted, the closing one included */
+    uint8_t seq_errors;    /* frames dropped by the sequence check since the LSF */
+    uint8_t reserved;
+    uint8_t data[840];     /* at most 32 x 25 + 25 bytes are ever used */
+} m17_packet_rec; /* 864 bytes */
+int m17hip_packets_fetch(m17hip_ctx* ctx, m17_packet_rec* recs_host, uint32_t capacity, uint32_t* count);
+/* The same consumer over frame records supplied by the caller (fetched earlier, or gathered from other GPUs) instead of the
+ * last run's: recs_host[channels][pitch] with counts_host[c] records used in row c.  The per-channel assembly state advances
+ * exactly as it does at the end of a run; the packets completed are then returned by m17hip_packets_fetch. */
+int m17hip_packets_feed(m17hip_ctx* ctx, const m17_frame_rec* recs_host, const uint32_t* counts_host, uint32_t channels, uint32_t pitch);
+
 /* Payload consumer: link setup frames as text — LinkSetupFrame::decode_callsign (LinkSetupFrame.h:95-121: 6 bytes
  * big-endian base 40 -> up to 9 characters, all ones = "BROADCAST"), the 16-bit type field and the CRC check of dump_lsf
  * (apps/m17-demod.cpp:124-200), for a batch of n 30-byte LSFs (e.g. the payloads of the frame_type 0 records). */
@@ -181,7 +208,7 @@ int m17hip_lsf_info(m17hip_ctx* ctx, const uint8_t* lsf30_host, uint32_t n, m17_
  * (0 = default 4; 1, 2, 4, 8).  key 1: per-channel tick counters of that kernel on/off (m17hip_debug_counters).
  * key 2: run the correlator's limit filter ahead of the sequential kernel (default 1) or inside it (0).
  * key 3: samples per segment a run is processed in (default 48000; 0 = one segment).  key 4: samples of the first segment
- * (default 0 = like the others).  key 6: BERT statistics on/off (m17hip_bert_stats; default off).  key 5: segments the front end (K1, K3) may run ahead of the sequential kernel
+ * (default 0 = like the others).  key 6: BERT statistics on/off (m17hip_bert_stats; default off).  key 7: packet reassembly, value = packets of room per run (m17hip_packets_fetch; default 0 = off).  key 5: segments the front end (K1, K3) may run ahead of the sequential kernel
  * (default 0 = unlimited). */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 

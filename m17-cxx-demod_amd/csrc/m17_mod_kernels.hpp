@@ -105,6 +105,13 @@ __device__ inline uint32_t mod_crc16(const uint8_t* d, int n)   // CRC16<0x5935,
     for (int i = 0; i != 16; ++i) { const uint32_t msb = reg & 0x8000u; reg = (reg << 1) & 0xFFFFu; if (msb) reg ^= 0x5935u; }
     return reg;
 }
+// CRC-16/X.25 register update for one byte (reflected 0x1021, no final xor): the checksum of apps/m17-demod.cpp:218
+__host__ __device__ inline uint32_t mod_crc16_x25_update(uint32_t crc, uint32_t b)
+{
+    crc ^= b;
+    for (int i = 0; i != 8; ++i) crc = (crc & 1u) ? ((crc >> 1) ^ 0x8408u) : (crc >> 1);
+    return crc;
+}
 __device__ inline uint32_t mod_golay24(uint32_t data)   // Golay24.h:100-129
 {
     uint32_t cw = data;
@@ -191,6 +198,35 @@ __global__ __launch_bounds__(64) void mod_symbols_kernel(ModParams base, uint32_
             d[24] = (uint8_t)rnd();
             const bool last = i == base.n_frames - 1;
             d[25] = (uint8_t)((last ? 0x80 : 0x00) | ((last ? 25 : i) << 2));
+            f.clear();
+            mod_encode(f, [&](uint32_t b) { return (uint32_t)(d[b >> 3] >> (7 - (b & 7))) & 1u; }, 206, 3, 0, 368);
+            ss.byte(0x75); ss.byte(0xFF); ss.frame(f);
+        }
+        ss.byte(0x55); ss.byte(0x5D); ss.zeros(40);
+    } else if (kind == 4) {   // RAW packet closed by its CRC-16/X.25 frame check sequence (what apps/m17-demod.cpp:207-253 verifies)
+        for (int k = 0; k < (base.n_preamble > 0 ? base.n_preamble : 1); ++k) ss.preamble();
+        make_lsf(0x0002u);
+        send_lsf();
+        uint32_t crc = 0xFFFFu;
+        for (int i = 0; i < base.n_frames; ++i) {
+            uint8_t d[26];
+            for (int k = 0; k < 24; k += 8) { const uint64_t r = rnd(); for (int q = 0; q < 8; ++q) d[k + q] = (uint8_t)(r >> (8 * q)); }
+            d[24] = (uint8_t)rnd();
+            const bool last = i == base.n_frames - 1;
+            if (!last) {
+                for (int k = 0; k < 25; ++k) crc = mod_crc16_x25_update(crc, d[k]);
+                d[25] = (uint8_t)(i << 2);
+            } else {
+                const int len = 2 + (int)(rnd() % 24u);
+                for (int k = 0; k < 25; ++k) if (k < len - 2) crc = mod_crc16_x25_update(crc, d[k]);
+                const uint32_t fcs = ~crc & 0xFFFFu;
+                for (int k = 0; k < 25; ++k) {
+                    if (k == len - 2) d[k] = (uint8_t)(fcs & 0xFFu);
+                    else if (k == len - 1) d[k] = (uint8_t)(fcs >> 8);
+                    else if (k >= len) d[k] = 0;
+                }
+                d[25] = (uint8_t)(0x80 | (len << 2));
+            }
             f.clear();
             mod_encode(f, [&](uint32_t b) { return (uint32_t)(d[b >> 3] >> (7 - (b & 7))) & 1u; }, 206, 3, 0, 368);
             ss.byte(0x75); ss.byte(0xFF); ss.frame(f);

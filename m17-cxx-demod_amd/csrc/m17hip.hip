@@ -56,6 +56,11 @@ struct m17hip_ctx {
     uint32_t* dropped = nullptr;      // [maxC] K5: the segment dropped the speculation
     void* bert_state = nullptr;       // [maxC] BertState (tuning knob 6)
     bool bert = false;
+    void* pkt_state = nullptr;        // [maxC] PacketState (tuning knob 7)
+    void* pkt_recs = nullptr;         // [pkt_cap] PacketRec: packets completed by the last run
+    uint32_t* pkt_count = nullptr;
+    uint32_t pkt_cap = 0;
+    bool pkt_fed = false;
     bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     uint32_t seg0_len = 0;            // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others; measured neutral)
@@ -320,6 +325,72 @@ __global__ void lsf_info_kernel(const uint8_t* lsf, uint32_t n, LsfInfo* out)
     out[f] = o;
 }
 
+// Packet reassembly per channel (apps/m17-demod.cpp:32-33,154-155,207-253), carried between runs
+struct PacketState {
+    uint32_t size, counter, seq_errors, frames, completed, pad[3];
+    uint8_t data[832];   // 32 numbered frames x 25 bytes + a last frame of up to 25
+};
+struct PacketRec {       // = m17_packet_rec
+    uint32_t channel, seq;
+    uint64_t sample_pos;
+    uint16_t size, checksum;
+    uint8_t crc_ok, frames, seq_errors, reserved;
+    uint8_t data[840];
+};
+// decode_packet over the packet records of the run just finished: one lane per channel.  An LSF callback starts a new packet
+// (dump_lsf clears current_packet and the frame counter); numbered frames must arrive in order (a frame out of sequence is
+// dropped, the counter stays); the frame with the EOF bit appends its last `n` bytes and closes the packet with the
+// CRC-16/X.25 check (0x0f47 over contents + FCS).  Completed packets go to `out` in arrival order of the atomics;
+// (channel, seq) orders them.
+__global__ void packet_asm_kernel(const FrameRec* recs, uint32_t rec_cap, const uint32_t* rec_count, PacketState* state, uint32_t C,
+                                  PacketRec* out, uint32_t out_cap, uint32_t* out_count)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    PacketState* st = state + c;
+    uint32_t size = st->size, counter = st->counter, seq_errors = st->seq_errors, frames = st->frames, completed = st->completed;
+    const uint32_t n = min(rec_count[c], rec_cap);
+    for (uint32_t r = 0; r < n; ++r) {
+        const FrameRec* rec = recs + (size_t)c * rec_cap + r;
+        const uint32_t type = rec->frame_type;
+        if (type == 0u) { size = 0; counter = 0; seq_errors = 0; frames = 0; continue; }   // FrameType::LSF -> dump_lsf
+        if (type != 3u && type != 4u) continue;
+        const uint8_t* p = rec->payload;
+        const uint32_t tag = p[25];
+        const uint32_t num = (tag & 0x7Fu) >> 2;
+        if (!(tag & 0x80u)) {
+            if (num != counter) { ++seq_errors; continue; }
+            ++counter; ++frames;
+            for (uint32_t i = 0; i < 25u; ++i) if (size + i < 832u) st->data[size + i] = p[i];
+            size = min(size + 25u, 832u);
+            continue;
+        }
+        const uint32_t take = min(num, 25u);
+        ++frames;
+        for (uint32_t i = 0; i < take; ++i) if (size + i < 832u) st->data[size + i] = p[i];
+        size = min(size + take, 832u);
+        uint32_t crc = 0xFFFFu;
+        for (uint32_t i = 0; i < size; ++i) crc = mod_crc16_x25_update(crc, st->data[i]);
+        crc = ~crc & 0xFFFFu;
+        const uint32_t slot = atomicAdd(out_count, 1u);
+        if (slot < out_cap) {
+            PacketRec* o = out + slot;
+            o->channel = c; o->seq = completed; o->sample_pos = rec->sample_pos;
+            o->size = (uint16_t)size; o->checksum = (uint16_t)crc;
+            o->crc_ok = crc == 0x0F47u ? 1 : 0; o->frames = (uint8_t)frames; o->seq_errors = (uint8_t)min(seq_errors, 255u); o->reserved = 0;
+            for (uint32_t i = 0; i < 840u; ++i) o->data[i] = i < size ? st->data[i] : (uint8_t)0;
+        }
+        ++completed;
+    }
+    st->size = size; st->counter = counter; st->seq_errors = seq_errors; st->frames = frames; st->completed = completed;
+}
+__global__ void packet_reset_kernel(PacketState* state, uint32_t C)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    state[c].size = 0; state[c].counter = 0; state[c].seq_errors = 0; state[c].frames = 0; state[c].completed = 0;
+}
+
 __global__ void bert_reset_kernel(BertState* state, uint32_t C)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -520,7 +591,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo, &c->ev_seq})
         for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage};
+                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -566,7 +637,8 @@ int m17hip_upload_i16_async(m17hip_ctx* c, const int16_t* host, uint32_t C, uint
 
 int m17hip_synth_i16(m17hip_ctx* c, const m17_synth_params* params, uint32_t C, uint32_t T, uint32_t chan0)
 {
-    if (!c || !params || C == 0 || T == 0 || C > c->maxC || T > c->maxT || params->n_frames < 0 || params->kind > 3) return M17HIP_EINVAL;
+    if (!c || !params || C == 0 || T == 0 || C > c->maxC || T > c->maxT || params->n_frames < 0 || params->kind > 4) return M17HIP_EINVAL;
+    if (params->kind == 4 && (params->n_frames < 1 || params->n_frames > 33)) return M17HIP_EINVAL;   // 5-bit frame numbers
     static_assert(sizeof(ModParams) == sizeof(m17_synth_params), "parameter block layout");
     ModParams mp;
     std::memcpy(&mp, params, sizeof(mp));
@@ -748,6 +820,10 @@ int m17hip_demod_reset(m17hip_ctx* c)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemset2DAsync(c->hbuf, c->ypitch * sizeof(float), 0, YPRE * sizeof(float), c->maxC, c->stream));
     hipLaunchKernelGGL(bert_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, (BertState*)c->bert_state, c->maxC);
+    if (c->pkt_cap) {
+        hipLaunchKernelGGL(packet_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, (PacketState*)c->pkt_state, c->maxC);
+        HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(c->rec_count, 0, (size_t)c->maxC * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->overflow, 0, 4, c->stream));
     c->pos = 0;
@@ -876,6 +952,11 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     HIPCHK(c, hipGetLastError());
     if (c->bert)   // payload consumer: PRBS9 statistics over this run's BERT records
         hipLaunchKernelGGL(bert_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->recs, c->rec_cap, c->rec_count, (BertState*)c->bert_state, C);
+    if (c->pkt_cap) {   // payload consumer: packet reassembly over this run's packet records
+        HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
+        hipLaunchKernelGGL(packet_asm_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->recs, c->rec_cap, c->rec_count, (PacketState*)c->pkt_state, C,
+                           (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count);
+    }
     hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
     if (c->speculate) hipLaunchKernelGGL(carry_tail_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->hbuf, c->ypitch, T);
     HIPCHK(c, hipGetLastError());
@@ -980,6 +1061,44 @@ int m17hip_bert_stats(m17hip_ctx* c, m17_bert_stat* stats_host, uint32_t C)
     return M17HIP_OK;
 }
 
+int m17hip_packets_feed(m17hip_ctx* c, const m17_frame_rec* recs_host, const uint32_t* counts_host, uint32_t C, uint32_t pitch)
+{
+    if (!c || !recs_host || !counts_host || C == 0 || C > c->maxC || pitch == 0) return M17HIP_EINVAL;
+    if (!c->pkt_cap) return M17HIP_ESTATE;
+    const size_t rec_b = round_up((size_t)C * pitch * sizeof(FrameRec), 256);
+    int r = ensure_scratch(c, rec_b + (size_t)C * 4);
+    if (r) return r;
+    FrameRec* drec = reinterpret_cast<FrameRec*>(c->scratch);
+    uint32_t* dcnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->scratch) + rec_b);
+    HIPCHK(c, hipMemcpyAsync(drec, recs_host, (size_t)C * pitch * sizeof(FrameRec), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dcnt, counts_host, (size_t)C * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
+    hipLaunchKernelGGL(packet_asm_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, drec, pitch, dcnt, (PacketState*)c->pkt_state, C,
+                       (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the host buffers may go away
+    c->pkt_fed = true;
+    return M17HIP_OK;
+}
+
+int m17hip_packets_fetch(m17hip_ctx* c, m17_packet_rec* recs_host, uint32_t capacity, uint32_t* count)
+{
+    if (!c || !count || (capacity && !recs_host)) return M17HIP_EINVAL;
+    static_assert(sizeof(PacketRec) == sizeof(m17_packet_rec) && sizeof(PacketRec) == 864, "m17_packet_rec layout");
+    if (!c->pkt_cap || !(c->have_run || c->pkt_fed)) return M17HIP_ESTATE;
+    uint32_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, c->pkt_count, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *count = total;
+    const uint32_t stored = std::min(total, c->pkt_cap);
+    std::vector<PacketRec> tmp(stored);
+    if (stored) HIPCHK(c, hipMemcpy(tmp.data(), c->pkt_recs, (size_t)stored * sizeof(PacketRec), hipMemcpyDeviceToHost));
+    std::sort(tmp.begin(), tmp.end(), [](const PacketRec& a, const PacketRec& b) { return a.channel != b.channel ? a.channel < b.channel : a.seq < b.seq; });
+    const uint32_t n = std::min(stored, capacity);
+    if (n) std::memcpy(recs_host, tmp.data(), (size_t)n * sizeof(PacketRec));
+    return total > c->pkt_cap ? M17HIP_EOVERFLOW : M17HIP_OK;
+}
+
 int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
 {
     if (!c) return M17HIP_EINVAL;
@@ -1005,6 +1124,23 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 6:  // BERT statistics (m17hip_bert_stats) on/off
         c->bert = value != 0;
         return M17HIP_OK;
+    case 7: {  // packet reassembly (m17hip_packets_fetch): room for `value` completed packets per run, 0 = off
+        if (value < 0 || value > (1 << 24)) return M17HIP_EINVAL;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->pkt_recs) hipFree(c->pkt_recs);
+        c->pkt_recs = nullptr; c->pkt_cap = 0; c->pkt_fed = false;
+        if (value == 0) return M17HIP_OK;
+        if (!c->pkt_state) {
+            HIPCHK(c, hipMalloc(&c->pkt_state, (size_t)c->maxC * sizeof(PacketState)));
+            HIPCHK(c, hipMalloc((void**)&c->pkt_count, 4));
+        }
+        HIPCHK(c, hipMalloc(&c->pkt_recs, (size_t)value * sizeof(PacketRec)));
+        c->pkt_cap = (uint32_t)value;
+        hipLaunchKernelGGL(packet_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, (PacketState*)c->pkt_state, c->maxC);
+        HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
+        HIPCHK(c, hipGetLastError());
+        return M17HIP_OK;
+    }
     case 4:  // samples of the first segment of a run (0 = like the others)
         if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
         c->seg0_len = (uint32_t)value;

@@ -16,7 +16,7 @@ namespace mobilinkd
 class BatchedDemodulator
 {
     m17hip_ctx* ctx_ = nullptr;
-    uint32_t channels_ = 0, samples_ = 0;
+    uint32_t channels_ = 0, samples_ = 0, room_ = 0;
 
     static void check(int code, const char* what)
     {
@@ -60,6 +60,17 @@ public:
         std::vector<m17_bert_stat> st(channels_);
         check(m17hip_bert_stats(ctx_, st.data(), channels_), "m17hip_bert_stats");
         return st;
+    }
+    // Packet reassembly per channel (decode_packet, apps/m17-demod.cpp:207-253): enable with room for `room` packets per run (0 = off),
+    // then packets() returns what the last run completed, ordered by (channel, seq)
+    void enable_packets(uint32_t room) { check(m17hip_tune(ctx_, 7, room), "m17hip_tune"); room_ = room; }
+    std::vector<m17_packet_rec> packets()
+    {
+        std::vector<m17_packet_rec> out(room_);
+        uint32_t n = 0;
+        check(m17hip_packets_fetch(ctx_, out.data(), room_, &n), "m17hip_packets_fetch");
+        out.resize(n < room_ ? n : room_);
+        return out;
     }
     std::vector<m17_diag> diagnostics()
     {

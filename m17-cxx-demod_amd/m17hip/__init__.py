@@ -27,13 +27,16 @@ FLAG_INVERT = 1
 KERNELS = {"fir_rrc150": 0, "dcd": 1, "demod_seq": 2, "decode": 3, "correlator": 4, "compact": 5, "limit_track": 6}
 LSF_INFO = np.dtype([("dst", "S10"), ("src", "S10"), ("type", "<u2"), ("crc_ok", "u1"), ("reserved", "u1", (9,))])
 BERT_STAT = np.dtype([("bits", "<u4"), ("errors", "<u4"), ("synced", "<u4"), ("frames", "<u4")])
+PACKET_REC = np.dtype([("channel", "<u4"), ("seq", "<u4"), ("sample_pos", "<u8"), ("size", "<u2"), ("checksum", "<u2"), ("crc_ok", "u1"),
+                       ("frames", "u1"), ("seq_errors", "u1"), ("reserved", "u1"), ("data", "u1", (840,))])
+assert PACKET_REC.itemsize == 864
 VITERBI_SHAPES = {0: (488, 240), 1: (296, 144), 2: (420, 206), 3: (402, 197)}
 
 EXPORTS = [
     "m17hip_strerror", "m17hip_last_hip_error", "m17hip_version", "m17hip_ctx_create", "m17hip_ctx_destroy", "m17hip_set_stream",
     "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_upload_i16_async", "m17hip_synth_i16", "m17hip_download_i16", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_dcd", "m17hip_viterbi",
     "m17hip_slice_llr", "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
-    "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
+    "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_packets_fetch", "m17hip_packets_feed", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
 ]
 
 
@@ -217,6 +220,19 @@ class Context:
         st = np.zeros(n, dtype=BERT_STAT)
         self._chk(self.lib.m17hip_bert_stats(self.h, _ptr(st), C.c_uint32(n)))
         return st
+
+    def packets(self, capacity=4096):
+        """Packets the last run completed, ordered by (channel, seq) (enable with tune(7, room) before the runs)."""
+        out = np.zeros(capacity, dtype=PACKET_REC)
+        n = C.c_uint32(0)
+        self._chk(self.lib.m17hip_packets_fetch(self.h, _ptr(out), C.c_uint32(capacity), C.byref(n)))
+        return out[: min(n.value, capacity)]
+
+    def packets_feed(self, recs2d, counts):
+        """Run the packet consumer over caller-supplied frame records [channels][pitch] (counts[c] used per row)."""
+        r = np.ascontiguousarray(recs2d, dtype=FRAME_REC)
+        n = np.ascontiguousarray(counts, dtype=np.uint32)
+        self._chk(self.lib.m17hip_packets_feed(self.h, _ptr(r), _ptr(n), C.c_uint32(r.shape[0]), C.c_uint32(r.shape[1])))
 
     def tune(self, key, value):
         self._chk(self.lib.m17hip_tune(self.h, C.c_int(key), C.c_int64(value)))

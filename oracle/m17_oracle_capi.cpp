@@ -207,6 +207,49 @@ void m17o_bert_count(const uint8_t* payloads25, size_t n_frames, uint32_t* bits,
     *bits = p.bit_count; *errs = p.err_count; *synced = p.synced;
 }
 
+// Packet reassembly consumer: decode_packet (apps/m17-demod.cpp:207-253) with dump_lsf's reset (:154-155) over the callback
+// records of ONE channel in order (types[n], payloads[n][32]).  `cur`/`st` carry current_packet and {frame counter, sequence
+// errors, frames accepted} between calls (st[0] = current_packet.size()).  Per closed packet k: size[k], checksum[k],
+// frames[k], seq_errors[k], rec_index[k] and data[k][840].  The checksum is CRC-16/X.25 (boost::crc_optimal<16, 0x1021,
+// 0xFFFF, 0xFFFF, true, true>, :218 — boost is absent, restated from the published parameters; "123456789" -> 0x906E).
+// dump_lsf's ENCAPSULATED branch (:157-171) indexes a 30-byte array at 109..111 (out of bounds) and is not modelled.
+size_t m17o_packet_reassemble(const uint8_t* types, const uint8_t* payloads32, size_t n, uint8_t* cur, uint32_t* st, size_t cap,
+                              uint16_t* size, uint16_t* checksum, uint8_t* frames, uint8_t* seq_errors, uint32_t* rec_index, uint8_t* data840)
+{
+    std::vector<uint8_t> current_packet(cur, cur + st[0]);
+    size_t packet_frame_counter = st[1];
+    uint32_t errs = st[2], nfr = st[3];
+    size_t done = 0;
+    for (size_t r = 0; r < n; ++r) {
+        const uint8_t* seg = payloads32 + 32 * r;
+        if (types[r] == (uint8_t)FrameType::LSF) { current_packet.clear(); packet_frame_counter = 0; errs = 0; nfr = 0; continue; }
+        if (types[r] != (uint8_t)FrameType::BASIC_PACKET && types[r] != (uint8_t)FrameType::FULL_PACKET) continue;
+        if (seg[25] & 0x80) {
+            size_t packet_size = (seg[25] & 0x7F) >> 2;
+            packet_size = std::min(packet_size, size_t(25));
+            for (size_t i = 0; i != packet_size; ++i) current_packet.push_back(seg[i]);
+            ++nfr;
+            const uint16_t sum = crc16_x25(current_packet.data(), current_packet.size());
+            if (done < cap) {
+                size[done] = (uint16_t)current_packet.size(); checksum[done] = sum; frames[done] = (uint8_t)nfr;
+                seq_errors[done] = (uint8_t)std::min<uint32_t>(errs, 255); rec_index[done] = (uint32_t)r;
+                std::memset(data840 + 840 * done, 0, 840);
+                std::memcpy(data840 + 840 * done, current_packet.data(), std::min<size_t>(current_packet.size(), 840));
+            }
+            ++done;
+            continue;
+        }
+        const size_t frame_number = (seg[25] & 0x7F) >> 2;
+        if (frame_number != packet_frame_counter) { ++errs; continue; }
+        packet_frame_counter += 1; ++nfr;
+        for (size_t i = 0; i != 25; ++i) current_packet.push_back(seg[i]);
+    }
+    st[0] = (uint32_t)current_packet.size(); st[1] = (uint32_t)packet_frame_counter; st[2] = errs; st[3] = nfr;
+    std::memcpy(cur, current_packet.data(), std::min<size_t>(current_packet.size(), 832));
+    return done;
+}
+uint16_t m17o_crc16_x25(const uint8_t* d, size_t n) { return crc16_x25(d, n); }
+
 // One frame through the frame decoder.  state_io: decoder state in/out; lich_io: lich_segments;
 // lsf_io[30]; dep401_io: the stale depuncture byte (Q4).  Returns number of callbacks (0..2) written to recs.
 struct VecSink {

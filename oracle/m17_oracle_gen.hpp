@@ -175,9 +175,25 @@ inline void packet_frame_bits(const uint8_t data26[26], int8_t f[368])  // 206 b
     finish_frame(f);
 }
 
+// CRC-16/X.25 (poly 0x1021 reflected = 0x8408, init 0xFFFF, xorout 0xFFFF; check "123456789" -> 0x906E): the
+// boost::crc_optimal<16, 0x1021, 0xFFFF, 0xFFFF, true, true> of apps/m17-demod.cpp:218.  boost is absent here, so this is
+// the published algorithm; one byte of the register update, without the final xor.
+inline uint16_t crc16_x25_update(uint16_t crc, uint8_t b)
+{
+    crc ^= b;
+    for (int i = 0; i < 8; ++i) crc = (crc & 1) ? (uint16_t)((crc >> 1) ^ 0x8408) : (uint16_t)(crc >> 1);
+    return crc;
+}
+inline uint16_t crc16_x25(const uint8_t* d, size_t n)
+{
+    uint16_t crc = 0xFFFF;
+    for (size_t i = 0; i < n; ++i) crc = crc16_x25_update(crc, d[i]);
+    return (uint16_t)~crc;
+}
+
 struct GenParams {
     uint64_t seed = 1;
-    int kind = 0;             // 0 = BERT, 1 = voice-like stream, 2 = packet (RAW), 3 = noise only
+    int kind = 0;             // 0 = BERT, 1 = voice-like stream, 2 = packet (RAW), 3 = noise only, 4 = packet with FCS
     int n_frames = 8;         // payload frames (BERT / stream / packet)
     int lead_in = 0;          // samples of loud noise before the burst (0 = start at the preamble)
     double lead_sigma = 20000.0;
@@ -257,6 +273,34 @@ inline std::vector<int16_t> generate(const GenParams& p, GenTruth* truth = nullp
             packet_frame_bits(d, f);
             ss.bytes(SYNC_PACKET, 2); ss.bits368(f);
             d[25] &= 0xFC;  // only 206 bits are carried
+            tr.payloads.emplace_back(d, d + 26);
+        }
+        ss.bytes(SYNC_EOT, 2); ss.zeros(40);
+    } else if (p.kind == 4) {  // RAW packet whose last two bytes are the CRC-16/X.25 frame check sequence the packet consumer
+                               // verifies (apps/m17-demod.cpp:207-253: residue 0x0f47 over contents + FCS)
+        for (int k = 0; k < (p.n_preamble > 0 ? p.n_preamble : 1); ++k) ss.preamble();
+        make_lsf("N0CALL", "", (uint16_t)0x0002, tr.lsf);
+        lsf_frame_bits(tr.lsf, f);
+        ss.bytes(SYNC_LSF, 2); ss.bits368(f);
+        uint16_t crc = 0xFFFF;
+        for (int i = 0; i < p.n_frames; ++i) {
+            uint8_t d[26];
+            for (int k = 0; k < 24; k += 8) { uint64_t r = rnd(); std::memcpy(d + k, &r, 8); }
+            d[24] = (uint8_t)rnd();
+            const bool last = (i == p.n_frames - 1);
+            if (!last) {
+                for (int k = 0; k < 25; ++k) crc = crc16_x25_update(crc, d[k]);
+                d[25] = (uint8_t)(i << 2);
+            } else {
+                const int len = 2 + (int)(rnd() % 24);  // 2..25 bytes in the last frame, FCS included
+                for (int k = 0; k < len - 2; ++k) crc = crc16_x25_update(crc, d[k]);
+                const uint16_t fcs = (uint16_t)~crc;
+                d[len - 2] = (uint8_t)(fcs & 0xFF); d[len - 1] = (uint8_t)(fcs >> 8);
+                for (int k = len; k < 25; ++k) d[k] = 0;
+                d[25] = (uint8_t)(0x80 | (len << 2));
+            }
+            packet_frame_bits(d, f);
+            ss.bytes(SYNC_PACKET, 2); ss.bits368(f);
             tr.payloads.emplace_back(d, d + 26);
         }
         ss.bytes(SYNC_EOT, 2); ss.zeros(40);

@@ -367,6 +367,37 @@ def bert_count(payloads25, lib=None, prefix="m17o_"):
     return bits.value, errs.value, bool(sync.value)
 
 
+def crc16_x25(data, lib=None, prefix="m17o_"):
+    lib = lib or oracle()
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    f = getattr(lib, prefix + "crc16_x25")
+    f.restype = C.c_uint16
+    return f(_p(d), C.c_size_t(d.size))
+
+
+class PacketAssembler:
+    """The packet consumer of apps/m17-demod.cpp (decode_packet + dump_lsf's reset) for one channel, state kept across calls."""
+
+    def __init__(self):
+        self.cur = np.zeros(832, dtype=np.uint8)
+        self.st = np.zeros(4, dtype=np.uint32)
+
+    def feed(self, types, payloads32, cap=64):
+        lib = oracle()
+        t = np.ascontiguousarray(types, dtype=np.uint8)
+        pl = np.ascontiguousarray(payloads32, dtype=np.uint8).reshape(-1, 32)
+        size, csum = np.zeros(cap, np.uint16), np.zeros(cap, np.uint16)
+        frames, errs, idx = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8), np.zeros(cap, np.uint32)
+        data = np.zeros((cap, 840), np.uint8)
+        f = lib.m17o_packet_reassemble
+        f.restype = C.c_size_t
+        n = f(_p(t), _p(pl), C.c_size_t(t.size), _p(self.cur), _p(self.st), C.c_size_t(cap), _p(size), _p(csum), _p(frames), _p(errs),
+              _p(idx), _p(data))
+        assert n <= cap
+        return [dict(size=int(size[k]), checksum=int(csum[k]), frames=int(frames[k]), seq_errors=int(errs[k]), rec_index=int(idx[k]),
+                     data=data[k].copy()) for k in range(n)]
+
+
 def decode_frame(sync_type, llr368, state=0, lich=0, lsf=None, dep401=0, cost=0, lib=None, prefix="m17o_"):
     """One frame through the frame decoder; returns (records, state, lich_segments, lsf, dep401, cost)."""
     lib = lib or oracle()

@@ -53,6 +53,8 @@ def test_scale_exhaustive(ctx):
     ramp = np.tile(s, 2)[:96000][None, :].repeat(2, axis=0)
     ramp[1] = ramp[1][::-1]
     ctx.upload(ramp)
+    for flags in (0, m17hip.FLAG_INVERT):   # ... and through K1: all values, both polarities
+        assert np.array_equal(ctx.fir(flags=flags), np.stack([ol.fir_i16(ramp[c], invert=flags) for c in range(2)]))
     sums = ctx.dcd()
     for c in range(2):
         xs = ol.scale(ramp[c])
@@ -412,6 +414,7 @@ def test_full_chain_random_scenarios(ctx, seed):
     dict(seed=13, kind=1, n_frames=14, lead_in=2000, noise_sigma=1500.0, tail_sigma=300.0, dc_offset=-1500.0, gain=0.6, invert=1),
     dict(seed=14, kind=2, n_frames=11, lead_in=100, noise_sigma=200.0, tail_sigma=4000.0, dc_offset=2500.0, gain=1.4, n_preamble=3),
     dict(seed=15, kind=3, n_frames=0, lead_in=500, noise_sigma=900.0, tail_sigma=100.0, lead_sigma=12000.0),
+    dict(seed=16, kind=4, n_frames=17, lead_in=3072, noise_sigma=500.0, tail_sigma=500.0, lead_sigma=40000.0),   # packets closed by an FCS
 ])
 def test_device_synthesis_bit_exact(ctx, kw):
     """m17hip_synth_i16 (m17-mod framing, RRC shaping in double, impairments) against the test generator: every
@@ -504,6 +507,95 @@ def test_bert_statistics_consumer(ctx):
     assert total_err > 0 and int(st["frames"].sum()) > 10 * C   # the scenario has both decoded frames and bit errors
     with pytest.raises(m17hip.M17HipError):
         ctx.bert_stats(C)   # not enabled any more
+
+
+def _check_packets(got, exp_by_channel, pos_by_channel=None):
+    for c, exp in enumerate(exp_by_channel):
+        g = got[got["channel"] == c]
+        assert len(exp) == g.size, (c, len(exp), g.size)
+        for e, q in zip(exp, g):
+            assert (int(q["size"]), int(q["checksum"]), int(q["frames"]), int(q["seq_errors"])) == (e["size"], e["checksum"], e["frames"], e["seq_errors"]), c
+            assert np.array_equal(q["data"], e["data"]) and bool(q["crc_ok"]) == (e["checksum"] == 0x0F47), c
+            if pos_by_channel is not None:
+                assert int(q["sample_pos"]) == int(pos_by_channel[c][e["rec_index"]]), c
+
+
+def test_packet_reassembly_consumer(ctx):
+    """decode_packet (apps/m17-demod.cpp:207-253) on the device (m17hip_packets_fetch) against the oracle's
+    restatement fed with the oracle's frame records: one packet transmission per channel (with and without a frame check
+    sequence, 1..33 frames, clean to very noisy so that frames are lost and checksums break), the stream fed as two runs so
+    that half-assembled packets cross the run boundary."""
+    C, T = 48, 90000
+    import itertools
+    cases = list(itertools.product([4, 4, 2], [300.0, 900.0, 1800.0, 2600.0], [1, 5, 33, 12]))   # kind x noise x frames = 48 channels
+    x = np.stack([ol.generate(ol.gen_params(seed=9000 + c, kind=kind, n_frames=nf, lead_in=3072, lead_sigma=40000.0, noise_sigma=sigma,
+                                            tail_sigma=400.0, total=T))[:T] for c, (kind, sigma, nf) in enumerate(cases)])
+    recs, counts, _ = ol.demod_batch(x, cap=2 * (T // 1920 + 2) + 4, threads=8)
+    ctx.tune(7, 1024)
+    try:
+        ctx.reset()
+        got = []
+        for a, b in ((0, 20000), (20000, T)):
+            ctx.upload(x[:, a:b])
+            ctx.run()
+            got.append(ctx.packets())
+        got = np.concatenate(got)
+    finally:
+        ctx.tune(7, 0)
+    exp = [ol.PacketAssembler().feed(recs[c, :counts[c]]["frame_type"], recs[c, :counts[c]]["payload"]) for c in range(C)]
+    _check_packets(got, exp, [recs[c]["sample_pos"] for c in range(C)])
+    assert int(got["crc_ok"].sum()) >= C // 3 and int((got["crc_ok"] == 0).sum()) >= 4, (int(got["crc_ok"].sum()), got.size)
+    assert got[got["crc_ok"] == 1]["size"].max() > 800      # a full-length (33-frame) packet made it through intact
+    assert (got["sample_pos"] > 20000).sum() > C // 4         # ... closed in the second run, begun in the first
+    with pytest.raises(m17hip.M17HipError):
+        ctx.packets()   # not enabled any more
+
+
+def test_packet_reassembly_rules_on_crafted_records(ctx):
+    """The packet consumer over caller-supplied records (m17hip_packets_feed): random record sequences per channel — LSFs,
+    numbered frames mostly but not always in sequence, closing frames with every byte count, other frame types in between —
+    fed in three slices with the assembly state carried over, against the oracle's decode_packet restatement."""
+    rng = np.random.default_rng(2024)
+    C, N = 80, 90
+    recs = np.zeros((C, N), dtype=m17hip.FRAME_REC)
+    for c in range(C):
+        counter, since_lsf = 0, 0
+        for k in range(N):
+            r = recs[c, k]
+            r["channel"], r["seq"], r["sample_pos"] = c, k, 1920 * k + c
+            u = rng.random()
+            r["payload"][:26] = rng.integers(0, 256, 26, dtype=np.uint8)
+            if u < 0.08 or since_lsf > 30:
+                r["frame_type"], counter, since_lsf = 0, 0, 0
+            elif u < 0.20:
+                r["frame_type"] = int(rng.choice([1, 2, 5]))
+            elif u < 0.32:                                                    # closing frame, any count (values above 25 are clamped)
+                r["frame_type"], r["payload"][25] = int(rng.choice([3, 4])), 0x80 | (int(rng.integers(0, 32)) << 2) | int(rng.integers(0, 4))
+                since_lsf += 1
+            else:
+                num = counter if rng.random() < 0.85 else int(rng.integers(0, 32))
+                r["frame_type"], r["payload"][25] = int(rng.choice([3, 4])), (num << 2) | int(rng.integers(0, 4))
+                counter += int(num == counter)
+                since_lsf += 1
+    ctx.tune(7, 4096)
+    try:
+        ctx.reset()
+        got = []
+        for a, b in ((0, 31), (31, 32), (32, N)):
+            counts = np.full(C, b - a, dtype=np.uint32)
+            counts[C - 1] = 0 if a == 31 else b - a                          # an empty row as well
+            ctx.packets_feed(recs[:, a:b], counts)
+            got.append(ctx.packets())
+        got = np.concatenate(got)
+    finally:
+        ctx.tune(7, 0)
+    exp = []
+    for c in range(C):
+        use = np.concatenate([recs[c, :31], recs[c, 31:32] if c != C - 1 else recs[c, :0], recs[c, 32:]])
+        exp.append(ol.PacketAssembler().feed(use["frame_type"], use["payload"]))
+    assert max(e["size"] for ex in exp for e in ex) <= 832
+    _check_packets(got, exp)
+    assert got.size > 5 * C and 0 < int((got["seq_errors"] > 0).sum()) < got.size
 
 
 def test_full_size_properties():

@@ -223,6 +223,21 @@ def test_scale_identities_exhaustive():
     assert np.array_equal(ref, s.astype(np.float32) / np.float32(41067.0))
     inv = ol.scale(s, invert=1)
     assert inv[0] == ref[0] and np.array_equal(inv[1:], -ref[1:])              # -32768 * -1 wraps (int16)
+    # the device's form (csrc/m17_common.hpp scale_sample): q = s * RN(1/41067); r = fma(-q, 41067, s); fma(r, RN(1/41067), q),
+    # evaluated here in exact rational arithmetic with one rounding per operation
+    from fractions import Fraction
+
+    def rn(fr):
+        x = np.float32(float(fr))
+        near = [x, np.nextafter(x, np.float32(np.inf), dtype=np.float32), np.nextafter(x, np.float32(-np.inf), dtype=np.float32)]
+        return np.float32(min(near, key=lambda v: (abs(Fraction(float(v)) - fr), int(np.float32(v).view(np.uint32)) & 1)))
+
+    rcp = Fraction(float(np.float32(1.0) / np.float32(41067.0)))
+    for v in list(range(-32768, 32768, 7)) + [-32768, -1, 0, 1, 32767, 41066 - 65536]:
+        q = rn(Fraction(v) * rcp)
+        r = rn(Fraction(v) - Fraction(float(q)) * 41067)
+        got = rn(Fraction(float(r)) * rcp + Fraction(float(q)))
+        assert got.view(np.uint32) == ref[v + 32768].view(np.uint32), v
 
 
 def test_front_end_golden(golden):
@@ -310,3 +325,79 @@ def test_callsign_kat():
     assert ol.decode_callsign(bytes([0x00, 0x00, 0x5F, 0x1B, 0x66, 0x91])) == b"IU2KWO" + bytes(4)
     assert ol.decode_callsign(bytes([0xFF] * 6)) == b"BROADCAST" + bytes(1)
     assert ol.decode_callsign(ol.encode_callsign("N0CALL")) == b"N0CALL" + bytes(4)
+
+
+def test_crc16_x25_kat():
+    """CRC-16/X.25 (apps/m17-demod.cpp:218 boost::crc_optimal<16, 0x1021, 0xFFFF, 0xFFFF, true, true>): the catalogue check value,
+    and the residue the packet consumer tests for (:222) once the FCS is appended low byte first."""
+    msg = np.frombuffer(b"123456789", dtype=np.uint8)
+    assert ol.crc16_x25(msg) == 0x906E
+    fcs = ol.crc16_x25(msg)
+    assert ol.crc16_x25(np.concatenate([msg, np.array([fcs & 0xFF, fcs >> 8], dtype=np.uint8)])) == 0x0F47
+    assert ol.crc16_x25(np.zeros(0, dtype=np.uint8)) == 0x0000
+
+
+def _packet_rec(data, tag):
+    p = np.zeros(32, dtype=np.uint8)
+    p[:len(data)] = data
+    p[25] = tag
+    return p
+
+
+def test_packet_reassembly_rules():
+    """decode_packet (apps/m17-demod.cpp:207-253) + dump_lsf's reset (:154-155) on hand-made callback records: frames in and out of
+    sequence, the byte count of the closing frame clamped to 25, an LSF restarting assembly, state carried across calls."""
+    rng = np.random.default_rng(5)
+    body = rng.integers(0, 256, 60, dtype=np.uint8)
+    fcs = ol.crc16_x25(body)
+    whole = np.concatenate([body, np.array([fcs & 0xFF, fcs >> 8], dtype=np.uint8)])       # 62 bytes = 25 + 25 + 12
+    lsf = (0, np.zeros(32, dtype=np.uint8))
+    f0, f1, fl = (3, _packet_rec(whole[:25], 0 << 2)), (3, _packet_rec(whole[25:50], 1 << 2)), (3, _packet_rec(whole[50:], 0x80 | (12 << 2)))
+    stray = (3, _packet_rec(rng.integers(0, 256, 25, dtype=np.uint8), 7 << 2))
+    bert = (5, np.zeros(32, dtype=np.uint8))
+
+    def run(seq, asm=None):
+        asm = asm or ol.PacketAssembler()
+        return asm.feed([t for t, _ in seq], np.stack([p for _, p in seq]))
+
+    (p,) = run([lsf, f0, bert, f1, fl])
+    assert (p["size"], p["checksum"], p["frames"], p["seq_errors"], p["rec_index"]) == (62, 0x0F47, 3, 0, 4) and bytes(p["data"][:62]) == whole.tobytes()
+    (p,) = run([lsf, f0, stray, f1, fl])                        # a frame out of sequence is dropped, the rest still assembles
+    assert (p["size"], p["checksum"], p["seq_errors"]) == (62, 0x0F47, 1)
+    (p,) = run([lsf, f1, f0, f1, fl])                           # frame 1 before frame 0: dropped, then the packet is whole
+    assert (p["size"], p["checksum"], p["frames"], p["seq_errors"]) == (62, 0x0F47, 3, 1)
+    (p,) = run([lsf, f0, fl])                                   # a lost frame: closes with a checksum error
+    assert p["size"] == 37 and p["checksum"] != 0x0F47
+    (p,) = run([lsf, (3, _packet_rec(whole[:25], 0x80 | (31 << 2)))])   # count above 25 is clamped (:212)
+    assert p["size"] == 25
+    a, b = run([lsf, f0, f1, fl, lsf, f0, f1, fl])              # an LSF clears the assembly
+    assert a["checksum"] == b["checksum"] == 0x0F47 and b["size"] == 62
+    a, b = run([lsf, f0, f1, fl, f0, f1, fl])                   # without one, nothing does (current_packet is only cleared in dump_lsf)
+    assert a["checksum"] == 0x0F47 and b["size"] == 74 and b["checksum"] != 0x0F47
+    asm = ol.PacketAssembler()                                  # state carried between calls
+    assert run([lsf, f0], asm) == [] and run([f1], asm) == []
+    (p,) = run([fl], asm)
+    assert (p["size"], p["checksum"], p["frames"]) == (62, 0x0F47, 3)
+
+
+def test_packet_with_fcs_end_to_end():
+    """Generator kind 4 (packets closed by a CRC-16/X.25 FCS) through the oracle demodulator and the packet consumer: the
+    reassembled bytes are the ones sent and the checksum test passes; also the maximum length (33 frames = 825 bytes)."""
+    for nf in (1, 4, 33):
+        for seed in range(40, 48):
+            p = ol.gen_params(seed=seed, kind=4, n_frames=nf, lead_in=3072, noise_sigma=300, tail=6000, tail_sigma=300, lead_sigma=40000.0)
+            s, truth = ol.generate(p, with_truth=True)
+            recs, _ = ol.demod(s)
+            pk = [r for r in recs if r["frame_type"] in (3, 4)]
+            if len(recs) and recs[0]["frame_type"] == 0 and len(pk) == nf:
+                break
+        else:
+            pytest.fail("no seed acquired the transmission")
+        out = ol.PacketAssembler().feed(recs["frame_type"], recs["payload"])
+        assert len(out) == 1
+        last = truth["payloads"][nf - 1]
+        assert last[25] & 0x80
+        sent = np.concatenate([truth["payloads"][i][:25] for i in range(nf - 1)] + [last[:(last[25] & 0x7F) >> 2]])
+        assert out[0]["size"] == sent.size and out[0]["checksum"] == 0x0F47 and out[0]["frames"] == nf and out[0]["seq_errors"] == 0
+        assert bytes(out[0]["data"][:sent.size]) == sent.tobytes()
+    assert sent.size > 800
