@@ -86,98 +86,6 @@ __global__ __launch_bounds__(FIR_THREADS, 3) void fir_rrc150_kernel(const int16_
     }
 }
 
-// K1, grouped form.  The same arithmetic in the same order, organised so that few registers are live: the 149 taps are taken in
-// groups of FIR_R = 15; inside a group the 15 outputs of a lane read the samples cur[0..14] (this group) and nxt[0..14] (the
-// 15 before them), so the "sliding window" is two register arrays that swap roles from group to group (the group loop is
-// rolled, two groups per trip) and the only loads are 15 LDS words per group, issued at the start of the group before the tap
-// that needs none of them.  Taps come from constant memory as scalars.  ~60 VGPRs instead of 167: up to 8 waves per SIMD hide
-// the LDS latency among themselves, and the kernel packs beside the 128-register waves of K5 / K3 without stranding registers.
-__device__ __constant__ const float RRC_TAPS_C[160] = {
-#define T10(b) rrc_tap(b), rrc_tap(b + 1), rrc_tap(b + 2), rrc_tap(b + 3), rrc_tap(b + 4), rrc_tap(b + 5), rrc_tap(b + 6), rrc_tap(b + 7), rrc_tap(b + 8), rrc_tap(b + 9)
-    T10(0), T10(10), T10(20), T10(30), T10(40), T10(50), T10(60), T10(70), T10(80), T10(90), T10(100), T10(110), T10(120), T10(130),
-    rrc_tap(140), rrc_tap(141), rrc_tap(142), rrc_tap(143), rrc_tap(144), rrc_tap(145), rrc_tap(146), rrc_tap(147), rrc_tap(148),
-#undef T10
-    0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-template <int WAVES>
-__global__ __launch_bounds__(FIR_THREADS, WAVES) void fir_rrc150_grouped_kernel(const int16_t* __restrict__ x, size_t xpitch,
-                                                                            float* __restrict__ y, size_t ypitch, uint32_t T,
-                                                                            uint32_t flags)
-{
-    __shared__ __attribute__((aligned(16))) float win[FIR_WIN + 4];
-    const int tid = threadIdx.x;
-    const uint32_t c = blockIdx.y;
-    const uint32_t t0 = blockIdx.x * FIR_TILE;
-    const bool invert = flags & 1u;
-    const int16_t* xr = x + (size_t)c * xpitch + XPRE;
-    float* yr = y + (size_t)c * ypitch + YPRE;
-    const int64_t w0 = (int64_t)t0 - (NTAPS - 1);
-    for (int k = tid; k < (FIR_WIN + 3) / 4; k += FIR_THREADS) {
-        const int64_t t = w0 + 4 * k;
-        short4 v = make_short4(0, 0, 0, 0);
-        if (t < (int64_t)T) v = *reinterpret_cast<const short4*>(xr + t);
-        float4 f;
-        f.x = scale_sample(v.x, invert);
-        f.y = scale_sample(v.y, invert);
-        f.z = scale_sample(v.z, invert);
-        f.w = scale_sample(v.w, invert);
-        *reinterpret_cast<float4*>(&win[4 * k]) = f;
-    }
-    __syncthreads();
-
-    // output r of this lane at tap i reads base[r - i]; group g (taps 15 g .. 15 g + 14): cur[q] = base[q - 15 g], nxt[q] = base[q - 15 (g + 1)]
-    const float* base = win + (NTAPS - 1) + tid * FIR_R;
-    float acc[FIR_R], A[FIR_R], B[FIR_R];
-#pragma unroll
-    for (int q = 0; q < FIR_R; ++q) A[q] = base[q];
-    auto group = [&](const float (&cur)[FIR_R], const float (&nxt)[FIR_R], int g, bool first, int ntaps) {
-#pragma unroll
-        for (int j = 0; j < FIR_R; ++j) {
-            if (j < ntaps) {
-                const float tap = RRC_TAPS_C[g * FIR_R + j];
-#pragma unroll
-                for (int r = 0; r < FIR_R; ++r) {
-                    const int q = r - j;
-                    const float p = (q >= 0 ? cur[q < 0 ? 0 : q] : nxt[q < 0 ? q + FIR_R : 0]) * tap;
-                    acc[r] = (first && j == 0 ? 0.0f : acc[r]) + p;
-                }
-            }
-        }
-    };
-    // groups 0..9: taps 0..148 (the last group has 14)
-#pragma unroll 1
-    for (int g2 = 0; g2 < 5; ++g2) {
-        const float* nb = base - FIR_R * (2 * g2 + 1);
-#pragma unroll
-        for (int q = 0; q < FIR_R; ++q) B[q] = nb[q];
-        if (g2 == 0) group(A, B, 0, true, FIR_R);
-        else group(A, B, 2 * g2, false, FIR_R);
-        if (g2 < 4) {
-#pragma unroll
-            for (int q = 0; q < FIR_R; ++q) A[q] = nb[q - FIR_R];
-            group(B, A, 2 * g2 + 1, false, FIR_R);
-        } else {   // last group: taps 135..148; the two oldest slots would lie in front of the window and are not used
-#pragma unroll
-            for (int q = 2; q < FIR_R; ++q) A[q] = nb[q - FIR_R];
-            A[0] = 0.f; A[1] = 0.f;
-            group(B, A, 2 * g2 + 1, false, FIR_R - 1);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < FIR_R; ++r) win[tid * FIR_R + r] = acc[r];
-    __syncthreads();
-    for (int k = tid; k < FIR_TILE / 4; k += FIR_THREADS) {
-        const uint32_t t = t0 + 4 * k;
-        if (t + 3 < T) {
-            *reinterpret_cast<float4*>(yr + t) = *reinterpret_cast<const float4*>(&win[4 * k]);
-        } else {
-            for (int q = 0; q < 4; ++q)
-                if (t + q < T) yr[t + q] = win[4 * k + q];
-        }
-    }
-}
-
 // =====================================================================================================
 // correlate_kernel — reference a4: Correlator::correlate (Correlator.h:51-64) against the four M17
 // sync words for every sample: corr[w][c][t] = sum_{i=0}^{7} word[i] * y[t - 70 + 10 i] (oldest symbol

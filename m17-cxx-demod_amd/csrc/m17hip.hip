@@ -56,7 +56,6 @@ struct m17hip_ctx {
     uint32_t* dropped = nullptr;      // [maxC] K5: the segment dropped the speculation
     void* bert_state = nullptr;       // [maxC] BertState (tuning knob 6)
     bool bert = false;
-    int fir_variant = 0;              // experiment
     void* pkt_state = nullptr;        // [maxC] PacketState (tuning knob 7)
     void* pkt_recs = nullptr;         // [pkt_cap] PacketRec: packets completed by the last run
     uint32_t* pkt_count = nullptr;
@@ -466,10 +465,7 @@ int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_
 {
     Timed tm(c, KT_FIR, st);
     dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C);
-    if (c->fir_variant == 8) hipLaunchKernelGGL(fir_rrc150_grouped_kernel<8>, grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags);
-    else if (c->fir_variant == 6) hipLaunchKernelGGL(fir_rrc150_grouped_kernel<6>, grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags);
-    else if (c->fir_variant == 4) hipLaunchKernelGGL(fir_rrc150_grouped_kernel<4>, grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags);
-    else hipLaunchKernelGGL(fir_rrc150_kernel, grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags);
+    hipLaunchKernelGGL(fir_rrc150_kernel, grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
@@ -1128,7 +1124,6 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 6:  // BERT statistics (m17hip_bert_stats) on/off
         c->bert = value != 0;
         return M17HIP_OK;
-    case 8: c->fir_variant = (int)value; return M17HIP_OK;
     case 7: {  // packet reassembly (m17hip_packets_fetch): room for `value` completed packets per run, 0 = off
         if (value < 0 || value > (1 << 24)) return M17HIP_EINVAL;
         HIPCHK(c, hipStreamSynchronize(c->stream));
