@@ -73,7 +73,7 @@ def main():
     # generated ON the device, straight into the input slab (m17hip_synth_i16: m17-mod framing, RRC shaping, impairments; bit-identical to
     # the test generator ol.generate_batch, tests/test_gpu_parity.py::test_device_synthesis_bit_exact): inputs are resident in HBM
     ctx.synth(p, C, T, chan0=rank * C)
-    x = ctx.download()   # host copy for the parity spot check and the cpu_baseline leg only
+    x = ctx.download() if rank == 0 else None   # host copy for the parity spot check and the cpu_baseline leg only (rank 0)
     t_gen = time.time() - t_gen
     rec_cap_total = C * (2 * (T // 1920 + 2) + 4)
     rec_buf = torch.zeros(rec_cap_total * 64, dtype=torch.uint8, device=dev)
@@ -162,7 +162,7 @@ def main():
 
     # ---- CPU baseline: the oracle (scalar C++ restatement), all host cores, bounded sample of the same workload ----------------
     cpu = None
-    if args.cpu_seconds > 0:
+    if args.cpu_seconds > 0 and world == 1:   # rank 0 at N = 1 only
         probe_n = min(C, ncpu)
         tp = time.perf_counter()
         ol.demod_batch(x[:probe_n, : min(T, 96000)], cap=128, threads=ncpu)
