@@ -246,19 +246,21 @@ __device__ __forceinline__ int32_t vit_partner(int32_t m, int wl)
 // cost_[j] to its own metric and the complement to its partner's; which of the two sums is "candidate A" depends on
 // whether the lane held state j or j + 8 (`upper`, as a wave mask): dec = A > B, new metric = min (ties: equal values).
 template <int R>
-__device__ __forceinline__ uint32_t vit_step(uint32_t W, int wl, int32_t& m, uint32_t sh, unsigned long long upper)
+__device__ __forceinline__ unsigned long long vit_step(uint32_t W, int wl, int32_t& m, uint32_t sh, unsigned long long upper)
 {
     const int32_t c_own = (int32_t)__builtin_amdgcn_ubfe(W, sh, 8u);
     const int32_t c_oth = (int32_t)__builtin_amdgcn_ubfe(W, 24u - sh, 8u);
     const int32_t mp = vit_partner<R>(m, wl);
     const int32_t own = m + c_own, oth = mp + c_oth;
-    const unsigned long long gt = __ballot(own > oth), lt = __ballot(oth > own);
+    // decision = (candidate through the lower predecessor) > (the other one): that candidate is `own` on the lane that held
+    // state j and `oth` on the lane that held j + 8, and it loses exactly when the minimum differs from it (a tie keeps it)
+    const int32_t low = ((upper >> wl) & 1ull) ? oth : own;
     m = min(own, oth);
-    const unsigned long long bal = (gt & ~upper) | (lt & upper);   // decision of the state now at position p is bit lane_of(p)
+    const unsigned long long bal = __ballot(m != low);   // decision of the state now at position p is bit lane_of(p)
     // replica 0 = lanes 0-3, 16-19, 32-35, 48-51 -> a 16-bit decision set spread over bits 0-7 and 16-23 of a word:
     // position p sits at bit vit_bit_of_pos(p); the odd step of a pair goes 8 bits higher into the same word
-    const unsigned long long rep0 = bal & 0x000F000F000F000Full;
-    return (uint32_t)rep0 | ((uint32_t)(rep0 >> 32) << 4);
+    // (the trellis loop runs with replica 0's lanes enabled only, so `bal` has no other bits: lanes 0-3, 16-19, 32-35, 48-51)
+    return bal;
 }
 // where the decision of the state at position p sits in a step's decision set (see vit_step)
 __device__ __forceinline__ uint32_t vit_bit_of_pos(uint32_t p) { return (p & 3u) | ((p & 8u) >> 1) | ((p & 4u) << 2); }
@@ -313,22 +315,27 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
     const unsigned long long tp1 = L.prof ? wall_clock64() : 0ull;
     const int groups = (steps + 3) >> 2;
     v4u Wn = *reinterpret_cast<const M17_LDS v4u*>(cw);
+    // Four replicas of the 16 states fill the wave; the exchanges (lane ^ 32, ^ 16, ^ 2, ^ 1) stay inside a replica, so the loop
+    // runs on replica 0's lanes alone and a step's ballot IS its decision set.
+    if ((0x000F000F000F000Full >> wl) & 1ull)
     for (int g = 0; g < groups; ++g) {
         const v4u W = Wn;
         if (g + 1 < groups) Wn = *reinterpret_cast<const M17_LDS v4u*>(cw + 4 * (g + 1));  // next group in flight
         const int h = 4 * g;
-        const uint32_t b0 = vit_step<0>(W.x, wl, m, sh[0], upper[0]);
+        const unsigned long long b0 = vit_step<0>(W.x, wl, m, sh[0], upper[0]);
         int32_t m1 = m, m2, m3;
-        const uint32_t b1 = vit_step<1>(W.y, wl, m1, sh[1], upper[1]);
+        const unsigned long long b1 = vit_step<1>(W.y, wl, m1, sh[1], upper[1]);
         m2 = m1;
-        const uint32_t b2 = vit_step<2>(W.z, wl, m2, sh[2], upper[2]);
+        const unsigned long long b2 = vit_step<2>(W.z, wl, m2, sh[2], upper[2]);
         m3 = m2;
-        const uint32_t b3 = vit_step<3>(W.w, wl, m3, sh[3], upper[3]);
+        const unsigned long long b3 = vit_step<3>(W.w, wl, m3, sh[3], upper[3]);
         // a trailing partial group computes steps that do not exist: keep the metric of the last real step
         const int left = steps - h;
         m = left >= 4 ? m3 : (left == 3 ? m2 : (left == 2 ? m1 : m));
-        hist[2 * g] = b0 | (b1 << 8);
-        hist[2 * g + 1] = b2 | (b3 << 8);
+        // a 16-bit decision set = the ballot's low word | its high word << 4 (bits 0-7 and 16-23); the odd step of a pair sits 8 bits higher
+        const unsigned long long p01 = b0 | (b1 << 8), p23 = b2 | (b3 << 8);
+        hist[2 * g] = (uint32_t)p01 | ((uint32_t)(p01 >> 32) << 4);
+        hist[2 * g + 1] = (uint32_t)p23 | ((uint32_t)(p23 >> 32) << 4);
     }
     const unsigned long long tp2 = L.prof ? wall_clock64() : 0ull;
     // end state: first strict minimum scanning 0 -> 15 (Viterbi.h:211-221); state s now sits at position rotr4(s, steps)
