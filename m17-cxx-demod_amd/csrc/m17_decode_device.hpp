@@ -216,28 +216,24 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
-// Lane <-> trellis state mapping of the wave decoder.  A 4-bit "position" p lives in lane bits (5,4,1,0) (bits 3,2 number
-// four identical replicas).  Before step h the metric of state s sits at position rotr4(s, h mod 4); the two predecessors
+// Lane <-> trellis state mapping of the wave decoder.  The 16 states live in lanes 0..15 (one DPP row; the other lanes idle
+// through the trellis loop).  Before step h the metric of state s sits at POSITION rotr4(s, h mod 4); the two predecessors
 // j and j+8 of the new states (2j, 2j+1) then differ in position bit 3 - (h mod 4), and the new states land on the SAME two
-// lanes (in-place butterfly).  So every step needs exactly one lane-bit exchange: lane bit 5 (v_permlane32_swap), 4
-// (v_permlane16_swap), 1 or 0 (DPP quad_perm) for h mod 4 = 0, 1, 2, 3 — register-to-register, no LDS round trip.
-__device__ __forceinline__ int vit_pos_of_lane(int wl) { return (wl & 3) | ((wl >> 2) & 12); }
-__device__ __forceinline__ int vit_lane_of_pos(int p) { return (p & 3) | ((p & 12) << 2); }
+// lanes (in-place butterfly).  Position p sits in lane p ^ (p & 4 ? 3 : 0), which makes every one of the four exchanges a
+// DPP row operation that folds into the add that consumes it: position bit 3 = lane ^ 8 (row_ror:8), bit 2 = lane ^ 7
+// (row_half_mirror), bit 1 = lane ^ 2 and bit 0 = lane ^ 1 (quad_perm) for h mod 4 = 0, 1, 2, 3.
+__device__ __forceinline__ int vit_pos_of_lane(int wl) { return (wl & 15) ^ ((wl & 4) ? 3 : 0); }
+__device__ __forceinline__ int vit_lane_of_pos(int p) { return p ^ ((p & 4) ? 3 : 0); }
 __device__ __forceinline__ int rotl4(int v, int r) { r &= 3; return ((v << r) | (v >> (4 - r))) & 15; }
 __device__ __forceinline__ int rotr4(int v, int r) { return rotl4(v, 4 - (r & 3)); }
 
 template <int R>  // R = h mod 4
-__device__ __forceinline__ int32_t vit_partner(int32_t m, int wl)
+__device__ __forceinline__ int32_t vit_partner(int32_t m)
 {
-    if constexpr (R == 3) return __builtin_amdgcn_update_dpp(m, m, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]: lane ^ 1
-    else if constexpr (R == 2) return __builtin_amdgcn_update_dpp(m, m, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]: lane ^ 2
-    else if constexpr (R == 1) {
-        const auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false);                      // odd rows of [0] <-> even rows of [1]
-        return (wl & 16) ? (int32_t)r[0] : (int32_t)r[1];
-    } else {
-        const auto r = __builtin_amdgcn_permlane32_swap(m, m, false, false);                      // upper half of [0] <-> lower half of [1]
-        return (wl & 32) ? (int32_t)r[0] : (int32_t)r[1];
-    }
+    if constexpr (R == 3) return __builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]: lane ^ 1
+    else if constexpr (R == 2) return __builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]: lane ^ 2
+    else if constexpr (R == 1) return __builtin_amdgcn_update_dpp(0, m, 0x141, 0xF, 0xF, true);  // row_half_mirror: lane ^ 7
+    else return __builtin_amdgcn_update_dpp(0, m, 0x128, 0xF, 0xF, true);                        // row_ror:8: lane ^ 8
 }
 
 // One trellis step.  W (wave-uniform) = the four branch costs of the step, one byte each: (-7,-7) | (-7,+7) << 8 |
@@ -246,24 +242,19 @@ __device__ __forceinline__ int32_t vit_partner(int32_t m, int wl)
 // cost_[j] to its own metric and the complement to its partner's; which of the two sums is "candidate A" depends on
 // whether the lane held state j or j + 8 (`upper`, as a wave mask): dec = A > B, new metric = min (ties: equal values).
 template <int R>
-__device__ __forceinline__ unsigned long long vit_step(uint32_t W, int wl, int32_t& m, uint32_t sh, unsigned long long upper)
+__device__ __forceinline__ uint32_t vit_step(uint32_t W, int wl, int32_t& m, uint32_t sh, unsigned long long upper)
 {
     const int32_t c_own = (int32_t)__builtin_amdgcn_ubfe(W, sh, 8u);
     const int32_t c_oth = (int32_t)__builtin_amdgcn_ubfe(W, 24u - sh, 8u);
-    const int32_t mp = vit_partner<R>(m, wl);
+    const int32_t mp = vit_partner<R>(m);
     const int32_t own = m + c_own, oth = mp + c_oth;
     // decision = (candidate through the lower predecessor) > (the other one): that candidate is `own` on the lane that held
     // state j and `oth` on the lane that held j + 8, and it loses exactly when the minimum differs from it (a tie keeps it)
     const int32_t low = ((upper >> wl) & 1ull) ? oth : own;
     m = min(own, oth);
-    const unsigned long long bal = __ballot(m != low);   // decision of the state now at position p is bit lane_of(p)
-    // replica 0 = lanes 0-3, 16-19, 32-35, 48-51 -> a 16-bit decision set spread over bits 0-7 and 16-23 of a word:
-    // position p sits at bit vit_bit_of_pos(p); the odd step of a pair goes 8 bits higher into the same word
-    // (the trellis loop runs with replica 0's lanes enabled only, so `bal` has no other bits: lanes 0-3, 16-19, 32-35, 48-51)
-    return bal;
+    // (the trellis loop runs with lanes 0..15 enabled only: the ballot is the step's 16 decisions, in LANE order)
+    return (uint32_t)__ballot(m != low);
 }
-// where the decision of the state at position p sits in a step's decision set (see vit_step)
-__device__ __forceinline__ uint32_t vit_bit_of_pos(uint32_t p) { return (p & 3u) | ((p & 8u) >> 1) | ((p & 4u) << 2); }
 
 __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int wl, int kind, int& stale_io)
 {
@@ -315,27 +306,24 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
     const unsigned long long tp1 = L.prof ? wall_clock64() : 0ull;
     const int groups = (steps + 3) >> 2;
     v4u Wn = *reinterpret_cast<const M17_LDS v4u*>(cw);
-    // Four replicas of the 16 states fill the wave; the exchanges (lane ^ 32, ^ 16, ^ 2, ^ 1) stay inside a replica, so the loop
-    // runs on replica 0's lanes alone and a step's ballot IS its decision set.
-    if ((0x000F000F000F000Full >> wl) & 1ull)
+    // the loop runs on the sixteen lanes that hold the states: a step's ballot IS its decision set
+    if (wl < 16)
     for (int g = 0; g < groups; ++g) {
         const v4u W = Wn;
         if (g + 1 < groups) Wn = *reinterpret_cast<const M17_LDS v4u*>(cw + 4 * (g + 1));  // next group in flight
         const int h = 4 * g;
-        const unsigned long long b0 = vit_step<0>(W.x, wl, m, sh[0], upper[0]);
+        const uint32_t b0 = vit_step<0>(W.x, wl, m, sh[0], upper[0]);
         int32_t m1 = m, m2, m3;
-        const unsigned long long b1 = vit_step<1>(W.y, wl, m1, sh[1], upper[1]);
+        const uint32_t b1 = vit_step<1>(W.y, wl, m1, sh[1], upper[1]);
         m2 = m1;
-        const unsigned long long b2 = vit_step<2>(W.z, wl, m2, sh[2], upper[2]);
+        const uint32_t b2 = vit_step<2>(W.z, wl, m2, sh[2], upper[2]);
         m3 = m2;
-        const unsigned long long b3 = vit_step<3>(W.w, wl, m3, sh[3], upper[3]);
+        const uint32_t b3 = vit_step<3>(W.w, wl, m3, sh[3], upper[3]);
         // a trailing partial group computes steps that do not exist: keep the metric of the last real step
         const int left = steps - h;
         m = left >= 4 ? m3 : (left == 3 ? m2 : (left == 2 ? m1 : m));
-        // a 16-bit decision set = the ballot's low word | its high word << 4 (bits 0-7 and 16-23); the odd step of a pair sits 8 bits higher
-        const unsigned long long p01 = b0 | (b1 << 8), p23 = b2 | (b3 << 8);
-        hist[2 * g] = (uint32_t)p01 | ((uint32_t)(p01 >> 32) << 4);
-        hist[2 * g + 1] = (uint32_t)p23 | ((uint32_t)(p23 >> 32) << 4);
+        hist[2 * g] = b0 | (b1 << 16);       // two steps per word, the odd one in the upper half
+        hist[2 * g + 1] = b2 | (b3 << 16);
     }
     const unsigned long long tp2 = L.prof ? wall_clock64() : 0ull;
     // end state: first strict minimum scanning 0 -> 15 (Viterbi.h:211-221); state s now sits at position rotr4(s, steps)
@@ -350,16 +338,22 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
     wave_lds_sync();
     for (int q = wl; q < 8; q += 64) outb[q] = 0;
     // decision words into registers: lane l holds words l and l + 64
-    const uint32_t hw0 = hist[wl];
-    const uint32_t hw1 = (wl + 64 < 122) ? hist[wl + 64] : 0u;
+    // ... and from lane order to position order while they are spread over the lanes: positions 4-7 and 12-15 sit in lanes
+    // p ^ 3, i.e. the odd nibbles of a decision set are bit-reversed
+    auto to_pos_order = [](uint32_t x) -> uint32_t {
+        const uint32_t odd = x & 0xF0F0F0F0u;
+        return (x & 0x0F0F0F0Fu) | ((odd & 0x10101010u) << 3) | ((odd & 0x20202020u) << 1) | ((odd >> 1) & 0x20202020u) | ((odd >> 3) & 0x10101010u);
+    };
+    const uint32_t hw0 = to_pos_order(hist[wl]);
+    const uint32_t hw1 = to_pos_order((wl + 64 < 122) ? hist[wl + 64] : 0u);
     wave_lds_sync();
     // chainback (Viterbi.h:226-236) fused with to_byte_array (Util.h:300-318); everything here is wave-uniform (scalar
     // registers).  It walks in POSITION space: the current state after step hi sits at position P = rotr4(state, hi + 1).
     // State bit 0 (the decoded bit) is position bit k = -(hi + 1) mod 4, and stepping back to (state >> 1) + 8 v replaces
-    // exactly that position bit by the decision v — no rotation per step.  The walk keeps I = vit_bit_of_pos(P), the bit
-    // index of P's decision inside a decision set; position bit k is bit KB[k] = {0, 1, 4, 2}[k] of I.
+    // exactly that position bit by the decision v — no rotation per step.  The walk keeps I = P, which is also the bit index
+    // of P's decision inside a (position-ordered) decision set.
     // The first steps - OUT (= 4) steps are the flush bits and decode nothing.
-    uint32_t I = (uint32_t)__builtin_amdgcn_readfirstlane((int)vit_bit_of_pos((uint32_t)rotr4(best, steps)));
+    uint32_t I = (uint32_t)__builtin_amdgcn_readfirstlane(rotr4(best, steps));
     uint32_t w = 0;   // decoded bits of the current 32-bit group, newest in bit 0: bit q of the group ends at position q
     int o = OUT;
     auto fetch = [&](int hi) -> uint32_t {
@@ -373,18 +367,18 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
     for (int n = 4 + (steps & 3); n > 0; --n, --hi) {  // generic steps down to a multiple of four
         const uint32_t hw = fetch(hi);
         const uint32_t k = (uint32_t)(~hi) & 3u;
-        const uint32_t kb = (0x2410u >> (4u * k)) & 15u;
-        const uint32_t v = (hw >> (I + ((uint32_t)(hi & 1) << 3))) & 1u;  // the decision taken when this state was entered at step hi
+        const uint32_t kb = k;
+        const uint32_t v = (hw >> (I + ((uint32_t)(hi & 1) << 4))) & 1u;  // the decision taken when this state was entered at step hi
         if (hi < OUT) { --o; w = (w << 1) | ((I >> kb) & 1u); flush(); }
         I = (I & ~(1u << kb)) | (v << kb);
     }
     for (; hi >= 3; hi -= 4) {   // hi = 3 (mod 4): k = 0, 1, 2, 3 with constant bit numbers
         const uint32_t ha = fetch(hi), hb = fetch(hi - 2);
         uint32_t v;
-        v = (ha >> (I + 8u)) & 1u; w = (w << 1) | (I & 1u);          I = (I & ~1u) | v;           // step hi     (odd)
-        v = (ha >> I) & 1u;        w = (w << 1) | ((I >> 1) & 1u);   I = (I & ~2u) | (v << 1);    // step hi - 1 (even)
-        v = (hb >> (I + 8u)) & 1u; w = (w << 1) | ((I >> 4) & 1u);   I = (I & ~16u) | (v << 4);   // step hi - 2
-        v = (hb >> I) & 1u;        w = (w << 1) | ((I >> 2) & 1u);   I = (I & ~4u) | (v << 2);    // step hi - 3
+        v = (ha >> (I + 16u)) & 1u; w = (w << 1) | (I & 1u);          I = (I & ~1u) | v;           // step hi     (odd)
+        v = (ha >> I) & 1u;         w = (w << 1) | ((I >> 1) & 1u);   I = (I & ~2u) | (v << 1);    // step hi - 1 (even)
+        v = (hb >> (I + 16u)) & 1u; w = (w << 1) | ((I >> 2) & 1u);   I = (I & ~4u) | (v << 2);    // step hi - 2
+        v = (hb >> I) & 1u;         w = (w << 1) | ((I >> 3) & 1u);   I = (I & ~8u) | (v << 3);    // step hi - 3
         o -= 4;
         flush();
     }
