@@ -337,50 +337,50 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
     const uint32_t cost = (uint32_t)roundf((float)best_cost / 7.0f);
     wave_lds_sync();
     for (int q = wl; q < 8; q += 64) outb[q] = 0;
-    // decision words into registers: lane l holds words l and l + 64
+    // decision words into registers
     // ... and from lane order to position order while they are spread over the lanes: positions 4-7 and 12-15 sit in lanes
     // p ^ 3, i.e. the odd nibbles of a decision set are bit-reversed
     auto to_pos_order = [](uint32_t x) -> uint32_t {
         const uint32_t odd = x & 0xF0F0F0F0u;
         return (x & 0x0F0F0F0Fu) | ((odd & 0x10101010u) << 3) | ((odd & 0x20202020u) << 1) | ((odd >> 1) & 0x20202020u) | ((odd >> 3) & 0x10101010u);
     };
-    const uint32_t hw0 = to_pos_order(hist[wl]);
-    const uint32_t hw1 = to_pos_order((wl + 64 < 122) ? hist[wl + 64] : 0u);
+    // lane l holds the words of steps 4l .. 4l + 3: hwA = steps 4l, 4l + 1; hwB = steps 4l + 2, 4l + 3 (122 words -> 61 lanes)
+    const uint32_t hwA = to_pos_order((wl < 61) ? hist[2 * wl] : 0u);
+    const uint32_t hwB = to_pos_order((wl < 61) ? hist[2 * wl + 1] : 0u);
     wave_lds_sync();
     // chainback (Viterbi.h:226-236) fused with to_byte_array (Util.h:300-318); everything here is wave-uniform (scalar
     // registers).  It walks in POSITION space: the current state after step hi sits at position P = rotr4(state, hi + 1).
     // State bit 0 (the decoded bit) is position bit k = -(hi + 1) mod 4, and stepping back to (state >> 1) + 8 v replaces
     // exactly that position bit by the decision v — no rotation per step.  The walk keeps I = P, which is also the bit index
-    // of P's decision inside a (position-ordered) decision set.
-    // The first steps - OUT (= 4) steps are the flush bits and decode nothing.
+    // of P's decision inside a (position-ordered) decision set.  The bit a step decodes is the one written into that position
+    // four steps earlier: message bit n IS the decision read at step n + 4, so the output is the decision stream itself and
+    // the walk ends at step 4 (the first steps - OUT = 4 steps of the walk are the flush bits: nothing is decoded from them).
     uint32_t I = (uint32_t)__builtin_amdgcn_readfirstlane(rotr4(best, steps));
     uint32_t w = 0;   // decoded bits of the current 32-bit group, newest in bit 0: bit q of the group ends at position q
-    int o = OUT;
-    auto fetch = [&](int hi) -> uint32_t {
-        const int wi = hi >> 1;
-        return (wi < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)hw0, wi) : (uint32_t)__builtin_amdgcn_readlane((int)hw1, wi - 64);
+    auto fetch = [&](int hi) -> uint32_t {   // the word that holds step hi
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)hwA, hi >> 2), b = (uint32_t)__builtin_amdgcn_readlane((int)hwB, hi >> 2);
+        return (hi & 2) ? b : a;
     };
-    auto flush = [&] {   // message bit n -> byte n >> 3, bit 7 - (n & 7); four bytes per little-endian word
-        if ((o & 31) == 0) { outb[o >> 5] = __builtin_bswap32(__builtin_bitreverse32(w)); w = 0; }
+    auto flush = [&](int n) {   // message bit n -> byte n >> 3, bit 7 - (n & 7); four bytes per little-endian word
+        if ((n & 31) == 0) { outb[n >> 5] = __builtin_bswap32(__builtin_bitreverse32(w)); w = 0; }
     };
     int hi = steps - 1;
-    for (int n = 4 + (steps & 3); n > 0; --n, --hi) {  // generic steps down to a multiple of four
+    for (; (hi & 3) != 3; --hi) {  // generic steps down to hi = 3 (mod 4)
         const uint32_t hw = fetch(hi);
         const uint32_t k = (uint32_t)(~hi) & 3u;
-        const uint32_t kb = k;
         const uint32_t v = (hw >> (I + ((uint32_t)(hi & 1) << 4))) & 1u;  // the decision taken when this state was entered at step hi
-        if (hi < OUT) { --o; w = (w << 1) | ((I >> kb) & 1u); flush(); }
-        I = (I & ~(1u << kb)) | (v << kb);
+        w = (w << 1) | v;
+        flush(hi - 4);
+        I = (I & ~(1u << k)) | (v << k);
     }
-    for (; hi >= 3; hi -= 4) {   // hi = 3 (mod 4): k = 0, 1, 2, 3 with constant bit numbers
-        const uint32_t ha = fetch(hi), hb = fetch(hi - 2);
+    for (; hi >= 7; hi -= 4) {   // hi = 3 (mod 4): k = 0, 1, 2, 3
+        const uint32_t ha = (uint32_t)__builtin_amdgcn_readlane((int)hwB, hi >> 2), hb = (uint32_t)__builtin_amdgcn_readlane((int)hwA, hi >> 2);
         uint32_t v;
-        v = (ha >> (I + 16u)) & 1u; w = (w << 1) | (I & 1u);          I = (I & ~1u) | v;           // step hi     (odd)
-        v = (ha >> I) & 1u;         w = (w << 1) | ((I >> 1) & 1u);   I = (I & ~2u) | (v << 1);    // step hi - 1 (even)
-        v = (hb >> (I + 16u)) & 1u; w = (w << 1) | ((I >> 2) & 1u);   I = (I & ~4u) | (v << 2);    // step hi - 2
-        v = (hb >> I) & 1u;         w = (w << 1) | ((I >> 3) & 1u);   I = (I & ~8u) | (v << 3);    // step hi - 3
-        o -= 4;
-        flush();
+        v = (ha >> (I + 16u)) & 1u; w = (w << 1) | v; I = (I & ~1u) | v;          // step hi     (odd)
+        v = (ha >> I) & 1u;         w = (w << 1) | v; I = (I & ~2u) | (v << 1);   // step hi - 1 (even)
+        v = (hb >> (I + 16u)) & 1u; w = (w << 1) | v; I = (I & ~4u) | (v << 2);   // step hi - 2
+        v = (hb >> I) & 1u;         w = (w << 1) | v; I = (I & ~8u) | (v << 3);   // step hi - 3
+        flush(hi - 7);
     }
     wave_lds_sync();
     if (L.prof && wl == 0) {
