@@ -337,50 +337,64 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
     const uint32_t cost = (uint32_t)roundf((float)best_cost / 7.0f);
     wave_lds_sync();
     for (int q = wl; q < 8; q += 64) outb[q] = 0;
-    // decision words into registers
-    // ... and from lane order to position order while they are spread over the lanes: positions 4-7 and 12-15 sit in lanes
-    // p ^ 3, i.e. the odd nibbles of a decision set are bit-reversed
-    auto to_pos_order = [](uint32_t x) -> uint32_t {
-        const uint32_t odd = x & 0xF0F0F0F0u;
-        return (x & 0x0F0F0F0Fu) | ((odd & 0x10101010u) << 3) | ((odd & 0x20202020u) << 1) | ((odd >> 1) & 0x20202020u) | ((odd >> 3) & 0x10101010u);
-    };
-    // lane l holds the words of steps 4l .. 4l + 3: hwA = steps 4l, 4l + 1; hwB = steps 4l + 2, 4l + 3 (122 words -> 61 lanes)
-    const uint32_t hwA = to_pos_order((wl < 61) ? hist[2 * wl] : 0u);
-    const uint32_t hwB = to_pos_order((wl < 61) ? hist[2 * wl + 1] : 0u);
-    wave_lds_sync();
-    // chainback (Viterbi.h:226-236) fused with to_byte_array (Util.h:300-318); everything here is wave-uniform (scalar
-    // registers).  It walks in POSITION space: the current state after step hi sits at position P = rotr4(state, hi + 1).
-    // State bit 0 (the decoded bit) is position bit k = -(hi + 1) mod 4, and stepping back to (state >> 1) + 8 v replaces
-    // exactly that position bit by the decision v — no rotation per step.  The walk keeps I = P, which is also the bit index
-    // of P's decision inside a (position-ordered) decision set.  The bit a step decodes is the one written into that position
-    // four steps earlier: message bit n IS the decision read at step n + 4, so the output is the decision stream itself and
-    // the walk ends at step 4 (the first steps - OUT = 4 steps of the walk are the flush bits: nothing is decoded from them).
-    uint32_t I = (uint32_t)__builtin_amdgcn_readfirstlane(rotr4(best, steps));
-    uint32_t w = 0;   // decoded bits of the current 32-bit group, newest in bit 0: bit q of the group ends at position q
-    auto fetch = [&](int hi) -> uint32_t {   // the word that holds step hi
-        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)hwA, hi >> 2), b = (uint32_t)__builtin_amdgcn_readlane((int)hwB, hi >> 2);
-        return (hi & 2) ? b : a;
-    };
-    auto flush = [&](int n) {   // message bit n -> byte n >> 3, bit 7 - (n & 7); four bytes per little-endian word
-        if ((n & 31) == 0) { outb[n >> 5] = __builtin_bswap32(__builtin_bitreverse32(w)); w = 0; }
-    };
-    int hi = steps - 1;
-    for (; (hi & 3) != 3; --hi) {  // generic steps down to hi = 3 (mod 4)
-        const uint32_t hw = fetch(hi);
-        const uint32_t k = (uint32_t)(~hi) & 3u;
-        const uint32_t v = (hw >> (I + ((uint32_t)(hi & 1) << 4))) & 1u;  // the decision taken when this state was entered at step hi
-        w = (w << 1) | v;
-        flush(hi - 4);
-        I = (I & ~(1u << k)) | (v << k);
+    // ---- chainback (Viterbi.h:226-236) fused with to_byte_array (Util.h:300-318), lane-parallel ---------------------------
+    // The walk goes in POSITION space: the current state after step hi sits at position P = rotr4(state, hi + 1).  State bit 0
+    // (the decoded bit) is position bit k = -(hi + 1) mod 4, and stepping back to (state >> 1) + 8 v replaces exactly that
+    // position bit by the decision v — no rotation per step; P is also the bit index of its own decision inside a
+    // (position-ordered) decision set.  The bit a step decodes is the one written into that position four steps earlier:
+    // message bit n IS the decision read at step n + 4, so the output is the decision stream itself.
+    // A walk of up to 240 dependent steps is cut into four blocks of 64 message bits; lane (b, e) walks block b from the
+    // hypothetical entry position e (16 x 4 = 64 lanes, all blocks in lock step: 64 = 0 mod 4, so k and the odd/even half are
+    // the same for every block), keeping the position it ends in and the 64 bits it decoded.  Chaining the four blocks is then
+    // four lane reads.  Steps beyond the real ones (a partly filled or empty top block) get NEUTRAL decision sets — bit p =
+    // position bit k of p — that leave the position unchanged.
+    // Decision words: lane order -> position order (positions 4-7 and 12-15 sit in lanes p ^ 3, i.e. the odd nibbles of a set
+    // are bit-reversed), neutral words behind them; into the cost-word array, which the trellis no longer needs.
+    {
+        auto to_pos_order = [](uint32_t x) -> uint32_t {
+            const uint32_t odd = x & 0xF0F0F0F0u;
+            return (x & 0x0F0F0F0Fu) | ((odd & 0x10101010u) << 3) | ((odd & 0x20202020u) << 1) | ((odd >> 1) & 0x20202020u) | ((odd >> 3) & 0x10101010u);
+        };
+        const int nreal = (steps + 1) >> 1;
+        for (int q = wl; q < 130; q += 64) {
+            const uint32_t neutral = (q & 1) ? 0xAAAACCCCu : 0xF0F0FF00u;   // steps 2q (k = 3 or 1) and 2q + 1 (k = 2 or 0)
+            uint32_t x = neutral;
+            if (q < nreal) {
+                x = to_pos_order(hist[q]);
+                if (2 * q + 1 >= steps) x = (x & 0xFFFFu) | (neutral & 0xFFFF0000u);   // odd step count: the upper half is not a step
+            }
+            cw[q] = x;
+        }
     }
-    for (; hi >= 7; hi -= 4) {   // hi = 3 (mod 4): k = 0, 1, 2, 3
-        const uint32_t ha = (uint32_t)__builtin_amdgcn_readlane((int)hwB, hi >> 2), hb = (uint32_t)__builtin_amdgcn_readlane((int)hwA, hi >> 2);
-        uint32_t v;
-        v = (ha >> (I + 16u)) & 1u; w = (w << 1) | v; I = (I & ~1u) | v;          // step hi     (odd)
-        v = (ha >> I) & 1u;         w = (w << 1) | v; I = (I & ~2u) | (v << 1);   // step hi - 1 (even)
-        v = (hb >> (I + 16u)) & 1u; w = (w << 1) | v; I = (I & ~4u) | (v << 2);   // step hi - 2
-        v = (hb >> I) & 1u;         w = (w << 1) | v; I = (I & ~8u) | (v << 3);   // step hi - 3
-        flush(hi - 7);
+    wave_lds_sync();
+    uint32_t I = (uint32_t)wl & 15u, w = 0, w_hi = 0;
+    {
+        // block b = wl >> 4 decodes message bits 64 b + 63 .. 64 b, i.e. steps hi = 64 b + 67 .. 64 b + 4: words 32 b + 33 .. 32 b + 2
+        const M17_LDS uint32_t* hp = cw + 32 * (wl >> 4) + 2;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {   // four steps: hi = 3, 2, 1, 0 (mod 4) -> k = 0, 1, 2, 3
+            const uint32_t wa = hp[31 - 2 * g], wb = hp[30 - 2 * g];
+            uint32_t v;
+            v = __builtin_amdgcn_ubfe(wa, I + 16u, 1u); w = (w << 1) | v; I = (I & ~1u) | v;
+            v = __builtin_amdgcn_ubfe(wa, I, 1u);       w = (w << 1) | v; I = (I & ~2u) | (v << 1);
+            v = __builtin_amdgcn_ubfe(wb, I + 16u, 1u); w = (w << 1) | v; I = (I & ~4u) | (v << 2);
+            v = __builtin_amdgcn_ubfe(wb, I, 1u);       w = (w << 1) | v; I = (I & ~8u) | (v << 3);
+            if (g == 7) { w_hi = w; w = 0; }
+        }
+    }
+    // chain the blocks from the top: the walk enters block 3 at the position of the best end state
+    {
+        uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane(rotr4(best, steps));
+#pragma unroll
+        for (int b = 3; b >= 0; --b) {
+            const int lane = 16 * b + (int)e;
+            const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)w_hi, lane), lo32 = (uint32_t)__builtin_amdgcn_readlane((int)w, lane);
+            e = (uint32_t)__builtin_amdgcn_readlane((int)I, lane);
+            // message bit n -> byte n >> 3, bit 7 - (n & 7); four bytes per little-endian word; bits at and beyond OUT stay zero
+            const int nh = OUT - (64 * b + 32), nl = OUT - 64 * b;
+            if (nh > 0) outb[2 * b + 1] = __builtin_bswap32(__builtin_bitreverse32(nh >= 32 ? hi32 : (hi32 & ((1u << nh) - 1u))));
+            if (nl > 0) outb[2 * b] = __builtin_bswap32(__builtin_bitreverse32(nl >= 32 ? lo32 : (lo32 & ((1u << nl) - 1u))));
+        }
     }
     wave_lds_sync();
     if (L.prof && wl == 0) {
