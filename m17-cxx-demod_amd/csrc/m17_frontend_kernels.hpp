@@ -244,14 +244,19 @@ __device__ __forceinline__ void dcd_step(DcdLane& s, float delta)
 }
 
 // pos0: absolute index (since reset) of the first sample of this run — identical for every channel.
-__global__ __launch_bounds__(64) void dcd_kernel(const int16_t* __restrict__ x, size_t xpitch, DcdState* __restrict__ state,
+// DCD_WPB independent waves per workgroup: a workgroup's waves land on one CU, one per SIMD, so the 128 lone waves of a
+// 4096-channel launch take a wave slot on every SIMD of 32 CUs instead of one SIMD on each of 128 CUs — K5 (whose workgroups
+// need a slot on all four SIMDs of a CU) then loses 32 workgroup slots to K3 instead of 128, K1 likewise.
+constexpr int DCD_WPB = 4;
+__global__ __launch_bounds__(64 * DCD_WPB) void dcd_kernel(const int16_t* __restrict__ x, size_t xpitch, DcdState* __restrict__ state,
                                                  float* __restrict__ table, uint32_t ticks_cap, uint32_t C, uint32_t T,
                                                  uint64_t pos0, DcdCoef k, uint32_t flags)
 {
-    __shared__ __attribute__((aligned(16))) float dl[DCD_CPW][DCD_PITCH];
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float dl_all[DCD_WPB][DCD_CPW][DCD_PITCH];
+    float (*dl)[DCD_PITCH] = dl_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
     const int g = lane >> 1, bin = lane & 1;
-    uint32_t c = blockIdx.x * DCD_CPW + g;
+    uint32_t c = (blockIdx.x * DCD_WPB + (threadIdx.x >> 6)) * DCD_CPW + g;
     const bool live = c < C;   // lanes beyond the last channel shadow it and never store
     if (!live) c = C - 1;
     const bool invert = flags & 1u;

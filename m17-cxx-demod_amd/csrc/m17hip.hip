@@ -474,7 +474,7 @@ int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_
     Timed tm(c, KT_DCD, st);
     // table rows are numbered from the first tick of the RUN: a later segment continues where the previous one stopped
     const uint64_t row0 = (c->pos + t0) / TICK - c->pos / TICK;
-    hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW - 1) / DCD_CPW), dim3(64), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+    hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW * DCD_WPB - 1) / (DCD_CPW * DCD_WPB)), dim3(64 * DCD_WPB), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
                        c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
