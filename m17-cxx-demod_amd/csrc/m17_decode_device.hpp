@@ -205,9 +205,10 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
 }
 
 // Wave-cooperative form of the same decoder (one frame per WAVE; used by the one-wave-per-channel demodulator, where
-// a frame completes on one channel at a time): lane l owns trellis state l & 15 (the four 16-lane groups compute the
-// same thing), the 16 decision bits of a step are one ballot, and the add-compare-select exchanges metrics between lanes
-// with register-to-register lane swaps (see below).  Columns have stride 1 here (per-wave LDS arrays).  `wl` = lane id in the wave.
+// a frame completes on one channel at a time): sixteen lanes hold the sixteen trellis states, the 16 decision bits of a step
+// are one ballot, the add-compare-select exchanges metrics between lanes with DPP row operations (see below), and the
+// chainback walks four blocks x sixteen hypothetical entry states on all 64 lanes.  Columns have stride 1 here (per-wave
+// LDS arrays).  `wl` = lane id in the wave.
 // LDS-only ordering between the lanes of one wave: the fences are restricted to the local address space so that global
 // loads in flight (window prefetches) are NOT waited for here.
 __device__ __forceinline__ void wave_lds_sync()
