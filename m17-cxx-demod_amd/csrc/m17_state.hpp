@@ -150,7 +150,7 @@ __device__ __forceinline__ uint32_t slice_llr(float sample, const float* edges)
     const float e0 = edges[n - 1], e1 = edges[n], e2 = edges[n + 1];
     // edges are strictly increasing; the guess is within one row of the answer
     if (e0 >= cl) n = n - 1;
-    else if (e1 >= cl) n = n;
+    else if (e1 >= cl) { /* the guess is the row */ }
     else if (e2 >= cl) n = n + 1;
     else n = n + 2;
     int li, lj;  // Util.h:63-104: i falls 7..1,-1..-7 over rows 14..27, j falls over rows 0..13 and rises over 28..41
