@@ -198,9 +198,29 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // 64-sample LDS window (the e2 array, idle outside payload chunks); otherwise from the filter K5 carries itself.
     int32_t hw_base = 0x40000000;  // first hbuf index held in the window (invalid)
     uint32_t cur_tt = 0;           // index of the newest fed sample (single-sample path)
+    // The filter history the sync-word window of a *_SYNC state will need (sync_count 77 .. 86 and the single-sample step that
+    // follows) is known 77 samples ahead: fetched from hbuf straight into LDS (global_load_lds) when the quiet stretch before the
+    // window starts, so that neither the window chunk nor the step waits for HBM.  hpf[k] = hbuf[hpf_base + k]; the buffer sits
+    // in the decoder's cost-word array (idle between frames; every decode invalidates it).
+    float* hpf = reinterpret_cast<float*>(DL.soft) + 240;
+    int32_t hpf_base = -0x40000000;
+    bool hpf_wait = false;
+    auto hpf_issue = [&](int32_t base) {
+        const int64_t i = min((int64_t)base + wl, (int64_t)P.T - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hrow + i), (__attribute__((address_space(3))) void*)hpf, 4, 0, 0);
+        hpf_base = base;
+        hpf_wait = true;
+    };
+    auto hpf_ready = [&] {
+        if (hpf_wait) { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); hpf_wait = false; }   // vmcnt(0)
+    };
     auto cur_lim = [&]() -> float {
         if (!s.spec_ok) return iir_output(s.h0, s.h1, s.h2);
         const int32_t tt = (int32_t)cur_tt;
+        {
+            const int32_t o2 = tt - hpf_base;
+            if (o2 >= 2 && o2 < 64) { hpf_ready(); return iir_output(hpf[o2], hpf[o2 - 1], hpf[o2 - 2]); }
+        }
         if (tt - 2 < hw_base || tt >= hw_base + 64) {
             hw_base = tt - 2;
             const int64_t i = (int64_t)hw_base + wl;
@@ -396,7 +416,13 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 if (s.need_clock_reset | s.need_clock_update) lim = min(lim, 10u - idx0);  // stop before the next index-0 sample
                 const bool is_sync = s.st == ST_STREAM_SYNC || s.st == ST_PACKET_SYNC || s.st == ST_BERT_SYNC;
                 if (is_sync) {
-                    if (s.sync_count < 77) { n = min((uint32_t)(77 - s.sync_count), lim); mode = BULK_QUIET; }
+                    if (s.sync_count < 77) {
+                        n = min((uint32_t)(77 - s.sync_count), lim); mode = BULK_QUIET;
+                        if (s.spec_ok) {
+                            const int32_t target = (int32_t)t + (77 - (int32_t)s.sync_count) - 3;
+                            if (hpf_base != target) hpf_issue(target);
+                        }
+                    }
                     else if (s.sync_count < 86) {   // the window where the next sync word is looked for (:420-574), up to the sample
                         n = min(min(10u, (uint32_t)(86 - s.sync_count)), lim);   // before its trigger falls / EOT / the count runs out
                         mode = BULK_SYNCWIN;
@@ -461,7 +487,13 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             for (uint32_t k = wl; k < 80u; k += 64) W[k] = ring[(s.prev_pos + 1u + k) % 80u];   // oldest first
             if (wl < n) W[80u + wl] = ywin[(t + wl) & (WV_WIN - 1)];
             if (s.spec_ok) {   // the trajectory is in hbuf: hb[k] = history after sample t - 3 + k
-                for (uint32_t k = wl; k < n + 3u; k += 64) hb[k] = hrow[(int64_t)t - 3 + k];
+                const int32_t off = (int32_t)t - 3 - hpf_base;
+                if (off >= 0 && off + (int32_t)n + 3 <= 64) {   // ... and already in LDS
+                    hpf_ready();
+                    for (uint32_t k = wl; k < n + 3u; k += 64) hb[k] = hpf[off + (int32_t)k];
+                } else {
+                    for (uint32_t k = wl; k < n + 3u; k += 64) hb[k] = hrow[(int64_t)t - 3 + k];
+                }
             } else {
                 float h0 = s.h0, h1 = s.h1;
                 float m2 = IirCoef::a2 * h1;
@@ -782,6 +814,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         // ---- common tail: frame decode and the carrier-on update point ----------------------------------------------------
         if (decode_due) {  // decoder(...) and the rest of do_frame (:619-642)
             const unsigned long long d0 = now();
+            hpf_ready(); hpf_base = -0x40000000;   // the decoder takes the cost-word array
             const uint2 r = nf_decode_wave(P.tables, DL, wl, s.sync_word_type, cd, s.viterbi_cost, rec_base, P.rec_cap, c, P.pos0 + te, P.overflow);
             s.viterbi_cost = r.x;
             s.st = (r.y == 1u || r.y == 0u) ? ST_STREAM_SYNC : (r.y == 4u ? ST_BERT_SYNC : ST_PACKET_SYNC);
