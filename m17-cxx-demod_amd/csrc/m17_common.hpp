@@ -41,6 +41,23 @@ __device__ __forceinline__ float scale_sample(int s, bool invert)
 }
 
 // Sync words M17Demodulator.h:154-157: preamble, LSF(/stream), packet(/BERT), EOT — symbol signs (x3).
+// The same words as sign masks (bit i set = symbol i is -3): (float)(-3) * x == -(3.0f * x) exactly, and r + (-p) is what
+// r - p computes, so a correlation is eight multiplies by the literal 3.0f and eight adds / subtracts — no coefficient table
+// to keep in registers (the sequential kernel used to spill the 32 converted coefficients to scratch and reload them at every use).
+constexpr uint32_t SYNC_NEG[4] = {0xAAu, 0xB0u, 0xF2u, 0x40u};
+// Correlator::correlate (Correlator.h:51-64) for word w over r[0..7] (oldest symbol first)
+__device__ __forceinline__ float sync_correlate(int w, const float (&r)[8])
+{
+    const uint32_t neg = w == 0 ? SYNC_NEG[0] : (w == 1 ? SYNC_NEG[1] : (w == 2 ? SYNC_NEG[2] : SYNC_NEG[3]));
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float p = 3.0f * r[i];
+        const float q = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, p) ^ (((neg >> i) & 1u) << 31));
+        v = v + q;
+    }
+    return v;
+}
 __device__ __constant__ const int8_t SYNC_WORDS[4][8] = {{+3, -3, +3, -3, +3, -3, +3, -3},
                                                           {+3, +3, +3, +3, -3, -3, +3, -3},
                                                           {+3, -3, +3, +3, -3, -3, -3, -3},

@@ -186,13 +186,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         }
     };
     auto correlate = [&](int w) -> float {  // Correlator.h:51-64: oldest symbol first
-        float r = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float prod = (float)SYNC_WORDS[w][i] * r8[i];
-            r = r + prod;
-        }
-        return r;
+        return sync_correlate(w, r8);
     };
     // Correlator::limit() after the newest sample `tt` was fed.  While the run trusts K2 the history comes from hbuf through a
     // 64-sample LDS window (the e2 array, idle outside payload chunks); otherwise from the filter K5 carries itself.
@@ -515,12 +509,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 float r[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) r[i] = W[10u + wl + 10u * i];   // samples k-70, k-60, ..., k
-                auto corr = [&](int w_) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { const float p = (float)SYNC_WORDS[w_][i] * r[i]; v = v + p; }
-                    return v;
-                };
+                auto corr = [&](int w_) { return sync_correlate(w_, r); };
                 auto beyond = [&](int w_, float v) { return v > lim_k * SW_MAG1[w_] || v < lim_k * SW_MAG2[w_]; };
                 if (mode == BULK_SEARCH) {
                     hit = phase_a ? beyond(0, corr(0)) : (beyond(1, corr(1)) || beyond(2, corr(2)));
