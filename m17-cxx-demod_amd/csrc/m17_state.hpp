@@ -233,7 +233,7 @@ __device__ __noinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32_t 
     return o;
 }
 // DataCarrierDetect::update (:63-69) with the sums K3 produced for the segment [seg_start_tick, k]; returns the trigger.
-__device__ __noinline__ uint32_t nf_dcd_update(M17_LDS Cold* cd, const float* tab, uint64_t tick0, uint64_t k, uint32_t trig)
+__device__ __forceinline__ uint32_t nf_dcd_update(M17_LDS Cold* cd, const float* tab, uint64_t tick0, uint64_t k, uint32_t trig)
 {
     const float* row = tab + (size_t)(k - tick0) * 12;
     const uint32_t span = (uint32_t)(k + 1 - cd->seg_start_tick);
@@ -245,7 +245,7 @@ __device__ __noinline__ uint32_t nf_dcd_update(M17_LDS Cold* cd, const float* ta
     return trig ? (level > 0.1f) : (level > 4.0f);
 }
 // arguments of the diagnostic callback (M17Demodulator.h:681-685, 746-750)
-__device__ __noinline__ void nf_fire_diag(M17_LDS Cold* cd, uint32_t dcd_on, float evm_arg, float idev, float offset, uint32_t locked, float clock,
+__device__ __forceinline__ void nf_fire_diag(M17_LDS Cold* cd, uint32_t dcd_on, float evm_arg, float idev, float offset, uint32_t locked, float clock,
                                           uint32_t sample_index, uint32_t sync_index, int32_t clock_index, uint32_t vcost)
 {
     Diag d = lds_get(&cd->diag);
