@@ -184,7 +184,7 @@ __device__ __forceinline__ int32_t clock_predict(float sample_est, float clock_e
 // ---- out-of-line helpers on COLD state ------------------------------------------------------------------------------
 // M17Demodulator::update_values (:233-241) = Correlator::outer_symbol_levels (Correlator.h:81-114) +
 // FreqDevEstimator::update (FreqDevEstimator.h:31-48).  Returns (idev, offset).
-__device__ __noinline__ float2 nf_update_values(M17_LDS Cold* cd, const float* ring, int stride, int lane, uint32_t si)
+__device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float* ring, int stride, int lane, uint32_t si)
 {
     float min_sum = 0.f, max_sum = 0.f;
     uint32_t min_count = 0, max_count = 0;
@@ -223,7 +223,7 @@ __device__ __noinline__ float2 nf_update_values(M17_LDS Cold* cd, const float* r
 }
 struct ClockOut { float sample_est, clock_est; int32_t sample_index; };
 // ClockRecovery::update(uint8_t) (ClockRecovery.h:54-67)
-__device__ __noinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32_t index, uint32_t ck_count)
+__device__ __forceinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32_t index, uint32_t ck_count)
 {
     kal_update(&cd->ck, (float)index, ck_count, 10);
     ClockOut o;
