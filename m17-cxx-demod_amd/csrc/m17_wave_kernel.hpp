@@ -681,6 +681,11 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         if (corr_index() == 0 && flags_t != tt) clock_flags();   // (once per index-0 sample: a pending reset AND update take two of them)
         s.ck_count++;
         if (s.st <= ST_BERT_SYNC && !(s.st >= ST_STREAM_SYNC && s.sync_count + 1 < 78)) load_r8();  // states that correlate
+        // update_values (M17Demodulator.h:233-241) is requested from seven places below and done once behind the switch (nothing
+        // in between reads what it writes; where two requests meet in one sample — both words of do_unlocked — each resets the
+        // deviation estimator first, so the later one decides alone)
+        bool upd_pending = false;
+        uint32_t upd_index = 0;
         switch (s.st) {
         case ST_UNLOCKED: {  // do_unlocked :289-342
             if (s.missing_sync_count < 1920) {
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 const uint32_t si = sw_step(0);
                 if (sw_updated(0)) {
                     s.sync_count = 0; s.missing_sync_count = 0; s.need_clock_reset = 1;
-                    dev_reset(); s.sample_index = si; update_values(si);
+                    dev_reset(); s.sample_index = si; upd_pending = true; upd_index = si;
                     s.st = ST_LSF_SYNC;
                 }
                 break;
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             int32_t up = sw_updated(1);
             if (up) {
                 s.sync_count = 86; s.missing_sync_count = 0; s.need_clock_reset = 1;
-                dev_reset(); s.sample_index = si; update_values(si);
+                dev_reset(); s.sample_index = si; upd_pending = true; upd_index = si;
                 s.st = ST_FRAME;
                 s.sync_word_type = up < 0 ? 1u : 0u;
             }
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             up = sw_updated(2);
             if (up < 0) {
                 s.sync_count = 86; s.missing_sync_count = 0; s.need_clock_reset = 1;
-                dev_reset(); s.sample_index = si; update_values(si);
+                dev_reset(); s.sample_index = si; upd_pending = true; upd_index = si;
                 s.st = ST_FRAME;
                 s.sync_word_type = 3u;
             }
@@ -719,16 +724,16 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             const float bert_triggered = sw_triggered(2);
             if (bert_triggered < 0.f) {
                 s.missing_sync_count = 0; s.sync_count = 86; s.need_clock_update = 1;
-                update_values(s.sample_index); s.st = ST_FRAME; s.sync_word_type = 3u;
+                upd_pending = true; upd_index = s.sample_index; s.st = ST_FRAME; s.sync_word_type = 3u;
             } else if ((double)fabsf(sync_triggered) > 0.1) {
                 s.missing_sync_count = 0; s.sync_count = 86; s.need_clock_update = 1;
-                update_values(s.sample_index); s.st = ST_FRAME;
+                upd_pending = true; upd_index = s.sample_index; s.st = ST_FRAME;
                 s.sync_word_type = sync_triggered > 0.f ? 0u : 1u;
             } else if (++s.missing_sync_count > 192) {
                 if (s.sync_count >= 10) { s.missing_sync_count = 0; s.need_clock_update = 1; }
                 else { s.sync_count = 0; s.st = ST_UNLOCKED; s.missing_sync_count = 0; if (s.dcd_trig) despec(tt); s.dcd_trig = 0; }
             } else {
-                update_values(s.sample_index);
+                upd_pending = true; upd_index = s.sample_index;
             }
             break;
         }
@@ -749,7 +754,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             const bool hit = (mode_st == ST_PACKET_SYNC) ? (up != 0) : (up < 0);
             const uint32_t swt = (mode_st == ST_STREAM_SYNC) ? 1u : (mode_st == ST_PACKET_SYNC ? 2u : 3u);
             if (hit) {
-                s.missing_sync_count = 0; update_values(si);
+                s.missing_sync_count = 0; upd_pending = true; upd_index = si;
                 s.sync_word_type = swt; s.st = ST_SYNC_WAIT;
                 if (mode_st == ST_STREAM_SYNC) s.eot_flag = 0;
             } else if (s.sync_count > 86) {
@@ -794,6 +799,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             break;
         }
         }
+        if (upd_pending) update_values(upd_index);
         wave_lds_sync();
         te = tt;
         tail_dcd = true;
