@@ -233,12 +233,15 @@ __device__ __forceinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32
     return o;
 }
 // DataCarrierDetect::update (:63-69) with the sums K3 produced for the segment [seg_start_tick, k]; returns the trigger.
-__device__ __forceinline__ uint32_t nf_dcd_update(M17_LDS Cold* cd, const float* tab, uint64_t tick0, uint64_t k, uint32_t trig)
+// (have: the two sums were fetched ahead, pl1 / pl2)
+__device__ __forceinline__ uint32_t nf_dcd_update(M17_LDS Cold* cd, const float* tab, uint64_t tick0, uint64_t k, uint32_t trig,
+                                                  bool have = false, float pl1 = 0.f, float pl2 = 0.f)
 {
     const float* row = tab + (size_t)(k - tick0) * 12;
     const uint32_t span = (uint32_t)(k + 1 - cd->seg_start_tick);
     const int j = span > 5 ? 5 : (int)(cd->seg_start_tick % 5u);
-    const float l1 = row[j], l2 = row[6 + j];  // table row: [2 bins][6 sums]
+    float l1, l2;  // table row: [2 bins][6 sums]
+    if (have) { l1 = pl1; l2 = pl2; } else { l1 = row[j]; l2 = row[6 + j]; }
     const float level = (float)((double)cd->dcd_level * 0.8 + 0.2 * (double)(l1 / l2));
     cd->dcd_level = level;
     cd->seg_start_tick = (uint32_t)(k + 1);

@@ -205,6 +205,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         hpf_base = base;
         hpf_wait = true;
     };
+    // The DCD sums of the NEXT update point (two floats of one table row) are fetched the same way right after each update:
+    // the point is 960 (carrier on) or 384 samples away and the sum it will read is the one that restarted with the next tick.
+    float* dpf = reinterpret_cast<float*>(hot_lds) + 62;   // two spare words of the hot slot
+    uint64_t dpf_tick = ~0ull;
     auto hpf_ready = [&] {
         if (hpf_wait) { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); hpf_wait = false; }   // vmcnt(0)
     };
@@ -305,6 +309,23 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         else err = sample + 3.f;
         return sample;
     };
+    // DataCarrierDetect::update at the point that ends with relative sample te, then the fetch for the next point
+    auto dcd_update_at = [&](uint32_t te) {
+        const uint64_t k = (P.pos0 + te + 1) / TICK - 1;
+        bool have = false;
+        float l1 = 0.f, l2 = 0.f;
+        if (dpf_tick == k) { hpf_ready(); l1 = dpf[0]; l2 = dpf[1]; have = true; }
+        s.dcd_trig = nf_dcd_update(cd, tab, tick0, k, s.dcd_trig, have, l1, l2);
+        const uint64_t kn = k + (s.dcd_on ? 5u : 2u);                 // 960 / 384 samples on
+        const uint64_t ten = (kn + 1) * TICK - 1 - P.pos0;            // relative sample of that point
+        dpf_tick = ~0ull;
+        if (ten < (uint64_t)P.T && kn - tick0 < (uint64_t)P.ticks_cap) {
+            const float* rown = tab + (size_t)(kn - tick0) * 12 + (size_t)((k + 1) % 5u);
+            if (wl < 2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rown + 6 * wl), (__attribute__((address_space(3))) void*)dpf, 4, 0, 0);
+            dpf_tick = kn;
+            hpf_wait = true;
+        }
+    };
     const float alpha = (float)(1.0 / 184);  // RunningStandardDeviation<float,184>::alpha
     // carrier-on update point: tail of operator() (:742-752); te = relative index of the sample just processed
     auto dcd_point_on = [&](uint32_t te) {
@@ -316,7 +337,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         s.count = 0;
         nf_fire_diag(cd, s.dcd_on, sqrtf(s.evm_S), s.idev, s.offset, s.st != ST_UNLOCKED, s.ck_clock_est, s.sample_index,
                      s.sync_sample_index, s.ck_sample_index, s.viterbi_cost);
-        s.dcd_trig = nf_dcd_update(cd, tab, tick0, (P.pos0 + te + 1) / TICK - 1, s.dcd_trig);
+        dcd_update_at(te);
     };
 
     unsigned long long n_bulk = 0, n_bulk_samples = 0, n_scalar = 0, n_flip = 0, n_decode = 0;
@@ -382,7 +403,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     s.run_pos = 0;  // a new gated run starts with the next sample
                     if (t < P.T) patch_run_start(t);
                 }
-                s.dcd_trig = nf_dcd_update(cd, tab, tick0, (P.pos0 + te + 1) / TICK - 1, s.dcd_trig);
+                dcd_update_at(te);
                 nf_fire_diag(cd, s.dcd_on, 0.f, s.idev, s.offset, s.st != ST_UNLOCKED, s.ck_clock_est, s.sample_index,
                              s.sync_sample_index, s.ck_sample_index, s.viterbi_cost);
                 s.count = 0;
