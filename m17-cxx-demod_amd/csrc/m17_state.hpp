@@ -32,6 +32,53 @@ struct Hot {  // per-channel scalars kept in registers while the kernel runs
     int32_t sync_count, missing_sync_count, initializing;
     uint32_t spec_ok;           // this run still trusts K2's speculative limit-filter history (m17_gate_kernel.hpp)
 };
+// The hot scalars while K5 runs: the same names as Hot, each one a wave-uniform value that every write forces into a SCALAR
+// register (v_readfirstlane), so the state machine's tests and counters are SALU work on registers instead of LDS round
+// trips (an LDS word is 64+ cycles away and the wave is latency-bound) and cost no VGPR.  The three SyncWord arrays are
+// indexed at run time and stay in the LDS copy of Hot.
+template <typename T> struct SReg {
+    T v;
+    __device__ __forceinline__ static T uni(T x)
+    {
+        return __builtin_bit_cast(T, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+    }
+    __device__ __forceinline__ operator T() const { return v; }
+    __device__ __forceinline__ SReg& operator=(T x) { v = uni(x); return *this; }
+    __device__ __forceinline__ SReg& operator=(const SReg& o) { v = o.v; return *this; }
+    __device__ __forceinline__ SReg& operator+=(T x) { v = uni((T)(v + x)); return *this; }
+    __device__ __forceinline__ SReg& operator-=(T x) { v = uni((T)(v - x)); return *this; }
+    __device__ __forceinline__ SReg& operator++() { v = uni((T)(v + 1)); return *this; }
+    __device__ __forceinline__ T operator++(int) { const T o = v; v = uni((T)(v + 1)); return o; }
+    __device__ __forceinline__ SReg& operator--() { v = uni((T)(v - 1)); return *this; }
+};
+#define M17_HOT_SCALARS(X)                                                                                                   \
+    X(uint32_t, dcd_trig) X(uint32_t, dcd_on) X(uint32_t, count) X(int32_t, run_pos) X(float, h0) X(float, h1) X(float, h2)      \
+    X(uint32_t, ring_pos) X(uint32_t, prev_pos) X(uint32_t, ck_count) X(int32_t, ck_sample_index) X(float, ck_clock_est)          \
+    X(float, ck_sample_est) X(float, idev) X(float, offset) X(float, evm_S) X(uint32_t, framer_idx) X(uint32_t, framer_half)       \
+    X(uint32_t, st) X(uint32_t, sync_word_type) X(uint32_t, sample_index) X(uint32_t, sync_sample_index)                           \
+    X(uint32_t, need_clock_reset) X(uint32_t, need_clock_update) X(uint32_t, eot_flag) X(uint32_t, viterbi_cost)                   \
+    X(int32_t, sync_count) X(int32_t, missing_sync_count) X(int32_t, initializing) X(uint32_t, spec_ok)
+struct HotRegs {
+#define X(T, n) SReg<T> n;
+    M17_HOT_SCALARS(X)
+#undef X
+    M17_LDS uint32_t* sw_trig;      // [4] in the LDS copy of Hot
+    M17_LDS uint32_t* sw_timing;    // [4]
+    M17_LDS int32_t* sw_updated;    // [4]
+    __device__ __forceinline__ void load(M17_LDS Hot* h)
+    {
+#define X(T, n) n = h->n;
+        M17_HOT_SCALARS(X)
+#undef X
+        sw_trig = h->sw_trig; sw_timing = h->sw_timing; sw_updated = h->sw_updated;
+    }
+    __device__ __forceinline__ void store(M17_LDS Hot* h) const
+    {
+#define X(T, n) h->n = n.v;
+        M17_HOT_SCALARS(X)
+#undef X
+    }
+};
 struct Cold {  // per-channel state touched a few times per frame (out-of-line helpers); lives in LDS while K5 runs, like Hot
     Kal2 ck, kmin, kmax;
     uint32_t dev_reset;

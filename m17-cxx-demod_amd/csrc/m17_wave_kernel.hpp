@@ -112,9 +112,9 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // global round trips (~1 us each, several in a row) made a single-sample step cost 6 us
     static_assert(sizeof(Cold) <= 48 * 4, "Cold must fit its LDS slot");
     M17_LDS Cold* cd = as_lds(reinterpret_cast<Cold*>(reinterpret_cast<uint32_t*>(hot_lds) + 64));
-    // The hot scalars live in LDS, not in registers: every lane holds the same values anyway, and with a 128-VGPR budget
-    // (4 waves per SIMD) keeping ~45 of them live across the whole loop spills to scratch (= HBM latency); an LDS word is
-    // 64 cycles away and costs no register between uses.
+    // The hot scalars are staged through LDS (global -> LDS -> HotRegs and back): while the kernel runs they are wave-uniform
+    // values in SCALAR registers (HotRegs, m17_state.hpp) — as plain per-lane variables ~45 of them spilled to scratch under
+    // the 128-VGPR budget (4 waves per SIMD), and as LDS words every test of the state machine was a 64-cycle round trip.
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&gs->hot);
         uint32_t* dst = reinterpret_cast<uint32_t*>(hot_lds);
@@ -125,13 +125,14 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         M17_LDS uint32_t* dst = reinterpret_cast<M17_LDS uint32_t*>(cd);
         for (int k = wl; k < (int)(sizeof(Cold) / 4); k += 64) dst[k] = src[k];
     }
-    Hot& s = *hot_lds;
+    HotRegs s;
     const float* hrow = P.h ? P.h + (size_t)c * P.ypitch + YPRE : nullptr;  // K2's filter history for this channel
     for (int k = wl; k < 80; k += 64) ring[k] = gs->ring[k];
     for (int k = wl; k < 40; k += 64) swsm[k] = gs->sw_samples[k / 10][k % 10];
     for (int k = wl; k < 92; k += 64) DL.llr[k] = gs->llr[k];
     for (int k = wl; k < 8; k += 64) DL.lsf[k] = gs->lsf[k];
     wave_lds_sync();
+    s.load(as_lds(hot_lds));
     s.spec_ok = hrow != nullptr;  // every run starts trusting K2 (which started from this very state)
     if (!(P.flags & 2u)) cd->n_run = 0;  // (flag bit 1: a later segment of the same run keeps counting its records)
     // Sample window: ybuf samples [t, avail) are in LDS; the next WV_PF samples are in flight in registers (pf) so that the
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         // ---- one input sample: M17Demodulator::operator() :657-753 -----------------------------------------------------------
         const unsigned long long c0 = now();
         ++n_scalar;
-        if constexpr (PROF) { if (wl == 0) P.dbg[(size_t)c * 24 + 17 + 1 + min(s.st, 5u)] += 1; }
+        if constexpr (PROF) { if (wl == 0) P.dbg[(size_t)c * 24 + 17 + 1 + min((uint32_t)s.st, 5u)] += 1; }
         const uint32_t tt = t;
         cur_tt = tt;
         s.count++;
@@ -843,6 +844,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // ---------------- save state ------------------------------------------------------------------------------
     if (s.spec_ok) { const float* f = P.final_h + (size_t)c * 4; s.h0 = f[0]; s.h1 = f[1]; s.h2 = f[2]; }
     if (P.dropped && wl == 0) P.dropped[c] = s.spec_ok ? 0u : 1u;
+    s.store(as_lds(hot_lds));
     wave_lds_sync();
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(hot_lds);
