@@ -27,6 +27,8 @@ extern "C" {
 #define M17HIP_ENOMEM (-3)
 #define M17HIP_ESTATE (-4)   /* call sequence error (e.g. fetch before run) */
 #define M17HIP_EOVERFLOW (-5) /* a per-channel frame-record buffer overflowed */
+#define M17HIP_ETRUNC (-6)   /* more results than the caller's capacity: *count says how many exist, `capacity` were written */
+#define M17HIP_ECOMM (-7)    /* an RCCL call failed (m17hip_gather_*) */
 
 /* Frame-type / sync-type codes = the reference enums M17FrameDecoder.h:52-55. */
 enum { M17_FRAME_LSF = 0, M17_FRAME_LICH = 1, M17_FRAME_STREAM = 2, M17_FRAME_BASIC_PACKET = 3, M17_FRAME_FULL_PACKET = 4, M17_FRAME_BERT = 5 };
@@ -80,14 +82,19 @@ int m17hip_set_stream(m17hip_ctx* ctx, void* hip_stream);
 
 /* Input: [C][T] int16, row pitch in samples.  Replaces the stdin read loop apps/m17-demod.cpp:484-488. */
 int m17hip_upload_i16(m17hip_ctx* ctx, const int16_t* host, uint32_t channels, uint32_t samples, size_t pitch);
-/* Same, from a DEVICE pointer (e.g. a tensor that already lives in HBM). */
+/* Same, from a DEVICE pointer (e.g. a tensor that already lives in HBM); the copy is complete when the call returns, so
+ * `dev` may be freed or refilled at once. */
 int m17hip_upload_i16_device(m17hip_ctx* ctx, const int16_t* dev, uint32_t channels, uint32_t samples, size_t pitch);
 /* Streaming ingest: stage the input of the NEXT m17hip_demod_run in a second slab while the current run is
  * computing.  The copy is queued on the context's own copy stream and starts as soon as the run before the current one has
- * released that slab; host memory must stay valid until the next m17hip_demod_run has been called, and should be pinned
- * (hipHostMalloc / hipHostRegister) for the copy to overlap.  The next m17hip_demod_run (same channel / sample counts) waits for
- * the copy, swaps the slabs (the carried 152-sample tail is moved over) and runs on the staged input. */
+ * released that slab; it should come from pinned memory (hipHostMalloc / hipHostRegister) to overlap.  The next
+ * m17hip_demod_run (same channel / sample counts) makes the device wait for the copy, swaps the slabs (the carried 152-sample
+ * tail is moved over) and runs on the staged input.  m17hip_demod_run does NOT wait on the host: the copy may still be in
+ * flight when it returns.  The host buffer must stay valid AND unmodified until m17hip_upload_wait has returned (or until a
+ * frames / diag fetch of the run that consumed it has returned — those synchronise with the run, which waited for the copy). */
 int m17hip_upload_i16_async(m17hip_ctx* ctx, const int16_t* host, uint32_t channels, uint32_t samples, size_t pitch);
+/* Block until the copy queued by the last m17hip_upload_i16_async has left the host buffer. */
+int m17hip_upload_wait(m17hip_ctx* ctx);
 
 /* ---- per-operator batched entry points (config 2 parity) ---------------------------------------- */
 /* K1: sample scaling + BaseFirFilter<float,150> with the RRC taps, ungated, over the uploaded slab
@@ -126,9 +133,11 @@ int m17hip_demod_reset(m17hip_ctx* ctx);
 int m17hip_demod_run(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint32_t flags);
 /* Number of records produced by the last run (all channels). */
 int m17hip_frames_count(m17hip_ctx* ctx, uint64_t* total);
-/* Records of the last run, ordered by (channel, seq).  Host destination. */
+/* Records of the last run, ordered by (channel, seq).  Host destination.  *count = records the run produced; when that is
+ * more than `capacity` only `capacity` are written and M17HIP_ETRUNC is returned. */
 int m17hip_frames_fetch(m17hip_ctx* ctx, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* count);
-/* Same, compacted into caller-provided DEVICE memory (so a collective can ship it without a host hop). */
+/* Same, compacted into caller-provided DEVICE memory (so a collective can ship it without a host hop); same
+ * truncation rule. */
 int m17hip_frames_compact_device(m17hip_ctx* ctx, m17_frame_rec* recs_dev, uint64_t capacity, uint64_t* count);
 /* Per-channel diagnostics after the last run: diag_host[C]. */
 int m17hip_diag_fetch(m17hip_ctx* ctx, m17_diag* diag_host, uint32_t channels);
@@ -204,12 +213,48 @@ typedef struct m17_lsf_info {
 } m17_lsf_info;
 int m17hip_lsf_info(m17hip_ctx* ctx, const uint8_t* lsf30_host, uint32_t n, m17_lsf_info* out_host);
 
+/* ---- numerics switch: evaluation order of the Kalman updates --------------------------------------------------------- */
+/* KalmanFilter.h:41-65,91-107 (used by ClockRecovery.h:54-67 and FreqDevEstimator.h:31-48) keeps the innovation covariance and
+ * the gain as lazy expressions of the blaze library (`auto S`, `auto K`), so the association and rounding of `x += K*y` and
+ * `P = P - K*H*P` are decided by blaze's restructuring operators.  blaze is not part of the reference tree (empty submodule),
+ * so the order is selectable: bit 0: x += double(fl32(P(:,0)*y)) * (1/S) instead of x += (double(P(:,0))/S) * y;
+ * bit 1: P -= double(fl32(P(i,0)*P(0,j))) * (1/S) instead of P -= (double(P(i,0))/S) * P(0,j); bit 2: F*(P*F^T) instead of
+ * (F*P)*F^T.  Default 3 (blaze's documented restructuring rules; DESIGN.md §4.4 has the measured sensitivity).  Applies to the
+ * runs that follow. */
+int m17hip_set_kalman_order(m17hip_ctx* ctx, int order);
+/* a9/a10 per-operator parity entry: `rows` independent filters reset to z0, n updates each with measurement z[r][i] after
+ * dt[r][i] samples; wrap = 10: KalmanFilter<float,10> (KalmanFilter.h:41-65), 0: SymbolKalmanFilter (:91-107).
+ * out[rows][n][6] = x[0], x[1], P(0,0), P(0,1), P(1,0), P(1,1) after each update. */
+int m17hip_kalman_trace(m17hip_ctx* ctx, const float* z_host, const uint32_t* dt_host, uint32_t rows, uint32_t n, int wrap, float z0, int order,
+                        float* out_host);
+
+/* ---- multi-GPU: contiguous channel shards, one context (rank) per GPU, no data-path collective ------------ */
+/* Records of this context carry channel = channel_base + local channel index (default 0), so the union of the shards'
+ * record sets is the record set of one big run.  Applies to the runs that follow (also to m17hip_packets_fetch). */
+int m17hip_set_channel_base(m17hip_ctx* ctx, uint32_t channel_base);
+/* The one exchange of the path: the gather of the frame records of the last run to `root` over RCCL (xGMI inside a node).
+ * Rank 0 obtains an id (ncclGetUniqueId) and hands its 128 bytes to the other ranks by any host-side channel; every rank then
+ * creates its communicator (ncclCommInitRank; collective).  m17hip_gather_frames is collective: every rank compacts its
+ * records on the device, the counts are all-gathered, the records travel to `root` with their exact sizes (grouped
+ * ncclSend / ncclRecv) and land in recs_host[capacity] rank after rank — with contiguous shards and channel bases set that is
+ * global (channel, seq) order.  counts[nranks] (optional) and *total are filled on every rank; recs_host is only used on
+ * `root`.  M17HIP_ETRUNC if total > capacity, M17HIP_ECOMM if RCCL is missing or fails (m17hip_comm_last_error). */
+typedef struct m17hip_comm m17hip_comm;
+#define M17HIP_COMM_ID_BYTES 128
+int m17hip_comm_get_id(void* id128);
+int m17hip_comm_create(m17hip_ctx* ctx, const void* id128, int rank, int nranks, m17hip_comm** out);
+void m17hip_comm_destroy(m17hip_comm* comm);
+int m17hip_comm_last_error(const m17hip_comm* comm);
+int m17hip_gather_frames(m17hip_ctx* ctx, m17hip_comm* comm, int root, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* counts,
+                         uint64_t* total);
+
 /* Tuning knobs (performance only, never results).  key 0: waves (= channels) per workgroup of the sequential kernel
  * (0 = default 4; 1, 2, 4, 8).  key 1: per-channel tick counters of that kernel on/off (m17hip_debug_counters).
  * key 2: run the correlator's limit filter ahead of the sequential kernel (default 1) or inside it (0).
  * key 3: samples per segment a run is processed in (default 48000; 0 = one segment).  key 4: samples of the first segment
  * (default 0 = like the others).  key 6: BERT statistics on/off (m17hip_bert_stats; default off).  key 7: packet reassembly, value = packets of room per run (m17hip_packets_fetch; default 0 = off).  key 5: segments the front end (K1, K3) may run ahead of the sequential kernel
- * (default 0 = unlimited). */
+ * (default 0 = unlimited).  key 8 (not a performance knob): record slots per channel and run actually used, 0 = all that were
+ * allocated (2 per 1920 samples + 8, which a run cannot outgrow) — a smaller value makes M17HIP_EOVERFLOW reachable for tests. */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 
 /* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][24] =

@@ -33,6 +33,27 @@ __global__ __launch_bounds__(64) void slice_kernel(const float* __restrict__ sym
     }
 }
 
+// a9/a10 stand-alone (parity API): the 2-state Kalman update of KalmanFilter.h:41-65 / :91-107 (kal_update, the function the
+// full-chain kernel calls) on `rows` independent filters, n updates each: z[r][i] after dt[r][i] samples.
+// out[r][i][6] = x0, x1, P00, P01, P10, P11 after update i.  One lane per row, the filter state in LDS as in K5.
+__global__ __launch_bounds__(64) void kalman_kernel(const float* __restrict__ z, const uint32_t* __restrict__ dt, uint32_t rows, uint32_t n, int wrap,
+                                                    float z0, uint32_t order, float* __restrict__ out)
+{
+    __shared__ Kal2 st[64];
+    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= rows) return;
+    M17_LDS Kal2* kp = as_lds(&st[threadIdx.x]);
+    Kal2 k;
+    kal_reset(k, z0);
+    lds_put(kp, k);
+    for (uint32_t i = 0; i < n; ++i) {
+        kal_update(kp, z[(size_t)r * n + i], dt[(size_t)r * n + i], wrap, order);
+        k = lds_get(kp);
+        float* o = out + ((size_t)r * n + i) * 6;
+        o[0] = k.x0; o[1] = k.x1; o[2] = k.p00; o[3] = k.p01; o[4] = k.p10; o[5] = k.p11;
+    }
+}
+
 // Standalone K4 entry points (parity API): one lane per frame.
 __global__ __launch_bounds__(64) void viterbi_kernel(const int8_t* __restrict__ soft, uint32_t n_frames, int kind,
                                                      uint8_t* __restrict__ bits, int32_t* __restrict__ cost,

@@ -123,6 +123,8 @@ struct SeqParams {
     const float* h;           // K2's limit-filter history, pitch ypitch (nullptr: no speculation, K5 runs the filter itself)
     const float* final_h;     // [C][4] K2's filter history after the last fed sample of the run
     uint32_t* dropped;        // [C] out: this segment dropped the speculation (K2 must redo the channel's next segment from K5's state)
+    uint32_t kalman_order;    // evaluation order of the Kalman update (kal_update)
+    uint32_t channel_base;    // global id of channel 0 of this context (written into the frame records)
 };
 
 // LDS words for a wave of `ls` channels: ring, sync samples, llr, hist, outb, lsf columns; edges, src maps, lich map
@@ -130,14 +132,20 @@ struct SeqParams {
 __device__ __constant__ const float SW_MAG1[4] = {29.f, 31.f, 31.f, 31.f};
 __device__ __constant__ const float SW_MAG2[4] = {-3.402823466e+38f, -31.f, -31.f, -3.402823466e+38f};
 
-// ---- Kalman pieces (semantics: eager evaluation, usual arithmetic conversions) --------------
+// ---- Kalman pieces --------------------------------------------------------------------------------------------
+// KalmanFilter.h:41-65,91-107.  `S` and `K` are lazy blaze expressions there (`auto`), so the association / rounding of
+// `x += K*y` and `P = P - K*H*P` follows blaze's restructuring operators; blaze is absent from the reference tree, hence the
+// order is a switch shared with the oracle (m17hip_set_kalman_order):
+//   bit 0: x += double(fl32(P(:,0)*y)) * invS      [(A*s)*v -> (A*v)*s]   else  x += (double(P(:,0))*invS) * double(y)
+//   bit 1: P -= double(fl32(P(i,0)*P(0,j))) * invS [(A*s)*B -> (A*B)*s]   else  P -= ((double(P(i,0))*invS) * double(P(0,j)))
+//   bit 2: F*(P*F^T) instead of (F*P)*F^T
 __device__ __forceinline__ void kal_reset(Kal2& k, float z)
 {
     k.x0 = z; k.x1 = 0.f;
     k.p00 = 4.f; k.p01 = 0.f; k.p10 = 0.f; k.p11 = (float)0.00000025;
 }
-// wrap != 0: KalmanFilter<float,SPS> (index filter, modulo SPS); 0: SymbolKalmanFilter.  State in global memory.
-__device__ __noinline__ void kal_update(M17_LDS Kal2* kp, float z, uint32_t dt_u, int wrap)
+// wrap != 0: KalmanFilter<float,SPS> (index filter, modulo SPS); 0: SymbolKalmanFilter.  State in LDS.
+__device__ __noinline__ void kal_update(M17_LDS Kal2* kp, float z, uint32_t dt_u, int wrap, uint32_t order)
 {
     Kal2 k = lds_get(kp);
     const float F00 = 1.f, F01 = (float)dt_u, F10 = 0.f, F11 = 1.f;
@@ -145,10 +153,18 @@ __device__ __noinline__ void kal_update(M17_LDS Kal2* kp, float z, uint32_t dt_u
     const float nx0 = F00 * k.x0 + F01 * k.x1;
     const float nx1 = F10 * k.x0 + F11 * k.x1;
     k.x0 = nx0; k.x1 = nx1;
-    const float A00 = F00 * k.p00 + F01 * k.p10, A01 = F00 * k.p01 + F01 * k.p11;
-    const float A10 = F10 * k.p00 + F11 * k.p10, A11 = F10 * k.p01 + F11 * k.p11;
-    const float B00 = A00 * F00 + A01 * F01, B01 = A00 * F10 + A01 * F11;
-    const float B10 = A10 * F00 + A11 * F01, B11 = A10 * F10 + A11 * F11;
+    float B00, B01, B10, B11;
+    if (!(order & 4u)) {
+        const float A00 = F00 * k.p00 + F01 * k.p10, A01 = F00 * k.p01 + F01 * k.p11;
+        const float A10 = F10 * k.p00 + F11 * k.p10, A11 = F10 * k.p01 + F11 * k.p11;
+        B00 = A00 * F00 + A01 * F01; B01 = A00 * F10 + A01 * F11;
+        B10 = A10 * F00 + A11 * F01; B11 = A10 * F10 + A11 * F11;
+    } else {
+        const float A00 = k.p00 * F00 + k.p01 * F01, A01 = k.p00 * F10 + k.p01 * F11;
+        const float A10 = k.p10 * F00 + k.p11 * F01, A11 = k.p10 * F10 + k.p11 * F11;
+        B00 = F00 * A00 + F01 * A10; B01 = F00 * A01 + F01 * A11;
+        B10 = F10 * A00 + F11 * A10; B11 = F10 * A01 + F11 * A11;
+    }
     k.p00 = B00 + Q00; k.p01 = B01 + Q01; k.p10 = B10 + Q10; k.p11 = B11 + Q11;
     const float hp0 = 1.f * k.p00 + 0.f * k.p10;
     const float hp1 = 1.f * k.p01 + 0.f * k.p11;
@@ -163,17 +179,36 @@ __device__ __noinline__ void kal_update(M17_LDS Kal2* kp, float z, uint32_t dt_u
         else if ((double)(z - k.x0) > ((double)wrap / 2.0)) z -= fw;
     }
     const float y = z - (1.f * k.x0 + 0.f * k.x1);
-    k.x0 = (float)((double)k.x0 + K0 * (double)y);
-    k.x1 = (float)((double)k.x1 + K1 * (double)y);
+    if (order & 1u) {
+        const float hy0 = 1.f * y, hy1 = 0.f * y;
+        const float t0 = k.p00 * hy0 + k.p01 * hy1;
+        const float t1 = k.p10 * hy0 + k.p11 * hy1;
+        k.x0 = (float)((double)k.x0 + (double)t0 * invS);
+        k.x1 = (float)((double)k.x1 + (double)t1 * invS);
+    } else {
+        k.x0 = (float)((double)k.x0 + K0 * (double)y);
+        k.x1 = (float)((double)k.x1 + K1 * (double)y);
+    }
     if (wrap) {
         while (k.x0 >= fw) k.x0 -= fw;
         while (k.x0 < 0.f) k.x0 += fw;
     }
-    const double KH00 = K0 * 1.0, KH01 = K0 * 0.0, KH10 = K1 * 1.0, KH11 = K1 * 0.0;
-    const float n00 = (float)((double)k.p00 - (KH00 * (double)k.p00 + KH01 * (double)k.p10));
-    const float n01 = (float)((double)k.p01 - (KH00 * (double)k.p01 + KH01 * (double)k.p11));
-    const float n10 = (float)((double)k.p10 - (KH10 * (double)k.p00 + KH11 * (double)k.p10));
-    const float n11 = (float)((double)k.p11 - (KH10 * (double)k.p01 + KH11 * (double)k.p11));
+    float n00, n01, n10, n11;
+    if (order & 2u) {
+        const float G00 = ph0 * 1.f, G01 = ph0 * 0.f, G10 = ph1 * 1.f, G11 = ph1 * 0.f;
+        const float T00 = G00 * k.p00 + G01 * k.p10, T01 = G00 * k.p01 + G01 * k.p11;
+        const float T10 = G10 * k.p00 + G11 * k.p10, T11 = G10 * k.p01 + G11 * k.p11;
+        n00 = (float)((double)k.p00 - (double)T00 * invS);
+        n01 = (float)((double)k.p01 - (double)T01 * invS);
+        n10 = (float)((double)k.p10 - (double)T10 * invS);
+        n11 = (float)((double)k.p11 - (double)T11 * invS);
+    } else {
+        const double KH00 = K0 * 1.0, KH01 = K0 * 0.0, KH10 = K1 * 1.0, KH11 = K1 * 0.0;
+        n00 = (float)((double)k.p00 - (KH00 * (double)k.p00 + KH01 * (double)k.p10));
+        n01 = (float)((double)k.p01 - (KH00 * (double)k.p01 + KH01 * (double)k.p11));
+        n10 = (float)((double)k.p10 - (KH10 * (double)k.p00 + KH11 * (double)k.p10));
+        n11 = (float)((double)k.p11 - (KH10 * (double)k.p01 + KH11 * (double)k.p11));
+    }
     k.p00 = n00; k.p01 = n01; k.p10 = n10; k.p11 = n11;
     lds_put(kp, k);
 }
@@ -231,7 +266,7 @@ __device__ __forceinline__ int32_t clock_predict(float sample_est, float clock_e
 // ---- out-of-line helpers on COLD state ------------------------------------------------------------------------------
 // M17Demodulator::update_values (:233-241) = Correlator::outer_symbol_levels (Correlator.h:81-114) +
 // FreqDevEstimator::update (FreqDevEstimator.h:31-48).  Returns (idev, offset).
-__device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float* ring, int stride, int lane, uint32_t si)
+__device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float* ring, int stride, int lane, uint32_t si, uint32_t order)
 {
     float min_sum = 0.f, max_sum = 0.f;
     uint32_t min_count = 0, max_count = 0;
@@ -251,8 +286,8 @@ __device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float
     }
     const float mn = min_count > 0 ? min_sum / (float)min_count : lo;
     const float mx = max_count > 0 ? max_sum / (float)max_count : hi;
-    kal_update(&cd->kmin, mn, 192u, 0);
-    kal_update(&cd->kmax, mx, 192u, 0);
+    kal_update(&cd->kmin, mn, 192u, 0, order);
+    kal_update(&cd->kmax, mx, 192u, 0, order);
     const Kal2 a = lds_get(&cd->kmin), b = lds_get(&cd->kmax);
     float offset = (float)((double)(b.x0 + a.x0) / 2.);
     float idev = (float)(6.0 / (double)(b.x0 - a.x0));
@@ -270,9 +305,9 @@ __device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float
 }
 struct ClockOut { float sample_est, clock_est; int32_t sample_index; };
 // ClockRecovery::update(uint8_t) (ClockRecovery.h:54-67)
-__device__ __forceinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32_t index, uint32_t ck_count)
+__device__ __forceinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32_t index, uint32_t ck_count, uint32_t order)
 {
-    kal_update(&cd->ck, (float)index, ck_count, 10);
+    kal_update(&cd->ck, (float)index, ck_count, 10, order);
     ClockOut o;
     o.sample_est = cd->ck.x0;
     o.sample_index = wrap10((int32_t)round((double)o.sample_est));

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     };
     auto sw_updated = [&](int w) -> int32_t { const int32_t r = s.sw_updated[w]; s.sw_updated[w] = 0; return r; };
     auto update_values = [&](uint32_t index) {  // M17Demodulator.h:233-241
-        const float2 r = nf_update_values(cd, ring, 1, 0, s.sample_index);
+        const float2 r = nf_update_values(cd, ring, 1, 0, s.sample_index, P.kalman_order);
         s.idev = r.x; s.offset = r.y;
         s.sync_sample_index = index;
     };
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             s.need_clock_reset = 0;
             s.sample_index = s.sync_sample_index;
         } else if (s.need_clock_update) {
-            const ClockOut o = nf_clock_update_idx(cd, s.sync_sample_index, s.ck_count);
+            const ClockOut o = nf_clock_update_idx(cd, s.sync_sample_index, s.ck_count, P.kalman_order);
             s.ck_sample_est = o.sample_est; s.ck_clock_est = o.clock_est; s.ck_sample_index = o.sample_index;
             s.ck_count = 0;
             s.need_clock_update = 0;
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         if (decode_due) {  // decoder(...) and the rest of do_frame (:619-642)
             const unsigned long long d0 = now();
             hpf_ready(); hpf_base = -0x40000000;   // the decoder takes the cost-word array
-            const uint2 r = nf_decode_wave(P.tables, DL, wl, s.sync_word_type, cd, s.viterbi_cost, rec_base, P.rec_cap, c, P.pos0 + te, P.overflow);
+            const uint2 r = nf_decode_wave(P.tables, DL, wl, s.sync_word_type, cd, s.viterbi_cost, rec_base, P.rec_cap, P.channel_base + c, P.pos0 + te, P.overflow);
             s.viterbi_cost = r.x;
             s.st = (r.y == 1u || r.y == 0u) ? ST_STREAM_SYNC : (r.y == 4u ? ST_BERT_SYNC : ST_PACKET_SYNC);
             ++n_decode;

@@ -11,6 +11,7 @@
 #include "m17_gate_kernel.hpp"
 #include "m17_mod_kernels.hpp"
 #include "m17_parity_kernels.hpp"
+#include "m17_gather.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -42,7 +43,7 @@ struct m17hip_ctx {
     uint32_t front_ahead = 0;         // tuning knob 5: segments the front end (K1, K3) may run ahead of K5 (0 = unlimited, measured best)
     uint32_t maxC = 0, maxT = 0;
     size_t xpitch = 0, ypitch = 0;
-    uint32_t ticks_cap = 0, rec_cap = 0;
+    uint32_t ticks_cap = 0, rec_cap = 0, rec_cap_alloc = 0;   // rec_cap: record slots per channel and run in use (<= allocated)
     int16_t* xbuf = nullptr;
     int16_t* xstage = nullptr;        // second input slab: the next run's samples are copied here while the current run computes
     hipStream_t copy = nullptr;
@@ -61,6 +62,8 @@ struct m17hip_ctx {
     uint32_t* pkt_count = nullptr;
     uint32_t pkt_cap = 0;
     bool pkt_fed = false;
+    uint32_t kalman_order = 3;        // evaluation order of the Kalman updates (m17hip_set_kalman_order)
+    uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
     bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     uint32_t seg0_len = 0;            // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others; measured neutral)
@@ -92,6 +95,16 @@ struct m17hip_ctx {
     std::vector<hipEvent_t> pool;
     double acc_ms[KT_N] = {0};
     uint64_t acc_n[KT_N] = {0};
+};
+
+struct m17hip_comm {
+    ncclComm_t comm = nullptr;
+    m17hip_ctx* ctx = nullptr;
+    int rank = 0, nranks = 1;
+    int last_rccl = 0;
+    uint64_t* counts_dev = nullptr;   // [nranks]
+    FrameRec* gathered = nullptr;     // root: every rank's records, rank after rank
+    uint64_t gathered_cap = 0;
 };
 
 namespace {
@@ -170,25 +183,47 @@ DcdCoef build_coef()  // SlidingDFT.h:85-95
 }
 
 // ---- timing ---------------------------------------------------------------------------------------------------
-hipEvent_t get_event(m17hip_ctx* c)
+hipEvent_t get_event(m17hip_ctx* c)   // nullptr (and last_hip set) when the runtime cannot create one
 {
     if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    hipEventCreate(&e);
+    const hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) { c->last_hip = (int)r; return nullptr; }
     return e;
 }
-struct Timed {  // HIP events on the stream the kernel is launched on
+struct Timed {  // HIP events on the stream the kernel is launched on; a launch whose events could not be had is not timed
     m17hip_ctx* c; int which; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     Timed(m17hip_ctx* ctx, int w, hipStream_t stream) : c(ctx), which(w), st(stream)
     {
-        if (c->timing) { a = get_event(c); b = get_event(c); hipEventRecord(a, st); }
+        if (!c->timing) return;
+        a = get_event(c); b = get_event(c);
+        if (!a || !b || hipEventRecord(a, st) != hipSuccess) {
+            if (a) c->pool.push_back(a);
+            if (b) c->pool.push_back(b);
+            a = b = nullptr;
+        }
     }
     Timed(m17hip_ctx* ctx, int w) : Timed(ctx, w, ctx->stream) {}
     ~Timed()
     {
-        if (c->timing) { hipEventRecord(b, st); c->pending.push_back({a, b, which}); }
+        if (!a) return;
+        if (hipEventRecord(b, st) == hipSuccess) c->pending.push_back({a, b, which});
+        else { c->pool.push_back(a); c->pool.push_back(b); }
     }
 };
+// Every entry point works on the context's own device whatever the calling thread's current device is (a host that also
+// drives other GPUs, torch.cuda.set_device, ...): set it for the duration of the call and put the caller's back.
+struct DeviceGuard {
+    int prev = -1; bool ok = true;
+    explicit DeviceGuard(m17hip_ctx* c)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) { const hipError_t e = hipSetDevice(c->device); if (e != hipSuccess) { c->last_hip = (int)e; ok = false; prev = -1; } }
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+#define GUARD(ctx) DeviceGuard guard_(ctx); if (!guard_.ok) return M17HIP_EHIP
 void drain_timing(m17hip_ctx* c)
 {
     for (auto& t : c->pending) {
@@ -343,7 +378,7 @@ struct PacketRec {       // = m17_packet_rec
 // CRC-16/X.25 check (0x0f47 over contents + FCS).  Completed packets go to `out` in arrival order of the atomics;
 // (channel, seq) orders them.
 __global__ void packet_asm_kernel(const FrameRec* recs, uint32_t rec_cap, const uint32_t* rec_count, PacketState* state, uint32_t C,
-                                  PacketRec* out, uint32_t out_cap, uint32_t* out_count)
+                                  PacketRec* out, uint32_t out_cap, uint32_t* out_count, uint32_t channel_base)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -375,7 +410,7 @@ __global__ void packet_asm_kernel(const FrameRec* recs, uint32_t rec_cap, const 
         const uint32_t slot = atomicAdd(out_count, 1u);
         if (slot < out_cap) {
             PacketRec* o = out + slot;
-            o->channel = c; o->seq = completed; o->sample_pos = rec->sample_pos;
+            o->channel = channel_base + c; o->seq = completed; o->sample_pos = rec->sample_pos;
             o->size = (uint16_t)size; o->checksum = (uint16_t)crc;
             o->crc_ok = crc == 0x0F47u ? 1 : 0; o->frames = (uint8_t)frames; o->seq_errors = (uint8_t)min(seq_errors, 255u); o->reserved = 0;
             for (uint32_t i = 0; i < 840u; ++i) o->data[i] = i < size ? st->data[i] : (uint8_t)0;
@@ -493,11 +528,13 @@ const char* m17hip_strerror(int code)
     case M17HIP_ENOMEM: return "out of memory";
     case M17HIP_ESTATE: return "call sequence error";
     case M17HIP_EOVERFLOW: return "frame record buffer overflow";
+    case M17HIP_ETRUNC: return "output truncated to the caller's capacity";
+    case M17HIP_ECOMM: return "RCCL communication error";
     default: return "unknown error";
     }
 }
 int m17hip_last_hip_error(const m17hip_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
-int m17hip_version(void) { return 100; }
+int m17hip_version(void) { return 200; }
 
 int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out)
 {
@@ -508,11 +545,12 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     c->maxC = max_channels;
     c->maxT = max_samples;
     auto fail = [&](int code) { m17hip_ctx_destroy(c); return code; };
-    if (hipSetDevice(device) != hipSuccess) return fail(M17HIP_EHIP);
+    DeviceGuard guard_(c);
+    if (!guard_.ok) return fail(M17HIP_EHIP);
     c->xpitch = round_up((size_t)XPRE + max_samples + 8, 8);
     c->ypitch = round_up((size_t)YPRE + max_samples + 4, 4);
     c->ticks_cap = max_samples / TICK + 2;
-    c->rec_cap = 2 * (max_samples / 1920 + 2) + 4;  // <= 2 callbacks per 1920-sample frame
+    c->rec_cap = c->rec_cap_alloc = 2 * (max_samples / 1920 + 2) + 4;  // <= 2 callbacks per 1920-sample frame
     const size_t C = max_channels;
 #define ALLOC(ptr, bytes)                                                            \
     do {                                                                             \
@@ -527,6 +565,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->dropped, C * sizeof(uint32_t));
     ALLOC(c->bert_state, C * sizeof(BertState));
     hipLaunchKernelGGL(bert_reset_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, 0, (BertState*)c->bert_state, (uint32_t)C);
+    if (hipGetLastError() != hipSuccess) return fail(M17HIP_EHIP);
     ALLOC(c->dcd_table, C * c->ticks_cap * 12 * sizeof(float));
     ALLOC(c->dcd_state, C * sizeof(DcdState));
     ALLOC(c->seq_state, C * sizeof(SeqState));
@@ -578,6 +617,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
 void m17hip_ctx_destroy(m17hip_ctx* c)
 {
     if (!c) return;
+    DeviceGuard guard_(c);
     drain_timing(c);
     for (auto e : c->pool) hipEventDestroy(e);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -600,6 +640,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
 int m17hip_set_stream(m17hip_ctx* c, void* hip_stream)
 {
     if (!c) return M17HIP_EINVAL;
+    GUARD(c);
     c->stream = (hipStream_t)hip_stream;
     return M17HIP_OK;
 }
@@ -607,6 +648,7 @@ int m17hip_set_stream(m17hip_ctx* c, void* hip_stream)
 int m17hip_upload_i16(m17hip_ctx* c, const int16_t* host, uint32_t C, uint32_t T, size_t pitch)
 {
     if (!c || !host || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
+    GUARD(c);
     HIPCHK(c, hipMemcpy2DAsync(c->xbuf + XPRE, c->xpitch * sizeof(int16_t), host, pitch * sizeof(int16_t), (size_t)T * sizeof(int16_t), C,
                                hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -618,6 +660,7 @@ int m17hip_upload_i16(m17hip_ctx* c, const int16_t* host, uint32_t C, uint32_t T
 int m17hip_upload_i16_async(m17hip_ctx* c, const int16_t* host, uint32_t C, uint32_t T, size_t pitch)
 {
     if (!c || !host || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
+    GUARD(c);
     if (!c->xstage) {
         hipError_t e = hipMalloc((void**)&c->xstage, (size_t)c->maxC * c->xpitch * sizeof(int16_t));
         if (e != hipSuccess) { c->last_hip = (int)e; return e == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP; }
@@ -638,6 +681,7 @@ int m17hip_upload_i16_async(m17hip_ctx* c, const int16_t* host, uint32_t C, uint
 int m17hip_synth_i16(m17hip_ctx* c, const m17_synth_params* params, uint32_t C, uint32_t T, uint32_t chan0)
 {
     if (!c || !params || C == 0 || T == 0 || C > c->maxC || T > c->maxT || params->n_frames < 0 || params->kind > 4) return M17HIP_EINVAL;
+    GUARD(c);
     if (params->kind == 4 && (params->n_frames < 1 || params->n_frames > 33)) return M17HIP_EINVAL;   // 5-bit frame numbers
     static_assert(sizeof(ModParams) == sizeof(m17_synth_params), "parameter block layout");
     ModParams mp;
@@ -661,6 +705,7 @@ int m17hip_synth_i16(m17hip_ctx* c, const m17_synth_params* params, uint32_t C, 
 int m17hip_download_i16(m17hip_ctx* c, int16_t* host, uint32_t C, uint32_t T, size_t pitch)
 {
     if (!c || !host || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
+    GUARD(c);
     if (!c->uploaded) return M17HIP_ESTATE;
     HIPCHK(c, hipMemcpy2DAsync(host, pitch * sizeof(int16_t), c->xbuf + XPRE, c->xpitch * sizeof(int16_t), (size_t)T * sizeof(int16_t), C,
                                hipMemcpyDeviceToHost, c->stream));
@@ -671,9 +716,11 @@ int m17hip_download_i16(m17hip_ctx* c, int16_t* host, uint32_t C, uint32_t T, si
 int m17hip_upload_i16_device(m17hip_ctx* c, const int16_t* dev, uint32_t C, uint32_t T, size_t pitch)
 {
     if (!c || !dev || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
+    GUARD(c);
     dim3 grid(((T + 7) / 8 + 255) / 256, C);
     hipLaunchKernelGGL(copy_rows_i16_kernel, grid, dim3(256), 0, c->stream, dev, pitch, c->xbuf, c->xpitch, T);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // `dev` belongs to the caller again when this returns
     c->uploaded = true;
     c->lastC = C; c->lastT = T;
     return M17HIP_OK;
@@ -682,6 +729,7 @@ int m17hip_upload_i16_device(m17hip_ctx* c, const int16_t* dev, uint32_t C, uint
 int m17hip_fir_rrc150(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* out_host)
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    GUARD(c);
     if (!c->uploaded) return M17HIP_ESTATE;
     int r = launch_fir(c, C, T, flags, c->stream);
     if (r) return r;
@@ -696,6 +744,7 @@ int m17hip_fir_rrc150(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, flo
 int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, float* corr_host)
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    GUARD(c);
     const size_t n = (size_t)C * T;
     int r = ensure_scratch(c, 5 * n * sizeof(float));
     if (r) return r;
@@ -716,6 +765,7 @@ int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, 
 int m17hip_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* sums_host, uint32_t* ticks_out)
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    GUARD(c);
     if (!c->uploaded) return M17HIP_ESTATE;
     // operator-level call: always from a fresh DFT state at stream position 0
     HIPCHK(c, hipMemsetAsync(c->dcd_state, 0, (size_t)C * sizeof(DcdState), c->stream));
@@ -736,6 +786,7 @@ int m17hip_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* sum
 int m17hip_viterbi(m17hip_ctx* c, const int8_t* soft_host, uint32_t n, int kind, uint8_t* bits_host, int32_t* cost_host)
 {
     if (!c || !soft_host || n == 0 || kind < 0 || kind > 3) return M17HIP_EINVAL;
+    GUARD(c);
     static const int IN[4] = {488, 296, 420, 402}, OUT[4] = {240, 144, 206, 197};
     const size_t in_b = (size_t)n * IN[kind], out_b = (size_t)n * OUT[kind];
     const size_t o1 = round_up(in_b, 256), o2 = o1 + round_up(out_b, 256);
@@ -758,6 +809,7 @@ int m17hip_viterbi(m17hip_ctx* c, const int8_t* soft_host, uint32_t n, int kind,
 int m17hip_slice_llr(m17hip_ctx* c, const float* sym_host, uint32_t rows, uint32_t n, int8_t* llr_host, float* evm_host)
 {
     if (!c || !sym_host || rows == 0 || n == 0) return M17HIP_EINVAL;
+    GUARD(c);
     const size_t cnt = (size_t)rows * n;
     const size_t o1 = round_up(cnt * 4, 256), o2 = o1 + round_up(cnt * 2, 256);
     int r = ensure_scratch(c, o2 + cnt * 4);
@@ -778,6 +830,7 @@ int m17hip_decode_frames(m17hip_ctx* c, const int8_t* llr368_host, uint32_t n, c
 {
     if (!c || !llr368_host || !sync_type || !state_io || !lich_io || !lsf_io || !dep401_io || !cost_io || !recs || !nrec || n == 0)
         return M17HIP_EINVAL;
+    GUARD(c);
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += round_up(bytes, 256); return o; };
     const size_t o_llr = take((size_t)n * 368), o_st = take(n), o_state = take(n), o_lich = take(n), o_lsf = take((size_t)n * 30),
@@ -815,13 +868,17 @@ int m17hip_decode_frames(m17hip_ctx* c, const int8_t* llr368_host, uint32_t n, c
 int m17hip_demod_reset(m17hip_ctx* c)
 {
     if (!c) return M17HIP_EINVAL;
+    GUARD(c);
     hipLaunchKernelGGL(seq_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->dcd_state, c->maxC);
+    HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(zero_prefix_kernel, dim3(c->maxC), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, c->maxC);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemset2DAsync(c->hbuf, c->ypitch * sizeof(float), 0, YPRE * sizeof(float), c->maxC, c->stream));
     hipLaunchKernelGGL(bert_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, (BertState*)c->bert_state, c->maxC);
+    HIPCHK(c, hipGetLastError());
     if (c->pkt_cap) {
         hipLaunchKernelGGL(packet_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, (PacketState*)c->pkt_state, c->maxC);
+        HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
     }
     HIPCHK(c, hipMemsetAsync(c->rec_count, 0, (size_t)c->maxC * 4, c->stream));
@@ -834,6 +891,7 @@ int m17hip_demod_reset(m17hip_ctx* c)
 int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    GUARD(c);
     if (c->staged) {   // input staged by m17hip_upload_i16_async: swap the slabs, move the carried tail over
         if (C != c->stagedC || T != c->stagedT) return M17HIP_EINVAL;
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
@@ -933,6 +991,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         P.recs = c->recs; P.rec_cap = c->rec_cap; P.rec_count = c->rec_count; P.overflow = c->overflow;
         P.tables = c->tables; P.taps = c->taps; P.llr_edges = c->llr_edges;
         P.C = C; P.T = len; P.pos0 = c->pos + t0; P.tick_row0 = c->pos / TICK; P.flags = (flags & 1u) | (t0 ? 2u : 0u);
+        P.kalman_order = c->kalman_order; P.channel_base = c->channel_base;
         // one wave per channel; `seq_lanes` (tuning knob 0) = waves per workgroup
         const uint32_t wpb = (c->seq_lanes && !c->profile) ? c->seq_lanes : 4;  // the profiling build exists for 4 waves per workgroup
         const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
@@ -955,7 +1014,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     if (c->pkt_cap) {   // payload consumer: packet reassembly over this run's packet records
         HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
         hipLaunchKernelGGL(packet_asm_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->recs, c->rec_cap, c->rec_count, (PacketState*)c->pkt_state, C,
-                           (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count);
+                           (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count, c->channel_base);
     }
     hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
     if (c->speculate) hipLaunchKernelGGL(carry_tail_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->hbuf, c->ypitch, T);
@@ -966,16 +1025,21 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     return M17HIP_OK;
 }
 
+// Offsets + (optionally) the dense copy in one pass and ONE stream synchronisation.  *count = records the run produced;
+// at most `cap` of them are written.  M17HIP_EOVERFLOW: a channel outran its record slots during the run;
+// M17HIP_ETRUNC: more records than `cap`.
 static int compact_into(m17hip_ctx* c, FrameRec* dev_out, uint64_t cap, uint64_t* count)
 {
     const uint32_t C = c->lastC;
     {
         Timed tm(c, KT_COMPACT);
         hipLaunchKernelGGL(rec_offsets_kernel, dim3(1), dim3(256), 0, c->stream, c->rec_count, c->rec_cap, c->rec_offsets, C);
-        if (dev_out)
+        HIPCHK(c, hipGetLastError());
+        if (dev_out) {
             hipLaunchKernelGGL(compact_kernel, dim3(C), dim3(64), 0, c->stream, c->recs, c->rec_cap, c->rec_count, c->rec_offsets, dev_out, cap, C);
+            HIPCHK(c, hipGetLastError());
+        }
     }
-    HIPCHK(c, hipGetLastError());
     uint64_t total = 0;
     uint32_t ovf = 0;
     HIPCHK(c, hipMemcpyAsync(&total, c->rec_offsets + C, 8, hipMemcpyDeviceToHost, c->stream));
@@ -983,12 +1047,14 @@ static int compact_into(m17hip_ctx* c, FrameRec* dev_out, uint64_t cap, uint64_t
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (count) *count = total;
     if (ovf) return M17HIP_EOVERFLOW;
+    if (dev_out && total > cap) return M17HIP_ETRUNC;
     return M17HIP_OK;
 }
 
 int m17hip_frames_count(m17hip_ctx* c, uint64_t* total)
 {
     if (!c || !total) return M17HIP_EINVAL;
+    GUARD(c);
     if (!c->have_run) return M17HIP_ESTATE;
     return compact_into(c, nullptr, 0, total);
 }
@@ -996,6 +1062,7 @@ int m17hip_frames_count(m17hip_ctx* c, uint64_t* total)
 int m17hip_frames_compact_device(m17hip_ctx* c, m17_frame_rec* recs_dev, uint64_t capacity, uint64_t* count)
 {
     if (!c || !recs_dev) return M17HIP_EINVAL;
+    GUARD(c);
     if (!c->have_run) return M17HIP_ESTATE;
     return compact_into(c, (FrameRec*)recs_dev, capacity, count);
 }
@@ -1003,27 +1070,30 @@ int m17hip_frames_compact_device(m17hip_ctx* c, m17_frame_rec* recs_dev, uint64_
 int m17hip_frames_fetch(m17hip_ctx* c, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* count)
 {
     if (!c || !recs_host) return M17HIP_EINVAL;
+    GUARD(c);
     if (!c->have_run) return M17HIP_ESTATE;
-    uint64_t total = 0;
-    int r = compact_into(c, nullptr, 0, &total);
-    if (r && r != M17HIP_EOVERFLOW) return r;
-    if (total > c->compact_cap) {
+    // one compaction into the context's dense buffer; it is sized for the caller's capacity (records beyond it are not
+    // wanted anyway), so a second pass is never needed
+    const uint64_t want = std::max<uint64_t>(std::min<uint64_t>(capacity, (uint64_t)c->lastC * c->rec_cap), 1024);
+    if (want > c->compact_cap) {
         if (c->compact) hipFree(c->compact);
         c->compact = nullptr; c->compact_cap = 0;
-        HIPCHK(c, hipMalloc((void**)&c->compact, (size_t)std::max<uint64_t>(total, 1024) * sizeof(FrameRec)));
-        c->compact_cap = std::max<uint64_t>(total, 1024);
+        HIPCHK(c, hipMalloc((void**)&c->compact, (size_t)want * sizeof(FrameRec)));
+        c->compact_cap = want;
     }
-    int r2 = total ? compact_into(c, c->compact, c->compact_cap, &total) : M17HIP_OK;
-    if (r2 && r2 != M17HIP_EOVERFLOW) return r2;
+    uint64_t total = 0;
+    const int r = compact_into(c, c->compact, std::min<uint64_t>(capacity, c->compact_cap), &total);
+    if (r && r != M17HIP_EOVERFLOW && r != M17HIP_ETRUNC) return r;
     const uint64_t n = std::min(total, capacity);
     if (n) HIPCHK(c, hipMemcpy(recs_host, c->compact, (size_t)n * sizeof(FrameRec), hipMemcpyDeviceToHost));
     if (count) *count = total;
-    return r ? r : r2;
+    return r;
 }
 
 int m17hip_diag_fetch(m17hip_ctx* c, m17_diag* diag_host, uint32_t C)
 {
     if (!c || !diag_host || C == 0 || C > c->maxC) return M17HIP_EINVAL;
+    GUARD(c);
     HIPCHK(c, hipMemcpy2DAsync(diag_host, sizeof(Diag), &c->seq_state[0].cold.diag, sizeof(SeqState), sizeof(Diag), C, hipMemcpyDeviceToHost,
                                c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1033,6 +1103,7 @@ int m17hip_diag_fetch(m17hip_ctx* c, m17_diag* diag_host, uint32_t C)
 int m17hip_lsf_info(m17hip_ctx* c, const uint8_t* lsf30_host, uint32_t n, m17_lsf_info* out_host)
 {
     if (!c || !lsf30_host || !out_host || n == 0) return M17HIP_EINVAL;
+    GUARD(c);
     static_assert(sizeof(LsfInfo) == sizeof(m17_lsf_info) && sizeof(LsfInfo) == 32, "m17_lsf_info layout");
     const size_t in_b = round_up((size_t)n * 30, 256);
     int r = ensure_scratch(c, in_b + (size_t)n * sizeof(LsfInfo));
@@ -1050,6 +1121,7 @@ int m17hip_lsf_info(m17hip_ctx* c, const uint8_t* lsf30_host, uint32_t n, m17_ls
 int m17hip_bert_stats(m17hip_ctx* c, m17_bert_stat* stats_host, uint32_t C)
 {
     if (!c || !stats_host || C == 0 || C > c->maxC) return M17HIP_EINVAL;
+    GUARD(c);
     if (!c->bert) return M17HIP_ESTATE;
     std::vector<BertState> tmp(C);
     HIPCHK(c, hipMemcpyAsync(tmp.data(), c->bert_state, (size_t)C * sizeof(BertState), hipMemcpyDeviceToHost, c->stream));
@@ -1064,6 +1136,7 @@ int m17hip_bert_stats(m17hip_ctx* c, m17_bert_stat* stats_host, uint32_t C)
 int m17hip_packets_feed(m17hip_ctx* c, const m17_frame_rec* recs_host, const uint32_t* counts_host, uint32_t C, uint32_t pitch)
 {
     if (!c || !recs_host || !counts_host || C == 0 || C > c->maxC || pitch == 0) return M17HIP_EINVAL;
+    GUARD(c);
     if (!c->pkt_cap) return M17HIP_ESTATE;
     const size_t rec_b = round_up((size_t)C * pitch * sizeof(FrameRec), 256);
     int r = ensure_scratch(c, rec_b + (size_t)C * 4);
@@ -1074,7 +1147,7 @@ int m17hip_packets_feed(m17hip_ctx* c, const m17_frame_rec* recs_host, const uin
     HIPCHK(c, hipMemcpyAsync(dcnt, counts_host, (size_t)C * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
     hipLaunchKernelGGL(packet_asm_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, drec, pitch, dcnt, (PacketState*)c->pkt_state, C,
-                       (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count);
+                       (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count, c->channel_base);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));   // the host buffers may go away
     c->pkt_fed = true;
@@ -1084,6 +1157,7 @@ int m17hip_packets_feed(m17hip_ctx* c, const m17_frame_rec* recs_host, const uin
 int m17hip_packets_fetch(m17hip_ctx* c, m17_packet_rec* recs_host, uint32_t capacity, uint32_t* count)
 {
     if (!c || !count || (capacity && !recs_host)) return M17HIP_EINVAL;
+    GUARD(c);
     static_assert(sizeof(PacketRec) == sizeof(m17_packet_rec) && sizeof(PacketRec) == 864, "m17_packet_rec layout");
     if (!c->pkt_cap || !(c->have_run || c->pkt_fed)) return M17HIP_ESTATE;
     uint32_t total = 0;
@@ -1099,9 +1173,160 @@ int m17hip_packets_fetch(m17hip_ctx* c, m17_packet_rec* recs_host, uint32_t capa
     return total > c->pkt_cap ? M17HIP_EOVERFLOW : M17HIP_OK;
 }
 
+int m17hip_set_kalman_order(m17hip_ctx* c, int order)
+{
+    if (!c || order < 0 || order > 7) return M17HIP_EINVAL;
+    c->kalman_order = (uint32_t)order;
+    return M17HIP_OK;
+}
+
+int m17hip_set_channel_base(m17hip_ctx* c, uint32_t channel_base)
+{
+    if (!c) return M17HIP_EINVAL;
+    c->channel_base = channel_base;
+    return M17HIP_OK;
+}
+
+int m17hip_kalman_trace(m17hip_ctx* c, const float* z_host, const uint32_t* dt_host, uint32_t rows, uint32_t n, int wrap, float z0, int order,
+                        float* out_host)
+{
+    if (!c || !z_host || !dt_host || !out_host || rows == 0 || n == 0 || order < 0 || order > 7 || (wrap != 0 && wrap != 10)) return M17HIP_EINVAL;
+    GUARD(c);
+    const size_t cnt = (size_t)rows * n;
+    const size_t o1 = round_up(cnt * 4, 256), o2 = o1 + round_up(cnt * 4, 256);
+    int r = ensure_scratch(c, o2 + cnt * 24);
+    if (r) return r;
+    char* b = (char*)c->scratch;
+    HIPCHK(c, hipMemcpyAsync(b, z_host, cnt * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o1, dt_host, cnt * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(kalman_kernel, dim3((rows + 63) / 64), dim3(64), 0, c->stream, (const float*)b, (const uint32_t*)(b + o1), rows, n, wrap, z0,
+                       (uint32_t)order, (float*)(b + o2));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out_host, b + o2, cnt * 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M17HIP_OK;
+}
+
+int m17hip_upload_wait(m17hip_ctx* c)
+{
+    if (!c) return M17HIP_EINVAL;
+    GUARD(c);
+    if (c->ev_copy) HIPCHK(c, hipEventSynchronize(c->ev_copy));
+    return M17HIP_OK;
+}
+
+// ---- multi-GPU: gather of the frame records over RCCL ------------------------------------------------------------------
+int m17hip_comm_get_id(void* id128)
+{
+    if (!id128) return M17HIP_EINVAL;
+    const Rccl& R = rccl();
+    if (!R.ok) return M17HIP_ECOMM;
+    static_assert(sizeof(ncclUniqueId) == M17HIP_COMM_ID_BYTES, "RCCL unique id size");
+    ncclUniqueId id;
+    if (R.GetUniqueId(&id) != ncclSuccess) return M17HIP_ECOMM;
+    std::memcpy(id128, &id, sizeof(id));
+    return M17HIP_OK;
+}
+
+int m17hip_comm_create(m17hip_ctx* c, const void* id128, int rank, int nranks, m17hip_comm** out)
+{
+    if (!c || !id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) return M17HIP_EINVAL;
+    GUARD(c);
+    const Rccl& R = rccl();
+    if (!R.ok) return M17HIP_ECOMM;
+    m17hip_comm* m = new (std::nothrow) m17hip_comm();
+    if (!m) return M17HIP_ENOMEM;
+    m->ctx = c; m->rank = rank; m->nranks = nranks;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    const ncclResult_t r = R.CommInitRank(&m->comm, nranks, id, rank);
+    if (r != ncclSuccess) { m->last_rccl = (int)r; delete m; return M17HIP_ECOMM; }
+    const hipError_t e = hipMalloc((void**)&m->counts_dev, (size_t)nranks * sizeof(uint64_t));
+    if (e != hipSuccess) { c->last_hip = (int)e; R.CommDestroy(m->comm); delete m; return M17HIP_ENOMEM; }
+    *out = m;
+    return M17HIP_OK;
+}
+
+void m17hip_comm_destroy(m17hip_comm* m)
+{
+    if (!m) return;
+    DeviceGuard guard_(m->ctx);
+    if (m->counts_dev) hipFree(m->counts_dev);
+    if (m->gathered) hipFree(m->gathered);
+    if (m->comm) rccl().CommDestroy(m->comm);
+    delete m;
+}
+
+int m17hip_gather_frames(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* counts_host,
+                         uint64_t* total_out)
+{
+    if (!c || !m || m->ctx != c || root < 0 || root >= m->nranks || (m->rank == root && capacity && !recs_host)) return M17HIP_EINVAL;
+    GUARD(c);
+    if (!c->have_run) return M17HIP_ESTATE;
+    const Rccl& R = rccl();
+    // 1. this rank's records, dense and (channel, seq)-ordered, in the context's compaction buffer
+    uint64_t mine = 0;
+    int r = compact_into(c, c->compact, c->compact_cap, &mine);
+    if (r == M17HIP_ETRUNC || (r == M17HIP_OK && !c->compact && mine)) {
+        if (c->compact) hipFree(c->compact);
+        c->compact = nullptr; c->compact_cap = 0;
+        const uint64_t want = std::max<uint64_t>(mine + mine / 8, 1024);
+        HIPCHK(c, hipMalloc((void**)&c->compact, (size_t)want * sizeof(FrameRec)));
+        c->compact_cap = want;
+        r = compact_into(c, c->compact, c->compact_cap, &mine);
+    }
+    const bool overflow = r == M17HIP_EOVERFLOW;
+    if (r && !overflow) return r;
+    // 2. every rank learns every rank's count
+#define RCCLCHK(expr) do { const ncclResult_t q_ = (expr); if (q_ != ncclSuccess) { m->last_rccl = (int)q_; return M17HIP_ECOMM; } } while (0)
+    std::vector<uint64_t> counts((size_t)m->nranks, 0);
+    HIPCHK(c, hipMemcpyAsync(m->counts_dev + m->rank, &mine, 8, hipMemcpyHostToDevice, c->stream));
+    RCCLCHK(R.AllGather(m->counts_dev + m->rank, m->counts_dev, 1, ncclUint64, m->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(counts.data(), m->counts_dev, (size_t)m->nranks * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t total = 0;
+    for (uint64_t v : counts) total += v;
+    if (counts_host) std::memcpy(counts_host, counts.data(), counts.size() * 8);
+    if (total_out) *total_out = total;
+    // 3. the records travel to the root with their exact sizes, rank after rank = global channel order
+    if (m->rank == root) {
+        if (total > m->gathered_cap) {
+            if (m->gathered) hipFree(m->gathered);
+            m->gathered = nullptr; m->gathered_cap = 0;
+            const uint64_t want = std::max<uint64_t>(total + total / 8, 1024);
+            HIPCHK(c, hipMalloc((void**)&m->gathered, (size_t)want * sizeof(FrameRec)));
+            m->gathered_cap = want;
+        }
+        RCCLCHK(R.GroupStart());
+        uint64_t off = 0;
+        for (int k = 0; k < m->nranks; ++k) {
+            if (k != root && counts[k]) RCCLCHK(R.Recv(m->gathered + off, (size_t)counts[k] * sizeof(FrameRec), ncclUint8, k, m->comm, c->stream));
+            if (k == root && mine) HIPCHK(c, hipMemcpyAsync(m->gathered + off, c->compact, (size_t)mine * sizeof(FrameRec), hipMemcpyDeviceToDevice, c->stream));
+            off += counts[k];
+        }
+        RCCLCHK(R.GroupEnd());
+        const uint64_t n = std::min(total, capacity);
+        if (n) HIPCHK(c, hipMemcpyAsync(recs_host, m->gathered, (size_t)n * sizeof(FrameRec), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (overflow) return M17HIP_EOVERFLOW;
+        return total > capacity ? M17HIP_ETRUNC : M17HIP_OK;
+    }
+    if (mine) {
+        RCCLCHK(R.GroupStart());
+        RCCLCHK(R.Send(c->compact, (size_t)mine * sizeof(FrameRec), ncclUint8, root, m->comm, c->stream));
+        RCCLCHK(R.GroupEnd());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+#undef RCCLCHK
+    return overflow ? M17HIP_EOVERFLOW : M17HIP_OK;
+}
+
+int m17hip_comm_last_error(const m17hip_comm* m) { return m ? m->last_rccl : 0; }
+
 int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
 {
     if (!c) return M17HIP_EINVAL;
+    GUARD(c);
     switch (key) {
     case 0:  // waves (= channels) per workgroup of the sequential kernel: 0 (default 4), 1, 2, 4 or 8
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return M17HIP_EINVAL;
@@ -1141,6 +1366,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         HIPCHK(c, hipGetLastError());
         return M17HIP_OK;
     }
+    case 8:  // record slots per channel and run actually used (0 = all that were allocated): exercises M17HIP_EOVERFLOW
+        if (value < 0 || value > (int64_t)c->rec_cap_alloc) return M17HIP_EINVAL;
+        c->rec_cap = value ? (uint32_t)value : c->rec_cap_alloc;
+        return M17HIP_OK;
     case 4:  // samples of the first segment of a run (0 = like the others)
         if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
         c->seg0_len = (uint32_t)value;
@@ -1152,6 +1381,7 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
 int m17hip_debug_counters(m17hip_ctx* c, uint64_t* host, uint32_t max_waves, uint32_t* waves)
 {
     if (!c || !host || !waves) return M17HIP_EINVAL;
+    GUARD(c);
     const uint32_t n = std::min(max_waves, c->dbg_waves);
     HIPCHK(c, hipMemcpy(host, c->dbg, (size_t)n * 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     *waves = n;
@@ -1161,6 +1391,7 @@ int m17hip_debug_counters(m17hip_ctx* c, uint64_t* host, uint32_t max_waves, uin
 int m17hip_timing_enable(m17hip_ctx* c, int on)
 {
     if (!c) return M17HIP_EINVAL;
+    GUARD(c);
     drain_timing(c);
     c->timing = on != 0;
     return M17HIP_OK;
@@ -1168,6 +1399,7 @@ int m17hip_timing_enable(m17hip_ctx* c, int on)
 int m17hip_timing_get(m17hip_ctx* c, int which, double* total_ms, uint64_t* launches)
 {
     if (!c || which < 0 || which >= KT_N) return M17HIP_EINVAL;
+    GUARD(c);
     drain_timing(c);
     if (total_ms) *total_ms = c->acc_ms[which];
     if (launches) *launches = c->acc_n[which];
@@ -1176,6 +1408,7 @@ int m17hip_timing_get(m17hip_ctx* c, int which, double* total_ms, uint64_t* laun
 int m17hip_timing_reset(m17hip_ctx* c)
 {
     if (!c) return M17HIP_EINVAL;
+    GUARD(c);
     drain_timing(c);
     for (int k = 0; k < KT_N; ++k) { c->acc_ms[k] = 0; c->acc_n[k] = 0; }
     return M17HIP_OK;

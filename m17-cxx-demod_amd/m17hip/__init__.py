@@ -37,7 +37,11 @@ EXPORTS = [
     "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_upload_i16_async", "m17hip_synth_i16", "m17hip_download_i16", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_dcd", "m17hip_viterbi",
     "m17hip_slice_llr", "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_packets_fetch", "m17hip_packets_feed", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
+    "m17hip_set_kalman_order", "m17hip_kalman_trace", "m17hip_set_channel_base", "m17hip_upload_wait", "m17hip_comm_get_id", "m17hip_comm_create",
+    "m17hip_comm_destroy", "m17hip_comm_last_error", "m17hip_gather_frames",
 ]
+ETRUNC = -6
+COMM_ID_BYTES = 128
 
 
 class M17HipError(RuntimeError):
@@ -56,12 +60,37 @@ def load_library():
                               "there is no CPU fallback for the demodulation hot path")
         lib = C.CDLL(LIB_PATH)
         lib.m17hip_strerror.restype = C.c_char_p
+        lib.m17hip_comm_destroy.restype = None
+        lib.m17hip_ctx_destroy.restype = None
         _lib = lib
     return _lib
 
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def comm_get_id():
+    """128-byte RCCL id (rank 0 calls this and hands the bytes to the other ranks)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    code = load_library().m17hip_comm_get_id(buf)
+    if code != 0:
+        raise M17HipError(f"m17hip_comm_get_id: {load_library().m17hip_strerror(C.c_int(code)).decode()}")
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of one rank (one context = one GPU = one rank); creation is collective."""
+
+    def __init__(self, ctx, comm_id, rank, nranks):
+        self.lib, self.ctx, self.rank, self.nranks = ctx.lib, ctx, int(rank), int(nranks)
+        self.h = C.c_void_p()
+        ctx._chk(self.lib.m17hip_comm_create(ctx.h, C.c_char_p(bytes(comm_id)), C.c_int(rank), C.c_int(nranks), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.m17hip_comm_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 class Context:
@@ -107,6 +136,10 @@ class Context:
         self.C, self.T = int(channels), int(samples)
         self._chk(self.lib.m17hip_upload_i16_async(self.h, C.c_void_p(int(host_ptr)), C.c_uint32(self.C), C.c_uint32(self.T),
                                                    C.c_size_t(self.T if pitch is None else pitch)))
+
+    def upload_wait(self):
+        """Block until the copy queued by upload_async has left the host buffer."""
+        self._chk(self.lib.m17hip_upload_wait(self.h))
 
     def synth(self, params, channels, samples, chan0=0):
         """Generate the input slab on the device (m17-mod framing + impairments); `params` = a ctypes block laid out as m17_synth_params."""
@@ -177,7 +210,38 @@ class Context:
                                                 _ptr(cost), _ptr(recs), _ptr(nrec)))
         return recs, nrec, state, lich, lsf, dep401, cost
 
+    def kalman_trace(self, z, dt, wrap, z0=0.0, order=3):
+        """rows x n updates of the 2-state Kalman filter (kal_update, as the full-chain kernel runs it): state after each update."""
+        zz = np.ascontiguousarray(z, dtype=np.float32)
+        if zz.ndim == 1:
+            zz = zz[None, :]
+        dd = np.ascontiguousarray(np.broadcast_to(dt, zz.shape), dtype=np.uint32)
+        out = np.empty(zz.shape + (6,), dtype=np.float32)
+        self._chk(self.lib.m17hip_kalman_trace(self.h, _ptr(zz), _ptr(dd), C.c_uint32(zz.shape[0]), C.c_uint32(zz.shape[1]), C.c_int(wrap),
+                                               C.c_float(z0), C.c_int(order), _ptr(out)))
+        return out
+
     # ---- the full chain ----------------------------------------------------------------------------------------------
+    def set_kalman_order(self, order):
+        """Evaluation order of the Kalman updates (bit set, include/m17hip.h); default 3."""
+        self._chk(self.lib.m17hip_set_kalman_order(self.h, C.c_int(order)))
+
+    def set_channel_base(self, base):
+        """Global id of this context's channel 0: frame records carry channel = base + local index."""
+        self._chk(self.lib.m17hip_set_channel_base(self.h, C.c_uint32(base)))
+
+    def gather_frames(self, comm, root=0, capacity=None):
+        """Collective: the records of the last run of every rank, gathered to `root` over RCCL in rank (= channel) order.
+        Returns (records or None off the root, counts per rank)."""
+        counts = np.zeros(comm.nranks, dtype=np.uint64)
+        total = C.c_uint64(0)
+        is_root = comm.rank == root
+        if capacity is None:
+            capacity = comm.nranks * self.max_channels * (2 * (self.max_samples // 1920 + 2) + 4) if is_root else 0
+        recs = np.empty(capacity, dtype=FRAME_REC) if is_root else None
+        self._chk(self.lib.m17hip_gather_frames(self.h, comm.h, C.c_int(root), _ptr(recs), C.c_uint64(capacity), _ptr(counts), C.byref(total)))
+        return (recs[: total.value] if is_root else None), counts
+
     def reset(self):
         self._chk(self.lib.m17hip_demod_reset(self.h))
 

@@ -141,6 +141,22 @@ void m17o_llr_table(float* edges43, int8_t* l0, int8_t* l1)
     for (int i = 0; i < 43; ++i) { edges43[i] = t.edge[i]; l0[i] = t.l0[i]; l1[i] = t.l1[i]; }
 }
 // Kalman-based estimators (parity unpinned) — exposed so the HIP path can be compared with them.
+// Evaluation order of the blaze expressions of KalmanFilter.h:49-64 (bit set, see m17_oracle_dsp.hpp); process-wide,
+// set it before starting a batch.
+void m17o_set_kalman_order(int order) { kalman_order() = order & 7; }
+int m17o_get_kalman_order(void) { return kalman_order(); }
+// One filter, n updates: z[i] after dt[i] samples; wrap = 10 (KalmanFilter<float,10>) or 0 (SymbolKalmanFilter).
+// out[i][6] = x0, x1, P00, P01, P10, P11 after update i.
+void m17o_kalman_trace(const float* z, const uint32_t* dt, size_t n, int wrap, float z0, float* out)
+{
+    Kalman2 k;
+    k.reset(z0);
+    for (size_t i = 0; i < n; ++i) {
+        k.update(z[i], dt[i], wrap);
+        float* o = out + 6 * i;
+        o[0] = k.x[0]; o[1] = k.x[1]; o[2] = k.P[0][0]; o[3] = k.P[0][1]; o[4] = k.P[1][0]; o[5] = k.P[1][1];
+    }
+}
 void m17o_freqdev(const float* mn, const float* mx, size_t n, const uint8_t* reset_before, float* idev, float* offset)
 {
     FreqDevEstimator d;

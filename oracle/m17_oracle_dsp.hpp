@@ -306,12 +306,30 @@ struct LlrTable {
 inline const LlrTable& llr_table() { static const LlrTable t; return t; }
 
 // ---------------------------------------------------------------------------
-// a9/a10: Kalman filters — PARITY UNPINNED (blaze absent).  Semantics chosen:
-// every blaze expression evaluated eagerly, element type = std::common_type of
-// the operands (so `* (1.0 / S)` promotes to double), results narrowed on
-// assignment to the float members.  Reference call sites: KalmanFilter.h:18-108,
-// ClockRecovery.h:16-111, FreqDevEstimator.h:14-54.
+// a9/a10: Kalman filters — PARITY UNPINNED (blaze, the reference's linear-algebra dependency, is absent from
+// /root/reference: `.gitmodules:1-3`, empty submodule, pinned version unknown).  Reference call sites:
+// KalmanFilter.h:18-108, ClockRecovery.h:16-111, FreqDevEstimator.h:14-54.
+//
+// KalmanFilter.h:49-64 keeps `S` and `K` as `auto`, i.e. as lazy blaze expression templates, so how the products are
+// associated and where they are rounded is decided by blaze's restructuring operators, not by the source text.  The
+// evaluation order is therefore a switch (kalman_order(), bit set), the same one the HIP path has
+// (m17hip_set_kalman_order):
+//   bit 0  x += K*y   : 1 = blaze's `(A*s)*v -> (A*v)*s` and `(A*B)*v -> A*(B*v)`: t = fl32(P(:,0)*y), x += double(t)*invS
+//                        0 = eager K = double(P(:,0))*invS, x += K*double(y)
+//   bit 1  P -= K*H*P : 1 = blaze's `(A*s)*B -> (A*B)*s` twice: T = fl32(P(i,0)*P(0,j)), P -= double(T)*invS
+//                        0 = eager (K*H)*P in double
+//   bit 2  F*P*F^T    : 0 = (F*P)*F^T as C++ parses it (blaze evaluates the left product into a float temporary)
+//                        1 = F*(P*F^T)
+// All variants share: element type of a product = common type of its operands (`* (1.0 / S(0,0))` promotes to double),
+// results narrowed when assigned to the float members, S(0,0) = P(0,0) + R in float.
+// Default 3 = what blaze's documented restructuring rules give.  tools/kalman_sensitivity.py measures how many frame
+// records the choice can move.
 // ---------------------------------------------------------------------------
+#ifndef M17O_KALMAN_ORDER
+#define M17O_KALMAN_ORDER 3
+#endif
+inline int& kalman_order() { static int v = M17O_KALMAN_ORDER; return v; }
+
 struct Kalman2 {
     float x[2], P[2][2], F[2][2];
     float Q[2][2] = {{(float)6.25e-13, (float)1.25e-12}, {(float)1.25e-12, (float)2.50e-12}};
@@ -326,6 +344,7 @@ struct Kalman2 {
     // wrap != 0: KalmanFilter<float,SPS> (index filter, modulo SPS); 0: SymbolKalmanFilter.
     void update(float z, size_t dt, int wrap)
     {
+        const int order = kalman_order();
         F[0][1] = (float)dt;
         // x = F * x
         float nx0 = F[0][0] * x[0] + F[0][1] * x[1];
@@ -333,10 +352,17 @@ struct Kalman2 {
         x[0] = nx0; x[1] = nx1;
         // P = F * P * trans(F) + Q
         float A[2][2], B[2][2];
-        for (int i = 0; i < 2; ++i)
-            for (int j = 0; j < 2; ++j) A[i][j] = F[i][0] * P[0][j] + F[i][1] * P[1][j];
-        for (int i = 0; i < 2; ++i)
-            for (int j = 0; j < 2; ++j) B[i][j] = A[i][0] * F[j][0] + A[i][1] * F[j][1];
+        if (!(order & 4)) {
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) A[i][j] = F[i][0] * P[0][j] + F[i][1] * P[1][j];
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) B[i][j] = A[i][0] * F[j][0] + A[i][1] * F[j][1];
+        } else {
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) A[i][j] = P[i][0] * F[j][0] + P[i][1] * F[j][1];
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) B[i][j] = F[i][0] * A[0][j] + F[i][1] * A[1][j];
+        }
         for (int i = 0; i < 2; ++i)
             for (int j = 0; j < 2; ++j) P[i][j] = B[i][j] + Q[i][j];
         // S = H * P * trans(H) + R, H = [1 0]
@@ -353,18 +379,35 @@ struct Kalman2 {
             else if ((double)(z - x[0]) > (wrap / 2.0)) z -= wrap;
         }
         float y = z - (1.f * x[0] + 0.f * x[1]);
-        x[0] = (float)((double)x[0] + K0 * (double)y);
-        x[1] = (float)((double)x[1] + K1 * (double)y);
+        if (order & 1) {
+            const float hy0 = 1.f * y, hy1 = 0.f * y;              // trans(H) * y
+            const float t0 = P[0][0] * hy0 + P[0][1] * hy1;         // P * (trans(H) * y), float
+            const float t1 = P[1][0] * hy0 + P[1][1] * hy1;
+            x[0] = (float)((double)x[0] + (double)t0 * invS);
+            x[1] = (float)((double)x[1] + (double)t1 * invS);
+        } else {
+            x[0] = (float)((double)x[0] + K0 * (double)y);
+            x[1] = (float)((double)x[1] + K1 * (double)y);
+        }
         if (wrap) {
             while (x[0] >= wrap) x[0] -= wrap;
             while (x[0] < 0) x[0] += wrap;
         }
         // P = P - K * H * P
-        double KH[2][2] = {{K0 * 1.0, K0 * 0.0}, {K1 * 1.0, K1 * 0.0}};
         float NP[2][2];
-        for (int i = 0; i < 2; ++i)
-            for (int j = 0; j < 2; ++j)
-                NP[i][j] = (float)((double)P[i][j] - (KH[i][0] * (double)P[0][j] + KH[i][1] * (double)P[1][j]));
+        if (order & 2) {
+            const float G[2][2] = {{ph0 * 1.f, ph0 * 0.f}, {ph1 * 1.f, ph1 * 0.f}};   // (P * trans(H)) * H, float
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) {
+                    const float t = G[i][0] * P[0][j] + G[i][1] * P[1][j];            // (...) * P, float
+                    NP[i][j] = (float)((double)P[i][j] - (double)t * invS);
+                }
+        } else {
+            double KH[2][2] = {{K0 * 1.0, K0 * 0.0}, {K1 * 1.0, K1 * 0.0}};
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j)
+                    NP[i][j] = (float)((double)P[i][j] - (KH[i][0] * (double)P[0][j] + KH[i][1] * (double)P[1][j]));
+        }
         std::memcpy(P, NP, sizeof(P));
     }
 };

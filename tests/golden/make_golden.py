@@ -123,6 +123,27 @@ def main():
             recs, state, lich, lsf, d401, cost = ol.decode_frame(st, fr, state, lich, lsf, d401, cost, lib=R, prefix="ref_")
             seqs.append(dict(seed=seed, f=f, st=st, llr=fr.tolist(), state=int(state), lich=int(lich), lsf=lsf.tolist(), d401=int(d401),
                              cost=int(cost), recs=[(int(r["frame_type"]), int(r["cost"]), int(r["len"]), bytes(r["payload"]).hex()) for r in recs]))
+    # --- more front-end sets (round 2): inverted input, DC offset + low gain, a window of exact zeros (DCD NaN) ----
+    extra = {
+        "inv_": (ol.gen_params(seed=31, kind=0, n_frames=2, lead_in=900, noise_sigma=700, tail=200, tail_sigma=700, lead_sigma=40000.0, invert=1), 1),
+        "dc_": (ol.gen_params(seed=32, kind=2, n_frames=2, lead_in=500, noise_sigma=300, tail=400, tail_sigma=300, lead_sigma=20000.0,
+                              dc_offset=-1500.0, gain=0.6), 0),
+        "zero_": (ol.gen_params(seed=33, kind=1, n_frames=2, lead_in=0, noise_sigma=0, tail=0, tail_sigma=0), 0),
+    }
+    for tag, (gp, inv) in extra.items():
+        s2 = ol.generate(gp)[:6000].copy()
+        if tag == "zero_":
+            s2[:768] = 0               # the stream opens with two whole 384-sample update windows of digital silence
+        x2 = ol.scale(s2, invert=inv)
+        y2 = np.zeros_like(x2)
+        R.ref_fir_f32(ol._p(taps), ol._p(x2), C.c_size_t(x2.size), ol._p(y2))
+        out[tag + "sig_i16"], out[tag + "fir_out"] = s2, y2
+        out[tag + "corr_limit"], out[tag + "corr_values"] = ol.correlator(y2, lib=R, prefix="ref_")
+        for period in (384, 960):
+            out[f"{tag}dcd{period}_level"], out[f"{tag}dcd{period}_trig"] = ol.dcd_trace(x2, period, lib=R, prefix="ref_")
+        out[tag + "dcd_sums"] = np.array([(st, ln) + ol.dcd_sums(x2, st, ln, lib=R, prefix="ref_")
+                                          for (st, ln) in ((0, 384), (384, 384), (1920, 384), (2304, 960), (4800, 960))], dtype=np.float64)
+    assert np.isnan(out["zero_dcd384_level"]).any(), "the zero-window set must poison the DCD level"
     np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **out)
 
     # --- literal KAT vectors from the reference's own unit tests ---------------------------------

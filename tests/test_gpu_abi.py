@@ -1,0 +1,229 @@
+"""GPU: C-ABI behaviour beyond the happy path — error codes, truncation, overflow, buffer lifetimes, the device guard, global
+channel ids and the RCCL gather entry points (include/m17hip.h)."""
+import ctypes as C
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import m17hip
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _signals(Cn, T, seed=5, sigma=500.0, kind=-1):
+    p = ol.gen_params(seed=seed, kind=kind, n_frames=max(1, T // 1920 - 4), lead_in=3072, noise_sigma=sigma, tail_sigma=sigma,
+                      lead_sigma=40000.0, total=T)
+    return ol.generate_batch(p, Cn, T, threads=8)
+
+
+def _oracle_flat(x, base=0):
+    recs, counts, _ = ol.demod_batch(x, cap=2 * (x.shape[1] // 1920 + 2) + 4, threads=8)
+    flat = np.concatenate([recs[c, :counts[c]] for c in range(x.shape[0])]).copy()
+    flat["channel"] += base
+    return flat
+
+
+def test_error_codes():
+    lib = m17hip.load_library()
+    h = C.c_void_p()
+    assert lib.m17hip_ctx_create(0, 0, 100, C.byref(h)) == -1                       # EINVAL: no channels
+    assert lib.m17hip_ctx_create(0, 4, 0, C.byref(h)) == -1
+    assert lib.m17hip_ctx_create(0, 4, 100, None) == -1
+    assert lib.m17hip_ctx_create(9999, 4, 4800, C.byref(h)) == -2 and lib.m17hip_strerror(-2) == b"HIP runtime error"
+    c = m17hip.Context(4, 4800)
+    n = C.c_uint64(0)
+    assert lib.m17hip_demod_run(c.h, 4, 4800, 0) == -4                              # ESTATE: nothing uploaded
+    assert lib.m17hip_frames_count(c.h, C.byref(n)) == -4                           # ESTATE: no run yet
+    assert lib.m17hip_fir_rrc150(c.h, 4, 4800, 0, None) == -4
+    x = _signals(4, 4800)
+    c.upload(x)
+    assert lib.m17hip_demod_run(c.h, 5, 4800, 0) == -1                              # EINVAL: beyond the context
+    assert lib.m17hip_demod_run(c.h, 4, 4801, 0) == -1
+    assert lib.m17hip_upload_i16(c.h, x.ctypes.data_as(C.c_void_p), 4, 4800, C.c_size_t(100)) == -1   # pitch < samples
+    assert lib.m17hip_set_kalman_order(c.h, 8) == -1 and lib.m17hip_set_kalman_order(c.h, 3) == 0
+    assert lib.m17hip_tune(c.h, 99, 0) == -1 and lib.m17hip_tune(c.h, 0, 3) == -1
+    bs = np.zeros(4, dtype=m17hip.BERT_STAT)
+    assert lib.m17hip_bert_stats(c.h, bs.ctypes.data_as(C.c_void_p), 4) == -4       # consumer not enabled
+    c.run()
+    assert lib.m17hip_demod_run(c.h, 2, 4800, 0) == -1                              # a continued stream keeps its channel count
+    assert lib.m17hip_strerror(-6) == b"output truncated to the caller's capacity"
+    c.close()
+
+
+def test_truncated_fetch_reports_total():
+    x = _signals(16, 48000, seed=8)
+    c = m17hip.Context(16, 48000)
+    c.upload(x); c.reset(); c.run()
+    full = c.frames()
+    assert full.size > 32
+    part = np.zeros(10, dtype=m17hip.FRAME_REC)
+    n = C.c_uint64(0)
+    code = c.lib.m17hip_frames_fetch(c.h, part.ctypes.data_as(C.c_void_p), C.c_uint64(10), C.byref(n))
+    assert code == m17hip.ETRUNC and n.value == full.size and part.tobytes() == full[:10].tobytes()
+    import torch
+    dev = torch.zeros(7 * 64, dtype=torch.uint8, device="cuda")
+    code = c.lib.m17hip_frames_compact_device(c.h, C.c_void_p(dev.data_ptr()), C.c_uint64(7), C.byref(n))
+    assert code == m17hip.ETRUNC and n.value == full.size
+    assert dev.cpu().numpy().tobytes() == full[:7].tobytes()
+    c.close()
+
+
+def test_record_buffer_overflow_is_reported():
+    """M17HIP_EOVERFLOW: with the default sizing a run cannot outgrow its record slots (2 callbacks per 1920 samples + 8; 25 short
+    runs on a context sized for one frame prove the slots start afresh every run); with the slots cut to 3 per channel (knob 8)
+    the fetch reports the overflow, still returns the records that fit, and a reset clears the condition."""
+    x = _signals(8, 48000, seed=3)
+    c = m17hip.Context(8, 1920)      # 10 record slots per channel and run
+    c.reset()
+    total = 0
+    for k in range(25):
+        c.upload(x[:, 1920 * k:1920 * (k + 1)]); c.run()
+        total += c.frames().size
+    exp = _oracle_flat(x[:, :1920 * 25])
+    assert total == exp.size and total > 8
+    c.close()
+    c = m17hip.Context(8, 48000)
+    c.tune(8, 3)
+    c.upload(x); c.reset(); c.run()
+    n = C.c_uint64(0)
+    assert c.lib.m17hip_frames_count(c.h, C.byref(n)) == -5 and n.value == 8 * 3
+    got = np.zeros(64, dtype=m17hip.FRAME_REC)
+    assert c.lib.m17hip_frames_fetch(c.h, got.ctypes.data_as(C.c_void_p), C.c_uint64(64), C.byref(n)) == -5
+    full = _oracle_flat(x)
+    first3 = np.concatenate([full[full["channel"] == ch][:3] for ch in range(8)])
+    assert n.value == 24 and got[:24].tobytes() == first3.tobytes()
+    c.tune(8, 0)
+    c.upload(x); c.reset(); c.run()
+    assert c.frames().tobytes() == full.tobytes()
+    # the packet consumer has its own room: more completed packets than tune(7, room) -> EOVERFLOW from the fetch
+    p = ol.gen_params(seed=6, kind=4, n_frames=3, lead_in=3072, noise_sigma=300.0, tail_sigma=300.0, lead_sigma=40000.0, total=48000)
+    c.tune(7, 2)
+    c.synth(p, 8, 48000); c.reset(); c.run()
+    out = np.zeros(8, dtype=m17hip.PACKET_REC); cnt = C.c_uint32(0)
+    assert c.lib.m17hip_packets_fetch(c.h, out.ctypes.data_as(C.c_void_p), 8, C.byref(cnt)) == -5 and cnt.value > 2
+    c.close()
+
+
+def test_async_upload_buffer_may_be_reused_after_upload_wait():
+    """m17hip_demod_run does not wait for the staged copy on the host.  The documented rule: the pinned buffer is the
+    caller's again after m17hip_upload_wait.  One pinned buffer, refilled for every run right after the wait."""
+    import torch
+    Cn, T, n = 32, 9600, 6
+    x = _signals(Cn, n * T, seed=21)
+    exp = _oracle_flat(x)
+    c = m17hip.Context(Cn, T)
+    pinned = torch.zeros((Cn, T), dtype=torch.int16).pin_memory()
+    c.reset()
+    parts = []
+    for k in range(n):
+        pinned.numpy()[:] = x[:, k * T:(k + 1) * T]
+        c.upload_async(pinned.data_ptr(), Cn, T)
+        c.run()
+        c.upload_wait()
+        pinned.numpy()[:] = -12345          # scribble: the copy has left the buffer
+        parts.append(c.frames().copy())
+    got = np.concatenate(parts)
+    got = got[np.lexsort((got["seq"], got["channel"]))]
+    assert got.tobytes() == exp.tobytes()
+    c.close()
+
+
+def test_device_guard_restores_callers_device_and_ignores_it():
+    """Entry points run on the context's device whatever the caller's current device is, and leave the caller's in place."""
+    import torch
+    c = m17hip.Context(4, 4800)
+    x = _signals(4, 4800)
+    torch.cuda.set_device(0)
+    c.upload(x); c.reset(); c.run()
+    assert torch.cuda.current_device() == 0
+    assert c.frames().tobytes() == _oracle_flat(x).tobytes()
+    c.close()
+
+
+def test_channel_base_gives_global_channel_ids():
+    """SURVEY §8e's correctness check on one GPU: two contexts = two shards of a 24-channel job; with channel bases set the
+    concatenation of their record sets IS the record set of the single 24-channel run (and of the oracle)."""
+    x = _signals(24, 48000, seed=31)
+    whole = m17hip.Context(24, 48000)
+    whole.upload(x); whole.reset(); whole.run()
+    one = whole.frames().copy()
+    whole.close()
+    parts = []
+    for lo, hi in ((0, 10), (10, 24)):
+        c = m17hip.Context(hi - lo, 48000)
+        c.set_channel_base(lo)
+        c.upload(x[lo:hi]); c.reset(); c.run()
+        parts.append(c.frames().copy())
+        c.close()
+    got = np.concatenate(parts)
+    assert got.tobytes() == one.tobytes() == _oracle_flat(x).tobytes()
+    key = got["channel"].astype(np.int64) << 32 | got["seq"]
+    assert (np.diff(key) > 0).all()                  # globally (channel, seq)-ordered, no duplicates
+
+
+def test_rccl_gather_single_rank():
+    """m17hip_comm_* / m17hip_gather_frames with a 1-rank communicator: RCCL is bound, the counts all-gather and the
+    compaction run, the root receives its own records."""
+    x = _signals(12, 48000, seed=41)
+    c = m17hip.Context(12, 48000)
+    c.set_channel_base(100)
+    comm = m17hip.Comm(c, m17hip.comm_get_id(), 0, 1)
+    c.upload(x); c.reset(); c.run()
+    recs, counts = c.gather_frames(comm, root=0)
+    assert counts.tolist() == [recs.size] and recs.tobytes() == _oracle_flat(x, base=100).tobytes()
+    small = np.zeros(5, dtype=m17hip.FRAME_REC)
+    tot = C.c_uint64(0)
+    code = c.lib.m17hip_gather_frames(c.h, comm.h, 0, small.ctypes.data_as(C.c_void_p), C.c_uint64(5), None, C.byref(tot))
+    assert code == m17hip.ETRUNC and tot.value == recs.size and small.tobytes() == recs[:5].tobytes()
+    comm.close(); c.close()
+
+
+_WORKER = r"""
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join({root!r}, "m17-cxx-demod_amd")); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch, torch.distributed as dist
+import m17hip, oracle_lib as ol
+from m17hip import dist as mdist
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+CT, T = 20, 48000
+p = ol.gen_params(seed=77, kind=-1, n_frames=20, lead_in=3072, noise_sigma=500.0, tail_sigma=500.0, lead_sigma=40000.0, total=T)
+lo, hi = mdist.shard_range(CT, rank, world)
+ctx = m17hip.Context(hi - lo, T)
+ctx.set_channel_base(lo)
+ctx.synth(p, hi - lo, T, chan0=lo)            # this shard's channels of the global job, generated on the device
+ctx.reset(); ctx.run()
+buf = torch.zeros((hi - lo) * 64 * 64, dtype=torch.uint8, device="cuda")
+n = ctx.frames_compact_device(buf.data_ptr(), buf.numel() // 64)
+allrecs, counts = mdist.gather_records(buf.cpu(), n)       # gloo: host tensors (two ranks share the one GPU of this box)
+np.save(os.path.join(sys.argv[4], f"rank{{rank}}.npy"), allrecs.numpy())
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_one_gpu_gather_equals_one_big_run(tmp_path):
+    """Two processes (ranks) on cuda:0, each running the real HIP path on its shard with its channel base, records compacted
+    on the device and all-gathered (gloo here: RCCL refuses two ranks on one device) == one 20-channel run."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(port), str(tmp_path)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    CT, T = 20, 48000
+    p = ol.gen_params(seed=77, kind=-1, n_frames=20, lead_in=3072, noise_sigma=500.0, tail_sigma=500.0, lead_sigma=40000.0, total=T)
+    whole = m17hip.Context(CT, T)
+    whole.synth(p, CT, T); whole.reset(); whole.run()
+    one = whole.frames().copy()
+    whole.close()
+    assert one.size > CT
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npy")
+        assert got.tobytes() == one.tobytes(), r

@@ -1,6 +1,8 @@
 """The oracle against the reference's own known-answer tests (values restated from
 /root/reference/tests/*.cpp, cited per test) and against the golden fixtures produced by the
 reference's own headers (tests/golden/make_golden.py).  CPU only."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -208,6 +210,71 @@ def test_freqdev_kat():
     idev = np.zeros(3, dtype=np.float32); off = np.zeros(3, dtype=np.float32)
     ol.oracle().m17o_freqdev(ol._p(mn), ol._p(mx), C.c_size_t(3), None, ol._p(idev), ol._p(off))
     assert abs(2400.0 / idev[-1] - 2400.0) < 0.1 and abs(off[-1]) < 0.1
+
+
+@pytest.fixture
+def kalman_order():
+    """Sets the oracle's evaluation order of the Kalman updates (m17_oracle_dsp.hpp) and puts the default back."""
+    lib = ol.oracle()
+    saved = lib.m17o_get_kalman_order()
+    yield lambda order: lib.m17o_set_kalman_order(C.c_int(order))
+    lib.m17o_set_kalman_order(C.c_int(saved))
+
+
+def kalman_trace(z, dt, wrap, z0=0.0):
+    z = np.ascontiguousarray(z, dtype=np.float32)
+    dt = np.ascontiguousarray(np.broadcast_to(dt, z.shape), dtype=np.uint32)
+    out = np.zeros((z.size, 6), dtype=np.float32)
+    ol.oracle().m17o_kalman_trace(ol._p(z), ol._p(dt), C.c_size_t(z.size), C.c_int(wrap), C.c_float(z0), ol._p(out))
+    return out
+
+
+def test_kalman_orders_all_pass_the_reference_kat_and_agree_to_rounding(kalman_order):
+    """KalmanFilter.h:49-64 leaves the association of `x += K*y` and `P = P - K*H*P` to blaze (absent).  Every order the
+    switch offers passes FreqDevEstimatorTest (the reference's only pin there), the default is the blaze-restructured one (3),
+    and the orders differ from each other by last-place rounding only — which is what tools/kalman_sensitivity.py follows
+    through the whole chain."""
+    assert ol.oracle().m17o_get_kalman_order() == 3
+    rng = np.random.default_rng(17)
+    z = (5.0 + rng.normal(0, 1.2, 400)).astype(np.float32) % np.float32(10)
+    dt = rng.choice([1920, 1920, 1920, 960, 3840, 17], 400)
+    mn = (-5.2 + rng.normal(0, 0.05, 400)).astype(np.float32)
+    traces = {}
+    for order in range(8):
+        kalman_order(order)
+        mn3 = np.full(3, -3, dtype=np.float32); mx3 = np.full(3, 3, dtype=np.float32)
+        idev = np.zeros(3, dtype=np.float32); off = np.zeros(3, dtype=np.float32)
+        ol.oracle().m17o_freqdev(ol._p(mn3), ol._p(mx3), C.c_size_t(3), None, ol._p(idev), ol._p(off))
+        assert abs(2400.0 / idev[-1] - 2400.0) < 0.1 and abs(off[-1]) < 0.1, order
+        traces[order] = (kalman_trace(z, dt, 10, z0=5.0), kalman_trace(mn, 192, 0, z0=-5.2))
+        assert np.isfinite(traces[order][0]).all() and np.isfinite(traces[order][1]).all()
+    differ = 0
+    for order in range(1, 8):
+        for a, b in zip(traces[0], traces[order]):
+            assert np.allclose(a[:, :2], b[:, :2], rtol=2e-5, atol=2e-6), order     # same filter, different rounding
+            differ += int((a.view(np.uint32) != b.view(np.uint32)).any())
+    assert differ > 0, "the orders are meant to be distinguishable in the last place"
+    # the wrap-around of the index filter: estimates stay in [0, 10)
+    kalman_order(3)
+    zz = np.tile(np.array([9.6, 0.2, 9.9, 0.4], dtype=np.float32), 50)
+    tr = kalman_trace(zz, 1920, 10, z0=9.0)
+    assert (tr[:, 0] >= 0).all() and (tr[:, 0] < 10).all()
+
+
+def test_front_end_golden_extra_sets(golden):
+    """Round-2 fixture sets: inverted input, DC offset with low gain, a stream that opens with digital silence (DCD NaN, Q1)."""
+    for tag, inv in (("inv_", 1), ("dc_", 0), ("zero_", 0)):
+        s = golden[tag + "sig_i16"]
+        x = ol.scale(s, invert=inv)
+        assert np.array_equal(ol.fir_i16(s, invert=inv), golden[tag + "fir_out"]), tag
+        lim, corr = ol.correlator(golden[tag + "fir_out"])
+        assert np.array_equal(lim, golden[tag + "corr_limit"]) and np.array_equal(corr, golden[tag + "corr_values"]), tag
+        for period in (384, 960):
+            l, t = ol.dcd_trace(x, period)
+            assert np.array_equal(l, golden[f"{tag}dcd{period}_level"], equal_nan=True) and np.array_equal(t, golden[f"{tag}dcd{period}_trig"]), tag
+        for st, ln, a, b in golden[tag + "dcd_sums"]:
+            assert tuple(float(v) for v in ol.dcd_sums(x, int(st), int(ln))) == (a, b), tag
+    assert np.isnan(golden["zero_dcd384_level"]).all() and not golden["zero_dcd384_trig"].any()
 
 
 # ---- golden fixtures generated from the reference's own headers (oracle/_ref) -------------------------------

@@ -2,14 +2,24 @@
 build container by oracle/Makefile from /root/reference where it lies).  Skipped where _ref is absent; the
 same comparison is frozen into tests/golden/ for everywhere else.  CPU only."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 import oracle_lib as ol
 
-R = ol.ref()
-pytestmark = pytest.mark.skipif(R is None, reason="oracle/_ref not built (reference not present)")
+
+class _LazyRef:
+    """The reference-header shim, bound at first use: collecting this module (e.g. under -m gpu) must not load it."""
+
+    def __getattr__(self, name):
+        return getattr(ol.ref(), name)
+
+
+R = _LazyRef()
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(ol.ORACLE_DIR, "_ref", "libm17ref.so")),
+                                reason="oracle/_ref not built (reference not present)")
 
 
 @pytest.mark.parametrize("seed,kind,sigma", [(1, 0, 0), (2, 1, 800), (3, 2, 2500), (4, 3, 0), (5, 0, 4000)])
