@@ -220,6 +220,7 @@ struct DeviceGuard {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != c->device) { const hipError_t e = hipSetDevice(c->device); if (e != hipSuccess) { c->last_hip = (int)e; ok = false; prev = -1; } }
         else prev = -1;
+        (void)hipGetLastError();   // a stale error of an earlier call (ours or the host's) must not be blamed on this one's launches
     }
     ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
 };
