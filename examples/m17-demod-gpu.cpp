@@ -38,6 +38,5 @@ int main()
         if (!std::cin) break;
         demod(sample / 41067.0);
     }
-    demod.flush();
-    return 0;
+    return 0;   // ~M17Demodulator() demodulates what is still buffered
 }

@@ -142,6 +142,14 @@ int m17hip_frames_compact_device(m17hip_ctx* ctx, m17_frame_rec* recs_dev, uint6
 /* Per-channel diagnostics after the last run: diag_host[C]. */
 int m17hip_diag_fetch(m17hip_ctx* ctx, m17_diag* diag_host, uint32_t channels);
 
+/* Every diagnostic callback of the last run, not only the last one: after m17hip_tune(ctx, 9, room) each invocation of the
+ * reference's diagnostic callback (every 960 samples while the carrier is on, every 384 while it is off) appends its
+ * arguments to the channel's log: log_host[channels][capacity], counts_host[channels] entries valid per row, in stream order.
+ * In a log entry demod_state / n_frames are the values at that moment and pad[0] | pad[1] << 32 is the index (since reset) of
+ * the sample whose processing fired the callback — frame callbacks of the same sample come first (M17Demodulator.h:729-752).
+ * M17HIP_ETRUNC if a channel fired more than min(capacity, room) callbacks. */
+int m17hip_diag_log_fetch(m17hip_ctx* ctx, m17_diag* log_host, uint32_t* counts_host, uint32_t channels, uint32_t capacity);
+
 /* Synthetic input on the device: the framing of the reference's modulator CLI (apps/m17-mod.cpp:164-504,
  * 628-677: preamble, LSF, stream / BERT / packet frames, EOT), its pulse shaping (one symbol per 10 samples through the 150-tap
  * RRC in double, x 7168, truncation to int16, :204-224) and the impairments of BASELINE config 5, written straight into the
@@ -254,7 +262,8 @@ int m17hip_gather_frames(m17hip_ctx* ctx, m17hip_comm* comm, int root, m17_frame
  * key 3: samples per segment a run is processed in (default 48000; 0 = one segment).  key 4: samples of the first segment
  * (default 0 = like the others).  key 6: BERT statistics on/off (m17hip_bert_stats; default off).  key 7: packet reassembly, value = packets of room per run (m17hip_packets_fetch; default 0 = off).  key 5: segments the front end (K1, K3) may run ahead of the sequential kernel
  * (default 0 = unlimited).  key 8 (not a performance knob): record slots per channel and run actually used, 0 = all that were
- * allocated (2 per 1920 samples + 8, which a run cannot outgrow) — a smaller value makes M17HIP_EOVERFLOW reachable for tests. */
+ * allocated (2 per 1920 samples + 8, which a run cannot outgrow) — a smaller value makes M17HIP_EOVERFLOW reachable for tests.
+ * key 9: diagnostic log, value = diagnostic callbacks of room per channel and run (m17hip_diag_log_fetch; default 0 = off). */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 
 /* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][24] =

@@ -9,7 +9,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// the arithmetic cores shared with the scalar operator classes of include/m17cxx (one definition of every rounding step)
+#include "m17cxx/detail/core.h"
+
 namespace m17 {
+namespace core = ::mobilinkd::core;
 
 // ---- slab geometry ---------------------------------------------------------------------------
 // xbuf row:  [XPRE samples carried from the previous run | T new samples]   (int16)
@@ -19,44 +23,26 @@ constexpr int YPRE = 96;   // >= 80 (correlator ring); multiple of 4
 constexpr int TICK = 192;  // gcd(384, 960): every DCD update point is a tick boundary (M17Demodulator.h:677,742)
 constexpr int NTAPS = 149; // taps[149] == 0.0 contributes a signed zero only
 
-// ---- RRC taps: reference M17Demodulator.h:79-118 (alpha = 0.5, 10 samples/symbol), symmetric -----
-static constexpr double RRC_HALF_D[75] = {
-#include "rrc_half_taps.inc"
-};
-__host__ __device__ constexpr float rrc_tap(int i) { return (float)(i <= 74 ? RRC_HALF_D[i] : RRC_HALF_D[148 - i]); }
+// ---- RRC taps: reference M17Demodulator.h:79-118 (alpha = 0.5, 10 samples/symbol), symmetric: core::rrc_tap -----
+using core::rrc_tap;
 
 // apps/m17-demod.cpp:486-489: x = float(double(s) / 41067.0) (optionally s *= -1 first, in int16).
 // (float)s / 41067.0f is bit-identical for all 65536 inputs (no double rounding: 41067 is odd and < 2^16, so s / 41067 is never
 // within 2^-40 of a float midpoint), and so is one Newton step on q = s * RN(1/41067): r = fma(-q, 41067, s) is the exact
 // remainder, fma(r, 1/41067, q) the correctly rounded quotient — 3 instructions instead of the 10 of an IEEE division.
 // Exhaustive: tests/test_oracle_kat.py::test_scale_identities_exhaustive (host), tests/test_gpu_parity.py::test_scale_exhaustive.
-__device__ __forceinline__ float scale_sample(int s, bool invert)
-{
-    if (invert) s = (int)(int16_t)(-s);
-    const float rcp = 1.0f / 41067.0f;
-    const float fs = (float)s;
-    const float q = fs * rcp;
-    const float r = __builtin_fmaf(-q, 41067.0f, fs);
-    return __builtin_fmaf(r, rcp, q);
-}
+__device__ __forceinline__ float scale_sample(int s, bool invert) { return core::scale_i16(s, invert); }
 
 // Sync words M17Demodulator.h:154-157: preamble, LSF(/stream), packet(/BERT), EOT — symbol signs (x3).
 // The same words as sign masks (bit i set = symbol i is -3): (float)(-3) * x == -(3.0f * x) exactly, and r + (-p) is what
 // r - p computes, so a correlation is eight multiplies by the literal 3.0f and eight adds / subtracts — no coefficient table
 // to keep in registers (the sequential kernel used to spill the 32 converted coefficients to scratch and reload them at every use).
-constexpr uint32_t SYNC_NEG[4] = {0xAAu, 0xB0u, 0xF2u, 0x40u};
+using core::SYNC_NEG;
 // Correlator::correlate (Correlator.h:51-64) for word w over r[0..7] (oldest symbol first)
 __device__ __forceinline__ float sync_correlate(int w, const float (&r)[8])
 {
     const uint32_t neg = w == 0 ? SYNC_NEG[0] : (w == 1 ? SYNC_NEG[1] : (w == 2 ? SYNC_NEG[2] : SYNC_NEG[3]));
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float p = 3.0f * r[i];
-        const float q = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, p) ^ (((neg >> i) & 1u) << 31));
-        v = v + q;
-    }
-    return v;
+    return core::correlate_mask(neg, r);
 }
 __device__ __constant__ const int8_t SYNC_WORDS[4][8] = {{+3, -3, +3, -3, +3, -3, +3, -3},
                                                           {+3, +3, +3, +3, -3, -3, +3, -3},

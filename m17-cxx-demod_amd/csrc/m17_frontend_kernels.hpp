@@ -118,18 +118,9 @@ __global__ __launch_bounds__(256) void correlate_kernel(const float* __restrict_
 // (Correlator.h:43-45, IirFilter.h:26-42, coefficients Correlator.h:38-39).  A float recurrence: strictly
 // sequential per channel, one lane per channel; each lane streams its own row with 16-byte accesses.
 // =====================================================================================================
-struct IirCoef {
-    static constexpr float b0 = 4.24433681e-05f, b1 = 8.48867363e-05f, b2 = 4.24433681e-05f;
-    static constexpr float a1 = -1.98148851f, a2 = 0.98165828f;
-};
+using IirCoef = core::LimitIir;
 // one step: returns h0; caller rotates (h2 <- h1, h1 <- h0)
-__device__ __forceinline__ float iir_advance(float in_abs, float h1, float h2)
-{
-    float h0 = in_abs;
-    h0 = h0 - IirCoef::a1 * h1;
-    h0 = h0 - IirCoef::a2 * h2;
-    return h0;
-}
+using core::iir_advance;
 // The same recurrence over a run of samples with the two products of a sample formed by ONE packed multiply:
 // (a1 * h, a2 * h) for the newest history value h gives a1*h1 for the next sample and a2*h2 for the one after
 // (identical IEEE products, one VALU instruction less per sample).  m2 carries a2 * h2 between calls.
@@ -142,14 +133,7 @@ __device__ __forceinline__ float iir_advance_pk(float in_abs, float h1, float& m
     m2 = pr.y;
     return h0;
 }
-__device__ __forceinline__ float iir_output(float h0, float h1, float h2)
-{
-    float r = 0.0f;
-    r = r + IirCoef::b0 * h0;
-    r = r + IirCoef::b1 * h1;
-    r = r + IirCoef::b2 * h2;
-    return r;
-}
+using core::iir_output;
 
 __global__ __launch_bounds__(64) void limit_kernel(const float* __restrict__ y, size_t ypitch, float* __restrict__ limit,
                                                    uint32_t C, uint32_t T)

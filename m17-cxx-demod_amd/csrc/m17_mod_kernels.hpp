@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void mod_shape_kernel(ModParams base, uint32_t
         for (uint32_t i = m % 10u; i < 150u && i <= m; i += 10u) {
             const uint32_t k = (m - i) / 10u;
             if (k < nsym) {
-                const double tap = i == 149u ? 0.0 : (i <= 74u ? RRC_HALF_D[i] : RRC_HALF_D[148u - i]);
+                const double tap = i == 149u ? 0.0 : (i <= 74u ? core::RRC_HALF[i] : core::RRC_HALF[148u - i]);
                 const double p = (double)sr[k] * tap;
                 acc = acc + p;
             }

@@ -11,9 +11,7 @@ namespace m17 {
 
 enum : uint32_t { ST_UNLOCKED = 0, ST_LSF_SYNC, ST_STREAM_SYNC, ST_PACKET_SYNC, ST_BERT_SYNC, ST_SYNC_WAIT, ST_FRAME };
 
-struct Kal2 {  // 2-state Kalman filter (KalmanFilter.h:18-108); F, H, R, Q are constants
-    float x0, x1, p00, p01, p10, p11;
-};
+using Kal2 = core::Kalman2;  // 2-state Kalman filter (KalmanFilter.h:18-108); F, H, R, Q are constants
 
 struct Hot {  // per-channel scalars kept in registers while the kernel runs
     uint32_t dcd_trig, dcd_on, count;
@@ -88,6 +86,7 @@ struct Cold {  // per-channel state touched a few times per frame (out-of-line h
     int32_t stale401;
     uint32_t seq;               // frame callbacks since reset
     uint32_t n_run;             // frame callbacks in the current run
+    uint32_t n_diag_run;        // diagnostic callbacks in the current run (only counted while the diagnostic log is on)
     Diag diag;
 };
 struct SeqState {
@@ -123,6 +122,9 @@ struct SeqParams {
     const float* h;           // K2's limit-filter history, pitch ypitch (nullptr: no speculation, K5 runs the filter itself)
     const float* final_h;     // [C][4] K2's filter history after the last fed sample of the run
     uint32_t* dropped;        // [C] out: this segment dropped the speculation (K2 must redo the channel's next segment from K5's state)
+    Diag* diag_log;           // optional [C][diag_cap]: one entry per diagnostic callback of the run (m17hip_tune key 9), else nullptr
+    uint32_t diag_cap;
+    uint32_t* diag_count;     // [C] entries written this run
     uint32_t kalman_order;    // evaluation order of the Kalman update (kal_update)
     uint32_t channel_base;    // global id of channel 0 of this context (written into the frame records)
 };
@@ -132,165 +134,50 @@ struct SeqParams {
 __device__ __constant__ const float SW_MAG1[4] = {29.f, 31.f, 31.f, 31.f};
 __device__ __constant__ const float SW_MAG2[4] = {-3.402823466e+38f, -31.f, -31.f, -3.402823466e+38f};
 
-// ---- Kalman pieces --------------------------------------------------------------------------------------------
-// KalmanFilter.h:41-65,91-107.  `S` and `K` are lazy blaze expressions there (`auto`), so the association / rounding of
-// `x += K*y` and `P = P - K*H*P` follows blaze's restructuring operators; blaze is absent from the reference tree, hence the
-// order is a switch shared with the oracle (m17hip_set_kalman_order):
-//   bit 0: x += double(fl32(P(:,0)*y)) * invS      [(A*s)*v -> (A*v)*s]   else  x += (double(P(:,0))*invS) * double(y)
-//   bit 1: P -= double(fl32(P(i,0)*P(0,j))) * invS [(A*s)*B -> (A*B)*s]   else  P -= ((double(P(i,0))*invS) * double(P(0,j)))
-//   bit 2: F*(P*F^T) instead of (F*P)*F^T
-__device__ __forceinline__ void kal_reset(Kal2& k, float z)
-{
-    k.x0 = z; k.x1 = 0.f;
-    k.p00 = 4.f; k.p01 = 0.f; k.p10 = 0.f; k.p11 = (float)0.00000025;
-}
+// ---- Kalman pieces: core::kalman2_update (evaluation-order switch: DESIGN.md §4.4, m17hip_set_kalman_order) -------------
+__device__ __forceinline__ void kal_reset(Kal2& k, float z) { core::kalman2_reset(k, z); }
 // wrap != 0: KalmanFilter<float,SPS> (index filter, modulo SPS); 0: SymbolKalmanFilter.  State in LDS.
-__device__ __noinline__ void kal_update(M17_LDS Kal2* kp, float z, uint32_t dt_u, int wrap, uint32_t order)
+template <uint32_t ORDER>
+__device__ __noinline__ void kal_update_as(M17_LDS Kal2* kp, float z, uint32_t dt_u, int wrap)
 {
     Kal2 k = lds_get(kp);
-    const float F00 = 1.f, F01 = (float)dt_u, F10 = 0.f, F11 = 1.f;
-    const float Q00 = (float)6.25e-13, Q01 = (float)1.25e-12, Q10 = (float)1.25e-12, Q11 = (float)2.50e-12;
-    const float nx0 = F00 * k.x0 + F01 * k.x1;
-    const float nx1 = F10 * k.x0 + F11 * k.x1;
-    k.x0 = nx0; k.x1 = nx1;
-    float B00, B01, B10, B11;
-    if (!(order & 4u)) {
-        const float A00 = F00 * k.p00 + F01 * k.p10, A01 = F00 * k.p01 + F01 * k.p11;
-        const float A10 = F10 * k.p00 + F11 * k.p10, A11 = F10 * k.p01 + F11 * k.p11;
-        B00 = A00 * F00 + A01 * F01; B01 = A00 * F10 + A01 * F11;
-        B10 = A10 * F00 + A11 * F01; B11 = A10 * F10 + A11 * F11;
-    } else {
-        const float A00 = k.p00 * F00 + k.p01 * F01, A01 = k.p00 * F10 + k.p01 * F11;
-        const float A10 = k.p10 * F00 + k.p11 * F01, A11 = k.p10 * F10 + k.p11 * F11;
-        B00 = F00 * A00 + F01 * A10; B01 = F00 * A01 + F01 * A11;
-        B10 = F10 * A00 + F11 * A10; B11 = F10 * A01 + F11 * A11;
-    }
-    k.p00 = B00 + Q00; k.p01 = B01 + Q01; k.p10 = B10 + Q10; k.p11 = B11 + Q11;
-    const float hp0 = 1.f * k.p00 + 0.f * k.p10;
-    const float hp1 = 1.f * k.p01 + 0.f * k.p11;
-    const float S = (hp0 * 1.f + hp1 * 0.f) + 0.5f;
-    const float ph0 = k.p00 * 1.f + k.p01 * 0.f;
-    const float ph1 = k.p10 * 1.f + k.p11 * 0.f;
-    const double invS = 1.0 / (double)S;
-    const double K0 = (double)ph0 * invS, K1 = (double)ph1 * invS;
-    const float fw = (float)wrap;
-    if (wrap) {
-        if ((double)(z - k.x0) < ((double)wrap / -2.0)) z += fw;
-        else if ((double)(z - k.x0) > ((double)wrap / 2.0)) z -= fw;
-    }
-    const float y = z - (1.f * k.x0 + 0.f * k.x1);
-    if (order & 1u) {
-        const float hy0 = 1.f * y, hy1 = 0.f * y;
-        const float t0 = k.p00 * hy0 + k.p01 * hy1;
-        const float t1 = k.p10 * hy0 + k.p11 * hy1;
-        k.x0 = (float)((double)k.x0 + (double)t0 * invS);
-        k.x1 = (float)((double)k.x1 + (double)t1 * invS);
-    } else {
-        k.x0 = (float)((double)k.x0 + K0 * (double)y);
-        k.x1 = (float)((double)k.x1 + K1 * (double)y);
-    }
-    if (wrap) {
-        while (k.x0 >= fw) k.x0 -= fw;
-        while (k.x0 < 0.f) k.x0 += fw;
-    }
-    float n00, n01, n10, n11;
-    if (order & 2u) {
-        const float G00 = ph0 * 1.f, G01 = ph0 * 0.f, G10 = ph1 * 1.f, G11 = ph1 * 0.f;
-        const float T00 = G00 * k.p00 + G01 * k.p10, T01 = G00 * k.p01 + G01 * k.p11;
-        const float T10 = G10 * k.p00 + G11 * k.p10, T11 = G10 * k.p01 + G11 * k.p11;
-        n00 = (float)((double)k.p00 - (double)T00 * invS);
-        n01 = (float)((double)k.p01 - (double)T01 * invS);
-        n10 = (float)((double)k.p10 - (double)T10 * invS);
-        n11 = (float)((double)k.p11 - (double)T11 * invS);
-    } else {
-        const double KH00 = K0 * 1.0, KH01 = K0 * 0.0, KH10 = K1 * 1.0, KH11 = K1 * 0.0;
-        n00 = (float)((double)k.p00 - (KH00 * (double)k.p00 + KH01 * (double)k.p10));
-        n01 = (float)((double)k.p01 - (KH00 * (double)k.p01 + KH01 * (double)k.p11));
-        n10 = (float)((double)k.p10 - (KH10 * (double)k.p00 + KH11 * (double)k.p10));
-        n11 = (float)((double)k.p11 - (KH10 * (double)k.p01 + KH11 * (double)k.p11));
-    }
-    k.p00 = n00; k.p01 = n01; k.p10 = n10; k.p11 = n11;
+    core::kalman2_update_as<ORDER>(k, z, dt_u, wrap);
     lds_put(kp, k);
 }
-
-__device__ __forceinline__ int32_t wrap10(int32_t v)
+// (one out-of-line function per order: the default one is as small as the single-order build was; a run-time branch inside
+// one function cost the sequential kernel 8 VGPRs and a 32-byte spill)
+__device__ __forceinline__ void kal_update(M17_LDS Kal2* kp, float z, uint32_t dt_u, int wrap, uint32_t order)
 {
-    v = (int32_t)(int8_t)v;
-    v = v < 0 ? v + 10 : v;
-    v = v >= 10 ? v - 10 : v;
-    return (int32_t)(int8_t)v;
-}
-
-// llr<float,4> (Util.h:63-104,128-145): index of the first float-accumulated table edge >= the clamped sample,
-// then the (int8,int8) pair of that row.  The index is guessed arithmetically and corrected against the exact
-// edges (LDS or global), so the result equals std::lower_bound over the reference's table for every float.
-__device__ __forceinline__ uint32_t slice_llr(float sample, const float* edges)
-{
-    const float cl = fminf(3.0f, fmaxf(-3.0f, sample));
-    int n = (int)ceilf((cl + 3.0f) * 7.0f) - 1;
-    n = n < 1 ? 1 : (n > 41 ? 41 : n);
-    const float e0 = edges[n - 1], e1 = edges[n], e2 = edges[n + 1];
-    // edges are strictly increasing; the guess is within one row of the answer
-    if (e0 >= cl) n = n - 1;
-    else if (e1 >= cl) { /* the guess is the row */ }
-    else if (e2 >= cl) n = n + 1;
-    else n = n + 2;
-    int li, lj;  // Util.h:63-104: i falls 7..1,-1..-7 over rows 14..27, j falls over rows 0..13 and rises over 28..41
-    if (n <= 14) { li = 7; lj = (n <= 6) ? 7 - n : ((n <= 13) ? 6 - n : -7); }
-    else if (n <= 28) { lj = -7; li = (n <= 20) ? 21 - n : ((n <= 27) ? 20 - n : -7); }
-    else { li = -7; lj = (n <= 34) ? n - 35 : ((n <= 41) ? n - 34 : 7); }
-    return ((uint32_t)(uint8_t)(int8_t)li) | (((uint32_t)(uint8_t)(int8_t)lj) << 8);
-}
-
-// ClockRecovery::update() (ClockRecovery.h:76-88) as a pure function of (sample_estimate_, clock_estimate_, count_).
-// std::fmod(double(v), 10) is exact; for |v| < 1e12 it is computed as v - 10*trunc(v/10) with one fma (exact, see
-// DESIGN.md §4.5), otherwise by the library fmod.
-__device__ __forceinline__ int32_t clock_predict(float sample_est, float clock_est, uint32_t count)
-{
-    const float v = sample_est + clock_est * (float)count;
-    const double dv = (double)v;
-    double csw;
-    if (fabs(dv) < 1.0e12) {
-        const double q = trunc(dv * 0.1);  // within one of trunc(dv/10); the exact remainder below is corrected by +-10
-        csw = fma(-q, 10.0, dv);
-        if (dv >= 0.0) { if (csw < 0.0) csw += 10.0; else if (csw >= 10.0) csw -= 10.0; }
-        else { if (csw > 0.0) csw -= 10.0; else if (csw <= -10.0) csw += 10.0; }
-    } else {
-        csw = fmod(dv, 10.0);
+    if (order == 3u) { kal_update_as<3>(kp, z, dt_u, wrap); return; }
+    switch (order & 7u) {
+    case 0: kal_update_as<0>(kp, z, dt_u, wrap); break;
+    case 1: kal_update_as<1>(kp, z, dt_u, wrap); break;
+    case 2: kal_update_as<2>(kp, z, dt_u, wrap); break;
+    case 4: kal_update_as<4>(kp, z, dt_u, wrap); break;
+    case 5: kal_update_as<5>(kp, z, dt_u, wrap); break;
+    case 6: kal_update_as<6>(kp, z, dt_u, wrap); break;
+    default: kal_update_as<7>(kp, z, dt_u, wrap); break;
     }
-    if (csw < 0.) csw += 10;
-    else if (csw >= 10) csw -= 10;
-    return wrap10((int32_t)round(csw));
 }
+using core::wrap10;
+// llr<float,4> (Util.h:63-104,128-145): core::llr_slice — the (int8,int8) pair of the first float-accumulated table edge >= the
+// clamped sample (edges in LDS or global)
+__device__ __forceinline__ uint32_t slice_llr(float sample, const float* edges) { return core::llr_slice(sample, edges); }
+// ClockRecovery::update() (ClockRecovery.h:76-88): core::clock_predict
+using core::clock_predict;
 
 // ---- out-of-line helpers on COLD state ------------------------------------------------------------------------------
 // M17Demodulator::update_values (:233-241) = Correlator::outer_symbol_levels (Correlator.h:81-114) +
 // FreqDevEstimator::update (FreqDevEstimator.h:31-48).  Returns (idev, offset).
 __device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float* ring, int stride, int lane, uint32_t si, uint32_t order)
 {
-    float min_sum = 0.f, max_sum = 0.f;
-    uint32_t min_count = 0, max_count = 0;
-    float lo = ring[si * stride + lane], hi = lo;
-    for (uint32_t i = si; i < 80u; i += 10u) {
-        const float v = ring[i * stride + lane];
-        lo = (v < lo) ? v : lo;  // std::min(lo, v)
-        hi = (hi < v) ? v : hi;  // std::max(hi, v)
-    }
-    const float avg = (float)((double)hi + (double)lo / 2.);  // sic: Correlator.h:97
-    for (uint32_t i = si; i < 80u; i += 10u) {
-        const float v = ring[i * stride + lane];
-        const bool high = v > avg, low = v < avg;
-        max_sum = max_sum + v * (high ? 1.f : 0.f);
-        min_sum = min_sum + v * (low ? 1.f : 0.f);
-        max_count += high; min_count += low;
-    }
-    const float mn = min_count > 0 ? min_sum / (float)min_count : lo;
-    const float mx = max_count > 0 ? max_sum / (float)max_count : hi;
+    float mn, mx;
+    core::outer_symbol_levels([&](uint32_t i) { return ring[i * stride + lane]; }, si, mn, mx);
     kal_update(&cd->kmin, mn, 192u, 0, order);
     kal_update(&cd->kmax, mx, 192u, 0, order);
     const Kal2 a = lds_get(&cd->kmin), b = lds_get(&cd->kmax);
-    float offset = (float)((double)(b.x0 + a.x0) / 2.);
-    float idev = (float)(6.0 / (double)(b.x0 - a.x0));
+    float offset = core::freqdev_offset(b.x0, a.x0);
+    float idev = core::freqdev_idev(b.x0, a.x0);
     uint32_t rst = cd->dev_reset;
     if (isnan(a.x0) || isnan(a.x1) || isnan(b.x0) || isnan(b.x1)) rst = 1;
     if (rst) {
@@ -298,7 +185,7 @@ __device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float
         kal_reset(k, mn); lds_put(&cd->kmin, k);
         kal_reset(k, mx); lds_put(&cd->kmax, k);
         offset = (mn + mx) / 2.f;
-        idev = (float)(6.0 / (double)(mx - mn));
+        idev = core::freqdev_idev(mx, mn);
     }
     cd->dev_reset = 0;
     return make_float2(idev, offset);
@@ -310,7 +197,7 @@ __device__ __forceinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32
     kal_update(&cd->ck, (float)index, ck_count, 10, order);
     ClockOut o;
     o.sample_est = cd->ck.x0;
-    o.sample_index = wrap10((int32_t)round((double)o.sample_est));
+    o.sample_index = core::clock_index_of(o.sample_est);
     o.clock_est = cd->ck.x1;
     return o;
 }
@@ -324,7 +211,7 @@ __device__ __forceinline__ uint32_t nf_dcd_update(M17_LDS Cold* cd, const float*
     const int j = span > 5 ? 5 : (int)(cd->seg_start_tick % 5u);
     float l1, l2;  // table row: [2 bins][6 sums]
     if (have) { l1 = pl1; l2 = pl2; } else { l1 = row[j]; l2 = row[6 + j]; }
-    const float level = (float)((double)cd->dcd_level * 0.8 + 0.2 * (double)(l1 / l2));
+    const float level = core::dcd_level(cd->dcd_level, l1, l2);
     cd->dcd_level = level;
     cd->seg_start_tick = (uint32_t)(k + 1);
     return trig ? (level > 0.1f) : (level > 4.0f);

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     wave_lds_sync();
     s.load(as_lds(hot_lds));
     s.spec_ok = hrow != nullptr;  // every run starts trusting K2 (which started from this very state)
-    if (!(P.flags & 2u)) cd->n_run = 0;  // (flag bit 1: a later segment of the same run keeps counting its records)
+    if (!(P.flags & 2u)) { cd->n_run = 0; cd->n_diag_run = 0; }  // (flag bit 1: a later segment of the same run keeps counting its records)
     // Sample window: ybuf samples [t, avail) are in LDS; the next WV_PF samples are in flight in registers (pf) so that the
     // HBM/L2 latency of this channel's row is paid ~WV_PF samples ahead of its use instead of at the head of every step.
     float pf[WV_PF / 64];
@@ -304,10 +304,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         float sample = filtered - s.offset;
         sample = sample * s.idev;
         sample = sample * 1.0f;  // polarity
-        if (sample > 2.f) err = sample - 3.f;
-        else if (sample > 0.f) err = sample - 1.f;
-        else if (sample > -2.f) err = sample + 1.f;
-        else err = sample + 3.f;
+        err = core::evm_error(sample);
         return sample;
     };
     // DataCarrierDetect::update at the point that ends with relative sample te, then the fetch for the next point
@@ -327,8 +324,32 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             hpf_wait = true;
         }
     };
-    const float alpha = (float)(1.0 / 184);  // RunningStandardDeviation<float,184>::alpha
+    const float alpha = core::EVM_ALPHA;  // RunningStandardDeviation<float,184>::alpha
     // carrier-on update point: tail of operator() (:742-752); te = relative index of the sample just processed
+    // The diagnostic callback (M17Demodulator.h:681-685, 746-750): its arguments become the channel's m17_diag; with the
+    // diagnostic log on, every invocation is also appended to the channel's log with the sample that fired it.
+    auto fire_diag = [&](uint32_t te, float evm_arg) {
+        nf_fire_diag(cd, s.dcd_on, evm_arg, s.idev, s.offset, s.st != ST_UNLOCKED, s.ck_clock_est, s.sample_index,
+                     s.sync_sample_index, s.ck_sample_index, s.viterbi_cost);
+        if (P.diag_log) {
+            const uint32_t n = cd->n_diag_run;
+            if (n < P.diag_cap) {
+                wave_lds_sync();
+                const M17_LDS uint32_t* src = reinterpret_cast<const M17_LDS uint32_t*>(&cd->diag);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(P.diag_log + ((size_t)c * P.diag_cap + n));
+                const uint64_t pos = P.pos0 + te;
+                if (wl < 16) {
+                    uint32_t w = src[wl];
+                    if (wl == 12) w = s.st;
+                    if (wl == 13) w = cd->seq;
+                    if (wl == 14) w = (uint32_t)pos;
+                    if (wl == 15) w = (uint32_t)(pos >> 32);
+                    dst[wl] = w;
+                }
+            }
+            cd->n_diag_run = n + 1;
+        }
+    };
     auto dcd_point_on = [&](uint32_t te) {
         if (!s.dcd_trig) {  // update_dcd -> dcd_off :260-265 (dcd_ is on here)
             s.st = ST_UNLOCKED;
@@ -336,8 +357,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             nf_snapshot_hist(gs->hist, xr, te);
         }
         s.count = 0;
-        nf_fire_diag(cd, s.dcd_on, sqrtf(s.evm_S), s.idev, s.offset, s.st != ST_UNLOCKED, s.ck_clock_est, s.sample_index,
-                     s.sync_sample_index, s.ck_sample_index, s.viterbi_cost);
+        fire_diag(te, sqrtf(s.evm_S));
         dcd_update_at(te);
     };
 
@@ -405,8 +425,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     if (t < P.T) patch_run_start(t);
                 }
                 dcd_update_at(te);
-                nf_fire_diag(cd, s.dcd_on, 0.f, s.idev, s.offset, s.st != ST_UNLOCKED, s.ck_clock_est, s.sample_index,
-                             s.sync_sample_index, s.ck_sample_index, s.viterbi_cost);
+                fire_diag(te, 0.f);
                 s.count = 0;
             }
             tk_off += now() - f0;
@@ -868,6 +887,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     for (int k = wl; k < 92; k += 64) gs->llr[k] = DL.llr[k];
     for (int k = wl; k < 8; k += 64) gs->lsf[k] = DL.lsf[k];
     P.rec_count[c] = cd->n_run;
+    if (P.diag_log && wl == 0) P.diag_count[c] = cd->n_diag_run;
     if constexpr (PROF) if (wl == 0) {
         unsigned long long* o = P.dbg + (size_t)c * 24;
         o[8] = tk_patch; o[12] = tk_ens; o[13] = tk_sym; o[14] = tk_iir; o[15] = tk_search; o[16] = tk_off; o[17] = n_despec;

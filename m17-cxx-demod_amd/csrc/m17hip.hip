@@ -62,6 +62,9 @@ struct m17hip_ctx {
     uint32_t* pkt_count = nullptr;
     uint32_t pkt_cap = 0;
     bool pkt_fed = false;
+    Diag* diag_log = nullptr;         // [maxC][diag_cap] one entry per diagnostic callback of the last run (tuning knob 9)
+    uint32_t* diag_count = nullptr;   // [maxC]
+    uint32_t diag_cap = 0;
     uint32_t kalman_order = 3;        // evaluation order of the Kalman updates (m17hip_set_kalman_order)
     uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
     bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
@@ -632,7 +635,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo, &c->ev_seq})
         for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count};
+                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -993,6 +996,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         P.tables = c->tables; P.taps = c->taps; P.llr_edges = c->llr_edges;
         P.C = C; P.T = len; P.pos0 = c->pos + t0; P.tick_row0 = c->pos / TICK; P.flags = (flags & 1u) | (t0 ? 2u : 0u);
         P.kalman_order = c->kalman_order; P.channel_base = c->channel_base;
+        P.diag_log = c->diag_cap ? c->diag_log : nullptr; P.diag_cap = c->diag_cap; P.diag_count = c->diag_count;
         // one wave per channel; `seq_lanes` (tuning knob 0) = waves per workgroup
         const uint32_t wpb = (c->seq_lanes && !c->profile) ? c->seq_lanes : 4;  // the profiling build exists for 4 waves per workgroup
         const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
@@ -1099,6 +1103,21 @@ int m17hip_diag_fetch(m17hip_ctx* c, m17_diag* diag_host, uint32_t C)
                                c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return M17HIP_OK;
+}
+
+int m17hip_diag_log_fetch(m17hip_ctx* c, m17_diag* log_host, uint32_t* counts_host, uint32_t C, uint32_t capacity)
+{
+    if (!c || !log_host || !counts_host || C == 0 || C > c->maxC || capacity == 0) return M17HIP_EINVAL;
+    GUARD(c);
+    if (!c->diag_cap || !c->have_run) return M17HIP_ESTATE;
+    HIPCHK(c, hipMemcpyAsync(counts_host, c->diag_count, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
+    const uint32_t n = std::min(capacity, c->diag_cap);
+    HIPCHK(c, hipMemcpy2DAsync(log_host, (size_t)capacity * sizeof(Diag), c->diag_log, (size_t)c->diag_cap * sizeof(Diag), (size_t)n * sizeof(Diag), C,
+                               hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    bool trunc = false;
+    for (uint32_t i = 0; i < C; ++i) trunc = trunc || counts_host[i] > n;
+    return trunc ? M17HIP_ETRUNC : M17HIP_OK;
 }
 
 int m17hip_lsf_info(m17hip_ctx* c, const uint8_t* lsf30_host, uint32_t n, m17_lsf_info* out_host)
@@ -1365,6 +1384,18 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         hipLaunchKernelGGL(packet_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, (PacketState*)c->pkt_state, c->maxC);
         HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
         HIPCHK(c, hipGetLastError());
+        return M17HIP_OK;
+    }
+    case 9: {  // diagnostic log: room for `value` diagnostic callbacks per channel and run, 0 = off (m17hip_diag_log_fetch)
+        if (value < 0 || value > (1 << 20)) return M17HIP_EINVAL;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->diag_log) hipFree(c->diag_log);
+        c->diag_log = nullptr; c->diag_cap = 0;
+        if (value == 0) return M17HIP_OK;
+        if (!c->diag_count) HIPCHK(c, hipMalloc((void**)&c->diag_count, (size_t)c->maxC * 4));
+        HIPCHK(c, hipMemset(c->diag_count, 0, (size_t)c->maxC * 4));
+        HIPCHK(c, hipMalloc((void**)&c->diag_log, (size_t)c->maxC * (size_t)value * sizeof(Diag)));
+        c->diag_cap = (uint32_t)value;
         return M17HIP_OK;
     }
     case 8:  // record slots per channel and run actually used (0 = all that were allocated): exercises M17HIP_EOVERFLOW

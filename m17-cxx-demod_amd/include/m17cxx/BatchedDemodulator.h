@@ -16,7 +16,7 @@ namespace mobilinkd
 class BatchedDemodulator
 {
     m17hip_ctx* ctx_ = nullptr;
-    uint32_t channels_ = 0, samples_ = 0, room_ = 0;
+    uint32_t channels_ = 0, samples_ = 0, room_ = 0, diag_room_ = 0;
 
     static void check(int code, const char* what)
     {
@@ -78,6 +78,22 @@ public:
         check(m17hip_diag_fetch(ctx_, d.data(), channels_), "m17hip_diag_fetch");
         return d;
     }
+    // Every diagnostic callback of a run, not only the last: enable with room for `room` callbacks per channel and run
+    // (samples / 384 + 2 is always enough), then diag_log(channel) returns them in stream order; entry.pad[0] | pad[1] << 32
+    // is the sample that fired it.
+    void enable_diag_log(uint32_t room) { check(m17hip_tune(ctx_, 9, room), "m17hip_tune"); diag_room_ = room; }
+    std::vector<m17_diag> diag_log(uint32_t channel = 0)
+    {
+        std::vector<m17_diag> all((size_t)channels_ * diag_room_);
+        std::vector<uint32_t> counts(channels_);
+        check(m17hip_diag_log_fetch(ctx_, all.data(), counts.data(), channels_, diag_room_), "m17hip_diag_log_fetch");
+        const auto first = all.begin() + (size_t)channel * diag_room_;
+        return std::vector<m17_diag>(first, first + counts[channel]);
+    }
+    // Multi-GPU (one BatchedDemodulator = one shard = one rank): records carry channel = base + local index
+    void set_channel_base(uint32_t base) { check(m17hip_set_channel_base(ctx_, base), "m17hip_set_channel_base"); }
+    // Evaluation order of the Kalman updates (include/m17hip.h); default 3
+    void set_kalman_order(int order) { check(m17hip_set_kalman_order(ctx_, order), "m17hip_set_kalman_order"); }
 
     // batched counterparts of the reference's operators (parity API)
     std::vector<float> fir(uint32_t flags = 0)  // BaseFirFilter<float,150> with the RRC taps: FirFilter.h:28-43

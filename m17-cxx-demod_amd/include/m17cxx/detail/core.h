@@ -159,7 +159,9 @@ M17_HD void kalman2_reset(Kalman2& k, float z)
     k.p00 = 4.f; k.p01 = 0.f; k.p10 = 0.f; k.p11 = (float)0.00000025;
 }
 // wrap != 0: KalmanFilter<float,SPS> (index filter, modulo SPS, :41-65); 0: SymbolKalmanFilter (:91-107).
-M17_HD void kalman2_update(Kalman2& k, float z, uint32_t dt_u, int wrap, uint32_t order)
+// The order is a template parameter so that each variant is straight-line code (the kernels dispatch once per update).
+template <uint32_t order>
+M17_HD void kalman2_update_as(Kalman2& k, float z, uint32_t dt_u, int wrap)
 {
     const float F00 = 1.f, F01 = (float)dt_u, F10 = 0.f, F11 = 1.f;
     const float Q00 = (float)6.25e-13, Q01 = (float)1.25e-12, Q10 = (float)1.25e-12, Q11 = (float)2.50e-12;
@@ -223,6 +225,19 @@ M17_HD void kalman2_update(Kalman2& k, float z, uint32_t dt_u, int wrap, uint32_
         n11 = (float)((double)k.p11 - (KH10 * (double)k.p01 + KH11 * (double)k.p11));
     }
     k.p00 = n00; k.p01 = n01; k.p10 = n10; k.p11 = n11;
+}
+M17_HD void kalman2_update(Kalman2& k, float z, uint32_t dt_u, int wrap, uint32_t order)
+{
+    switch (order & 7u) {
+    case 0: kalman2_update_as<0>(k, z, dt_u, wrap); break;
+    case 1: kalman2_update_as<1>(k, z, dt_u, wrap); break;
+    case 2: kalman2_update_as<2>(k, z, dt_u, wrap); break;
+    case 3: kalman2_update_as<3>(k, z, dt_u, wrap); break;
+    case 4: kalman2_update_as<4>(k, z, dt_u, wrap); break;
+    case 5: kalman2_update_as<5>(k, z, dt_u, wrap); break;
+    case 6: kalman2_update_as<6>(k, z, dt_u, wrap); break;
+    default: kalman2_update_as<7>(k, z, dt_u, wrap); break;
+    }
 }
 
 // ClockRecovery (ClockRecovery.h:54-88): int8 wrap of the rounded estimate into 0..9
@@ -311,7 +326,8 @@ M17_HD int llr_row(float sample, const float* edges)
 M17_HD uint32_t llr_slice(float sample, const float* edges) { return llr_pair_of_row(llr_row(sample, edges)); }
 
 // ---- a17: Viterbi<Trellis<4,2>,4> (Viterbi.h:94-240) scalar pieces -----------------------------------------------------------
-M17_HD uint32_t viterbi_cost_of(int32_t min_metric) { return (uint32_t)(uint64_t)(int64_t)__builtin_roundf((float)min_metric / 7.0f); }   // :223
+template <int LIMIT = 7>
+M17_HD uint32_t viterbi_cost_of(int32_t min_metric) { return (uint32_t)(int64_t)__builtin_roundf((float)min_metric / (float)LIMIT); }   // :223
 
 }  // namespace core
 }  // namespace mobilinkd

@@ -38,7 +38,7 @@ EXPORTS = [
     "m17hip_slice_llr", "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_packets_fetch", "m17hip_packets_feed", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
     "m17hip_set_kalman_order", "m17hip_kalman_trace", "m17hip_set_channel_base", "m17hip_upload_wait", "m17hip_comm_get_id", "m17hip_comm_create",
-    "m17hip_comm_destroy", "m17hip_comm_last_error", "m17hip_gather_frames",
+    "m17hip_comm_destroy", "m17hip_comm_last_error", "m17hip_gather_frames", "m17hip_diag_log_fetch",
 ]
 ETRUNC = -6
 COMM_ID_BYTES = 128
@@ -270,6 +270,15 @@ class Context:
         d = np.zeros(n, dtype=DIAG)
         self._chk(self.lib.m17hip_diag_fetch(self.h, _ptr(d), C.c_uint32(n)))
         return d
+
+    def diag_log(self, channels=None, capacity=None):
+        """Every diagnostic callback of the last run per channel (enable with tune(9, room) before the run): list of DIAG arrays."""
+        n = channels or self.C
+        cap = capacity or (self.T // 384 + 2)
+        log = np.zeros((n, cap), dtype=DIAG)
+        counts = np.zeros(n, dtype=np.uint32)
+        self._chk(self.lib.m17hip_diag_log_fetch(self.h, _ptr(log), _ptr(counts), C.c_uint32(n), C.c_uint32(cap)))
+        return [log[c, : counts[c]] for c in range(n)]
 
     def lsf_info(self, lsf30):
         """Callsigns, type field and CRC status of a batch of 30-byte link setup frames."""

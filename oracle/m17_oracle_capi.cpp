@@ -342,6 +342,30 @@ size_t m17o_demod_symbols(const int16_t* s, size_t n, int invert, float* sym_out
     run_channel(s, n, invert, 0, nullptr, 0, nullptr, sym_out, sym_cap, &ns);
     return ns;
 }
+// Every diagnostic callback of one channel, in order (same layout as the log entries of m17hip_diag_log_fetch: demod_state and
+// n_frames at that moment, pad[0] | pad[1] << 32 = the sample that fired it).  Returns the number of callbacks.
+size_t m17o_demod_diag_log(const int16_t* s, size_t n, int invert, m17o_diag* log, size_t cap)
+{
+    std::vector<FrameRecord> out;
+    auto d = std::make_unique<Demodulator>();
+    d->out = &out;
+    size_t cnt = 0;
+    Demodulator* dp = d.get();
+    d->on_diag = [&](uint64_t pos, const Diag& g) {
+        if (cnt < cap) {
+            m17o_diag& o = log[cnt];
+            std::memset(&o, 0, sizeof(o));
+            o.dcd = g.dcd; o.evm = g.evm; o.deviation = g.deviation; o.offset = g.offset; o.locked = g.locked; o.clock = g.clock;
+            o.sample_index = g.sample_index; o.sync_index = g.sync_index; o.clock_index = g.clock_index; o.viterbi_cost = g.viterbi_cost;
+            o.dcd_level = g.dcd_level; o.n_diag = g.n_diag; o.demod_state = (uint32_t)dp->st; o.n_frames = (uint32_t)out.size();
+            o.pad[0] = (uint32_t)pos; o.pad[1] = (uint32_t)(pos >> 32);
+        }
+        ++cnt;
+    };
+    d->run(s, n, invert != 0);
+    return cnt;
+}
+
 // Batch: samples[C][T] (row pitch = pitch samples); recs[C][cap]; counts[C]; diags[C].  `threads` host threads.
 void m17o_demod_batch(const int16_t* s, size_t C, size_t T, size_t pitch, int invert, int threads, m17o_frame_rec* recs,
                       size_t cap, uint32_t* counts, m17o_diag* diags)

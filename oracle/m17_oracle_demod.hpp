@@ -87,6 +87,7 @@ struct Demodulator {
 
     // optional taps for tests: called with (pos, filtered sample) / per symbol
     std::function<void(uint64_t, float, float)> on_symbol;  // pos, normalised symbol, raw filtered
+    std::function<void(uint64_t, const Diag&)> on_diag;     // every diagnostic callback: sample position, arguments
 
     Demodulator() { std::memset(framer, 0, 368); }
     Demodulator(const Demodulator&) = delete;
@@ -121,6 +122,7 @@ struct Demodulator {
         diag.sample_index = sample_index; diag.sync_index = sync_sample_index;
         diag.clock_index = clock.sample_index(); diag.viterbi_cost = (int)viterbi_cost;
         diag.dcd_level = dcd.level(); diag.n_diag++;
+        if (on_diag) on_diag(pos, diag);
     }
 
     void do_unlocked()  // :289-342

@@ -1,0 +1,352 @@
+// Test driver for the operator surface in m17-cxx-demod_amd/include/m17cxx (TEST INFRASTRUCTURE: built by
+// __graft_entry__.build(), run by tests/test_cxx_mirror.py).  Each mode reads raw little-endian arrays written by the test,
+// runs the classes exactly as a reference-style host would (one sample / one frame per call), and writes raw arrays back; the
+// test compares them with the golden vectors produced by the reference's own headers (tests/golden) or with the oracle.
+// Modes whose name starts with "gpu_" go through the batched overloads (C ABI -> HIP kernels) and need a GPU.
+#include "M17Demodulator.h"
+#include "IirFilter.h"
+#include "KalmanFilter.h"
+#include "SlidingDFT.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+bool display_lsf = false;
+using namespace mobilinkd;
+
+template <typename T>
+static std::vector<T> load(const char* path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) { std::fprintf(stderr, "cannot open %s\n", path); std::exit(2); }
+    const size_t bytes = (size_t)f.tellg();
+    std::vector<T> v(bytes / sizeof(T));
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
+    return v;
+}
+template <typename T>
+static void save(const char* path, const std::vector<T>& v)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
+}
+#define CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "KAT failed: %s (line %d)\n", #cond, __LINE__); return 1; } } while (0)
+
+static const std::array<float, 150> TAPS = detail::Taps<float>::rrc_taps;
+
+// ---- known answers of the reference's own unit tests (values cited per line) -----------------------------------------------
+static int kat()
+{
+    {   // tests/CRC16Test.cpp:21-55
+        CRC16<0x5935, 0xFFFF> crc;
+        auto run = [&](const std::string& s) { crc.reset(); for (char c : s) crc(uint8_t(c)); return crc.get(); };
+        CHECK(run("") == 0xFFFF); CHECK(run("A") == 0x206E); CHECK(run("123456789") == 0x772B);
+        std::string all; for (int i = 0; i < 256; ++i) all.push_back(char(i));
+        CHECK(run(all) == 0x1C31);
+        crc.reset(); for (char c : std::string("123456789")) crc(uint8_t(c));
+        auto b = crc.get_bytes(); crc(b[0]); crc(b[1]); CHECK(crc.get() == 0);
+    }
+    {   // tests/Golay24Test.cpp:20-152: encode24, clean decode, 1 / 2 / 3 corrupted bits corrected, 4 rejected, interop words
+        const uint32_t enc = Golay24::encode24(0xD78);
+        CHECK(enc == 0xD7880Fu);
+        uint32_t out = 0;
+        CHECK(Golay24::decode(enc, out) && out == 0xD7880Fu);
+        for (uint32_t e : {0x010000u, 0x010010u, 0x810100u}) { CHECK(Golay24::decode(enc ^ e, out) && out == 0xD7880Fu); }
+        CHECK(!Golay24::decode(enc ^ 0x011110u, out));
+        CHECK(Golay24::syndrome(0x010010u) == Golay24::syndrome((enc ^ (0x010010u << 1)) >> 1));
+        const uint32_t words[4] = {0b110101111000100000001111u, 0b101000001111010110011001u, 0u, 0b000000000001100011101011u};
+        const uint32_t data[4] = {0b110101111000u, 0b101000001111u, 0u, 1u};
+        for (int i = 0; i < 4; ++i) { CHECK(Golay24::decode(words[i], out) && (out >> 12) == data[i]); CHECK(Golay24::encode24(uint16_t(data[i])) == words[i]); }
+        // every error of weight <= 3 confined to the 23 code bits is corrected
+        for (int a = 1; a < 24; ++a) for (int b = a; b < 24; ++b) for (int c = b; c < 24; ++c) {
+            const uint32_t e = (1u << a) | (1u << b) | (1u << c);
+            CHECK(Golay24::decode(enc ^ e, out) && out == enc);
+        }
+    }
+    {   // tests/LinkSetupFrameTest.cpp:19-52: base-40 callsigns
+        LinkSetupFrame::call_t c = {'W', 'X', '9', 'O'};
+        auto e = LinkSetupFrame::encode_callsign(c);
+        const uint8_t exp[6] = {0, 0, 0, 0x0f, 0x8a, 0xd7};
+        CHECK(std::memcmp(e.data(), exp, 6) == 0);
+        auto d = LinkSetupFrame::decode_callsign(e); CHECK(std::string(d.data()) == "WX9O" && d[4] == 0);
+        auto d2 = LinkSetupFrame::decode_callsign({0x00, 0x00, 0x5F, 0x1B, 0x66, 0x91}); CHECK(std::string(d2.data()) == "IU2KWO");
+        auto bc = LinkSetupFrame::decode_callsign(LinkSetupFrame::BROADCAST_ADDRESS); CHECK(std::string(bc.data()) == "BROADCAST");
+    }
+    {   // tests/TrellisTest.cpp / Trellis.h:17-40: puncture matrices; PolynomialInterleaver indices
+        size_t z = 0; for (auto v : P1) z += v == 0; CHECK(z == 15 && P1[2] == 0 && P1[6] == 0 && P1[58] == 0 && P1[0] == 1);
+        CHECK(P2[11] == 0 && P3[7] == 0);
+        PolynomialInterleaver<45, 92, 368> il;
+        const size_t first[12] = {0, 137, 90, 227, 180, 317, 270, 39, 360, 129, 82, 219};
+        for (size_t i = 0; i < 12; ++i) CHECK(il.index(i) == first[i]);
+        std::array<int8_t, 368> f; for (size_t i = 0; i < 368; ++i) f[i] = int8_t(i % 127);
+        auto g = f; il.interleave(g); il.deinterleave(g); CHECK(g == f);
+        M17Randomizer<368> rnd; auto h = f; rnd(h); rnd(h); CHECK(h == f);
+    }
+    {   // tests/ViterbiTest.cpp:25-88 tables (SURVEY §8a "cost tables to reproduce exactly")
+        auto trellis = makeTrellis<4, 2>({031, 027});
+        Viterbi<decltype(trellis), 4> v(trellis);
+        const int exp[16][2] = {{-7, -7}, {-7, 7}, {-7, 7}, {-7, -7}, {7, -7}, {7, 7}, {7, 7}, {7, -7}, {7, 7}, {7, -7}, {7, -7}, {7, 7}, {-7, 7}, {-7, -7}, {-7, -7}, {-7, 7}};
+        for (int s = 0; s < 16; ++s) {
+            CHECK(v.cost_[s][0] == exp[s][0] && v.cost_[s][1] == exp[s][1]);
+            CHECK(v.nextState_[s][0] == ((2 * s) & 15) && v.nextState_[s][1] == ((2 * s + 1) & 15));
+            CHECK(v.prevState_[s][0] == (s >> 1) && v.prevState_[s][1] == (s >> 1) + 8);
+        }
+    }
+    {   // tests/UtilTest.cpp: PRBS9 sequence start and self-synchronisation; to_byte_array; llr corner values
+        PRBS9 g; uint16_t first16 = 0; for (int i = 0; i < 16; ++i) first16 = uint16_t((first16 << 1) | g.generate());
+        CHECK(first16 == 0x08C2);   // the first BERT payload starts 08 c2 72 ... (tests/UtilTest.cpp:221-270 baseline)
+        PRBS9 tx, rx; for (int i = 0; i < 200; ++i) rx.validate(tx.generate());
+        CHECK(rx.sync() && rx.errors() == 0 && rx.bits() == 200);
+        std::array<uint8_t, 12> bits = {1, 0, 1, 0, 0, 0, 0, 1, 1, 1, 0, 0};
+        auto by = to_byte_array(bits); CHECK(by[0] == 0xA1 && by[1] == 0xC0);
+        auto [a3, b3] = llr<float, 4>(3.0f); CHECK(a3 == -7 && b3 == 7);       // +3 -> dibit 01
+        auto [a1, b1] = llr<float, 4>(1.0f); CHECK(a1 == -7 && b1 == -7);      // +1 -> 00
+        auto [am1, bm1] = llr<float, 4>(-1.0f); CHECK(am1 == 7 && bm1 == -7);  // -1 -> 10
+        auto [am3, bm3] = llr<float, 4>(-3.0f); CHECK(am3 == 7 && bm3 == 7);   // -3 -> 11
+    }
+    {   // tests/FreqDevEstimatorTest.cpp:26-35
+        FreqDevEstimator<float> fde; fde.update(-3, 3); fde.update(-3, 3); fde.update(-3, 3);
+        CHECK(std::fabs(fde.deviation() - 2400.f) < 0.1f && std::fabs(fde.error()) < 0.1f);
+    }
+    std::puts("kat ok");
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) return 2;
+    const std::string mode = argv[1];
+    if (mode == "kat") return kat();
+    if (mode == "fir") {   // fir in.f32 out.f32 : BaseFirFilter<float,150>, one sample per call
+        auto x = load<float>(argv[2]);
+        BaseFirFilter<float, 150> f(TAPS);
+        std::vector<float> y(x.size());
+        for (size_t i = 0; i < x.size(); ++i) y[i] = f(x[i]);
+        save(argv[3], y);
+        return 0;
+    }
+    if (mode == "scale") {   // scale in.i16 invert out.f32 : the application's sample / 41067.0 (apps/m17-demod.cpp:486-489) == core::scale_i16
+        auto s = load<int16_t>(argv[2]);
+        const bool inv = std::atoi(argv[3]) != 0;
+        std::vector<float> y(s.size());
+        for (size_t i = 0; i < s.size(); ++i) {
+            int16_t v = s[i]; if (inv) v *= -1;
+            const float app = float(v / 41067.0);
+            y[i] = core::scale_i16(s[i], inv);
+            if (std::memcmp(&app, &y[i], 4) != 0) { std::fprintf(stderr, "scale mismatch at %zu\n", i); return 1; }
+        }
+        save(argv[4], y);
+        return 0;
+    }
+    if (mode == "corr") {   // corr y.f32 out.f32 : limit[n], corr[4][n], then per word w: trig[n], timing[n], updated[n] (as floats)
+        auto y = load<float>(argv[2]);
+        const size_t n = y.size();
+        Correlator<float> c;
+        using SW = SyncWord<Correlator<float>>;
+        SW sw[4] = {SW({+3, -3, +3, -3, +3, -3, +3, -3}, 29.f), SW({+3, +3, +3, +3, -3, -3, +3, -3}, 31.f, -31.f), SW({3, -3, 3, 3, -3, -3, -3, -3}, 31.f, -31.f),
+                    SW({+3, +3, +3, +3, +3, +3, -3, +3}, 31.f)};
+        std::vector<float> out(n * (5 + 12));
+        for (size_t i = 0; i < n; ++i) {
+            c.sample(y[i]);
+            out[i] = c.limit();
+            for (int w = 0; w < 4; ++w) {
+                out[(1 + w) * n + i] = c.correlate(sw[w].sync_word_);
+                out[(5 + 3 * w) * n + i] = sw[w].triggered(c);
+                out[(6 + 3 * w) * n + i] = float(sw[w](c));
+                out[(7 + 3 * w) * n + i] = float(sw[w].updated());
+            }
+        }
+        save(argv[3], out);
+        return 0;
+    }
+    if (mode == "outer") {   // outer y.f32 n si : prints the two levels as raw bits
+        auto y = load<float>(argv[2]);
+        Correlator<float> c;
+        for (size_t i = 0; i < (size_t)std::atol(argv[3]); ++i) c.sample(y[i]);
+        auto [mn, mx] = c.outer_symbol_levels((size_t)std::atol(argv[4]));
+        uint32_t a, b; std::memcpy(&a, &mn, 4); std::memcpy(&b, &mx, 4);
+        std::printf("%08x %08x\n", a, b);
+        return 0;
+    }
+    if (mode == "dcd") {   // dcd x.f32 period out.f32 : level[k], trig[k] per update
+        auto x = load<float>(argv[2]);
+        const size_t period = (size_t)std::atol(argv[3]);
+        DataCarrierDetect<float, 48000, 400> d{2400, 3600, 0.1, 4.0};
+        std::vector<float> out;
+        for (size_t i = 0; i < x.size(); ++i) {
+            d(x[i]);
+            if ((i + 1) % period == 0) { d.update(); out.push_back(d.level()); out.push_back(d.dcd() ? 1.f : 0.f); }
+        }
+        save(argv[4], out);
+        return 0;
+    }
+    if (mode == "sdft") {   // sdft x.f32 n out.f32 : raw NSlidingDFT outputs (re0, im0, re1, im1) per sample
+        auto x = load<float>(argv[2]);
+        NSlidingDFT<float, 48000, 120, 2> dft({2400, 3600});
+        std::vector<float> out;
+        for (size_t i = 0; i < (size_t)std::atol(argv[3]); ++i) { auto r = dft(x[i]); out.insert(out.end(), {r[0].real(), r[0].imag(), r[1].real(), r[1].imag()}); }
+        save(argv[4], out);
+        return 0;
+    }
+    if (mode == "llr") {   // llr sym.f32 out.i8 evm.f32 : llr<float,4> pairs and SymbolEvm after reset()
+        auto sym = load<float>(argv[2]);
+        std::vector<int8_t> out(2 * sym.size());
+        std::vector<float> ev(sym.size());
+        SymbolEvm<float> evm; evm.reset();
+        for (size_t i = 0; i < sym.size(); ++i) {
+            auto [a, b] = llr<float, 4>(sym[i]);
+            out[2 * i] = a; out[2 * i + 1] = b;
+            evm.update(sym[i]); ev[i] = evm.evm();
+        }
+        save(argv[3], out); save(argv[4], ev);
+        return 0;
+    }
+    if (mode == "viterbi" || mode == "gpu_viterbi") {   // viterbi in.i8 (rows of 488) meta.i64 (rows of IN, OUT, cost) out.u8 (rows of 240) cost.i64
+        auto in = load<int8_t>(argv[2]);
+        auto meta = load<int64_t>(argv[3]);
+        const size_t rows = meta.size() / 3;
+        std::vector<uint8_t> out(rows * 240, 0);
+        std::vector<int64_t> cost(rows);
+        auto trellis = makeTrellis<4, 2>({031, 027});
+        using V = Viterbi<decltype(trellis), 4>;
+        V v(trellis);
+        std::unique_ptr<batched::Device> dev;
+        if (mode == "gpu_viterbi") dev = std::make_unique<batched::Device>(1, 1920);
+        auto one = [&](auto in_tag, auto out_tag, size_t r) {
+            constexpr size_t IN = decltype(in_tag)::value, OUT = decltype(out_tag)::value;
+            std::array<int8_t, IN> a; std::array<uint8_t, OUT> b{};
+            std::memcpy(a.data(), &in[r * 488], IN);
+            if (dev) { int32_t c = 0; if (V::decode(*dev, &a, 1, &b, &c) != M17HIP_OK) std::exit(3); cost[r] = c; }
+            else cost[r] = (int64_t)v.decode(a, b);
+            std::memcpy(&out[r * 240], b.data(), OUT);
+        };
+        for (size_t r = 0; r < rows; ++r) {
+            switch (meta[3 * r]) {
+            case 488: one(std::integral_constant<size_t, 488>{}, std::integral_constant<size_t, 240>{}, r); break;
+            case 296: one(std::integral_constant<size_t, 296>{}, std::integral_constant<size_t, 144>{}, r); break;
+            case 420: one(std::integral_constant<size_t, 420>{}, std::integral_constant<size_t, 206>{}, r); break;
+            default: one(std::integral_constant<size_t, 402>{}, std::integral_constant<size_t, 197>{}, r); break;
+            }
+        }
+        save(argv[4], out); save(argv[5], cost);
+        return 0;
+    }
+    if (mode == "decoder") {   // decoder frames.i8 (rows: seed_id, sync type, 368 llr) : one M17FrameDecoder per seed id, text report
+        auto in = load<int8_t>(argv[2]);
+        const size_t rows = in.size() / 370;
+        struct Chan { std::unique_ptr<M17FrameDecoder> dec; size_t cost = 0; };
+        std::vector<Chan> ch(16);
+        for (size_t r = 0; r < rows; ++r) {
+            const int id = in[r * 370], st = in[r * 370 + 1];
+            Chan& c = ch[(size_t)id];
+            if (!c.dec) c.dec = std::make_unique<M17FrameDecoder>([](M17FrameDecoder::output_buffer_t const& f, int cost) {
+                const uint8_t* p = nullptr; size_t n = 0;
+                switch (f.type) {
+                case M17FrameDecoder::FrameType::LSF: p = f.lsf.data(); n = 30; break;
+                case M17FrameDecoder::FrameType::LICH: p = f.lich.data(); n = 6; break;
+                case M17FrameDecoder::FrameType::STREAM: p = f.stream.data(); n = 18; break;
+                case M17FrameDecoder::FrameType::BERT: p = f.bert.data(); n = 25; break;
+                default: p = f.packet.data(); n = 26; break;
+                }
+                std::printf("cb %d %d %zu ", (int)f.type, cost, n);
+                for (size_t i = 0; i < n; ++i) std::printf("%02x", p[i]);
+                std::printf("\n");
+                return true;
+            });
+            M17FrameDecoder::input_buffer_t buf;
+            std::memcpy(buf.data(), &in[r * 370 + 2], 368);
+            std::printf("frame %zu\n", r);
+            (*c.dec)((M17FrameDecoder::SyncWordType)st, buf, c.cost);
+            std::printf("state %d %d %d %lld ", (int)c.dec->state(), (int)c.dec->lich_segments, (int)c.dec->depuncture_buffer.bert[401], (long long)(int64_t)c.cost);
+            for (auto b : c.dec->output_buffer.lsf) std::printf("%02x", b);
+            std::printf("\n");
+        }
+        return 0;
+    }
+    if (mode == "kalman") {   // kalman order wrap z0 z.f32 dt.u32 out.f32 : m17::KalmanFilter<float,10> (wrap 10) / SymbolKalmanFilter (0)
+        const uint32_t order = (uint32_t)std::atoi(argv[2]);
+        const int wrap = std::atoi(argv[3]);
+        const float z0 = (float)std::atof(argv[4]);
+        auto z = load<float>(argv[5]); auto dt = load<uint32_t>(argv[6]);
+        std::vector<float> out;
+        m17::KalmanFilter<float, 10> kf; m17::SymbolKalmanFilter<float> sf;
+        kf.order = sf.order = order; kf.reset(z0); sf.reset(z0);
+        for (size_t i = 0; i < z.size(); ++i) {
+            if (wrap) { kf.update(z[i], dt[i]); out.insert(out.end(), {kf.x[0], kf.x[1], kf.P(0, 0), kf.P(0, 1), kf.P(1, 0), kf.P(1, 1)}); }
+            else { sf.update(z[i], dt[i]); out.insert(out.end(), {sf.x[0], sf.x[1], sf.P(0, 0), sf.P(0, 1), sf.P(1, 0), sf.P(1, 1)}); }
+        }
+        save(argv[7], out);
+        return 0;
+    }
+    if (mode == "clock") {   // clock op.u8 index.u8 count.u32 out.f32 : ClockRecovery<float,10>; per step (sample_index, clock_estimate)
+        auto op = load<uint8_t>(argv[2]); auto idx = load<uint8_t>(argv[3]); auto cnt = load<uint32_t>(argv[4]);
+        ClockRecovery<float, 10> c;
+        std::vector<float> out;
+        for (size_t i = 0; i < op.size(); ++i) {
+            for (uint32_t k = 0; k < cnt[i]; ++k) c(0.f);
+            if (op[i] == 0) c.reset((float)idx[i]); else if (op[i] == 1) c.update(idx[i]); else c.update();
+            out.push_back((float)c.sample_index()); out.push_back(c.clock_estimate());
+        }
+        save(argv[5], out);
+        return 0;
+    }
+    if (mode == "freqdev") {   // freqdev mn.f32 mx.f32 reset.u8 out.f32 : FreqDevEstimator<float>; per step (idev, offset)
+        auto mn = load<float>(argv[2]); auto mx = load<float>(argv[3]); auto rs = load<uint8_t>(argv[4]);
+        FreqDevEstimator<float> d;
+        std::vector<float> out;
+        for (size_t i = 0; i < mn.size(); ++i) {
+            if (rs[i]) d.reset();
+            d.update(mn[i], mx[i]);
+            out.push_back(d.idev()); out.push_back(d.offset());
+        }
+        save(argv[5], out);
+        return 0;
+    }
+    if (mode == "gpu_fir") {   // gpu_fir in.i16 channels samples invert out.f32 : the batched BaseFirFilter overload (kernel K1)
+        auto in = load<int16_t>(argv[2]);
+        const uint32_t C = (uint32_t)std::atoi(argv[3]), T = (uint32_t)std::atoi(argv[4]);
+        batched::Device dev(C, T);
+        BaseFirFilter<float, 150> f(TAPS);
+        std::vector<float> out((size_t)C * T);
+        const int r = f(dev, in.data(), C, T, out.data(), std::atoi(argv[5]) != 0);
+        if (r != M17HIP_OK) { std::fprintf(stderr, "batched fir: %s\n", m17hip_strerror(r)); return 3; }
+        save(argv[6], out);
+        return 0;
+    }
+    if (mode == "gpu_demod") {   // gpu_demod in.i16 block : M17Demodulator<float> fed one sample per call; prints every callback in order
+        auto in = load<int16_t>(argv[2]);
+        size_t n_diag = 0;
+        {
+            M17Demodulator<float> demod([](M17FrameDecoder::output_buffer_t const& f, int cost) {
+                const uint8_t* p = nullptr; size_t n = 0;
+                switch (f.type) {
+                case M17FrameDecoder::FrameType::LSF: p = f.lsf.data(); n = 30; break;
+                case M17FrameDecoder::FrameType::LICH: p = f.lich.data(); n = 6; break;
+                case M17FrameDecoder::FrameType::STREAM: p = f.stream.data(); n = 18; break;
+                case M17FrameDecoder::FrameType::BERT: p = f.bert.data(); n = 25; break;
+                default: p = f.packet.data(); n = 26; break;
+                }
+                std::printf("F %d %d ", (int)f.type, cost);
+                for (size_t i = 0; i < n; ++i) std::printf("%02x", p[i]);
+                std::printf("\n");
+                return true;
+            }, (uint32_t)std::atoi(argv[3]));
+            demod.diagnostics([&](bool dcd, float evm, float dev, float off, bool locked, float clock, int si, int sy, int ci, int vc) {
+                uint32_t w[4]; std::memcpy(&w[0], &evm, 4); std::memcpy(&w[1], &dev, 4); std::memcpy(&w[2], &off, 4); std::memcpy(&w[3], &clock, 4);
+                std::printf("D %d %08x %08x %08x %d %08x %d %d %d %d\n", (int)dcd, w[0], w[1], w[2], (int)locked, w[3], si, sy, ci, vc);
+                ++n_diag;
+            });
+            for (int16_t s : in) demod(s / 41067.0);
+        }   // the destructor flushes the last partial block
+        std::printf("END %zu\n", n_diag);
+        return 0;
+    }
+    std::fprintf(stderr, "unknown mode %s\n", mode.c_str());
+    return 2;
+}

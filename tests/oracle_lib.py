@@ -180,6 +180,17 @@ def demod_batch(samples2d, invert=0, cap=600, threads=8):
     return recs, counts, diags
 
 
+def demod_diag_log(samples, invert=0, cap=4096):
+    """Every diagnostic callback of one channel in order (entries laid out like m17hip_diag_log_fetch's)."""
+    lib = oracle()
+    lib.m17o_demod_diag_log.restype = C.c_size_t
+    s = np.ascontiguousarray(samples, dtype=np.int16)
+    log = np.zeros(cap, dtype=DIAG)
+    n = lib.m17o_demod_diag_log(_p(s), C.c_size_t(s.size), C.c_int(invert), _p(log), C.c_size_t(cap))
+    assert n <= cap
+    return log[:n].copy()
+
+
 def demod_symbols(samples, invert=0, cap=1 << 20):
     lib = oracle()
     s = np.ascontiguousarray(samples, dtype=np.int16)

@@ -1,0 +1,246 @@
+"""The C++ operator surface (m17-cxx-demod_amd/include/m17cxx: BaseFirFilter, Correlator / SyncWord, NSlidingDFT,
+DataCarrierDetect, ClockRecovery / KalmanFilter, FreqDevEstimator, SymbolEvm, llr, Viterbi, M17FrameDecoder, CRC16, Golay24,
+LinkSetupFrame, PRBS9 ...) driven the way a reference-style host drives it — one sample / one frame per call — by
+tests/cxx/mirror_check.cpp, against the golden vectors produced by the REFERENCE'S OWN HEADERS (tests/golden) and, for the
+blaze-dependent classes the reference cannot pin, against the oracle.  CPU tests run the scalar classes; the -m gpu tests
+run the batched overloads (C ABI -> HIP kernels) and the GPU-backed M17Demodulator through the same program."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cxx", "mirror_check")
+SRC = EXE + ".cpp"
+
+
+@pytest.fixture(scope="module")
+def exe():
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(SRC):
+        pkg = os.path.join(ROOT, "m17-cxx-demod_amd")
+        subprocess.run(["g++", "-std=c++20", "-O2", "-ffp-contract=off", "-I", os.path.join(pkg, "include", "m17cxx"), SRC, "-L", pkg, "-lm17hip",
+                        "-Wl,-rpath," + pkg, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", EXE], check=True)
+    return EXE
+
+
+def run(exe, *args, text=False):
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def test_reference_unit_test_values(exe):
+    assert run(exe, "kat").strip() == "kat ok"
+
+
+def test_scaling_and_fir_equal_reference(exe, golden, tmp_path):
+    for tag, inv in (("", 0), ("inv_", 1), ("dc_", 0), ("zero_", 0)):
+        s = golden[tag + "sig_i16"]
+        s.tofile(tmp_path / "s.i16")
+        run(exe, "scale", tmp_path / "s.i16", inv, tmp_path / "x.f32")      # also asserts float(s / 41067.0) == core::scale_i16 bitwise
+        x = np.fromfile(tmp_path / "x.f32", dtype=np.float32)
+        if tag == "":
+            assert np.array_equal(x, golden["sig_scaled"])
+        run(exe, "fir", tmp_path / "x.f32", tmp_path / "y.f32")
+        assert np.array_equal(np.fromfile(tmp_path / "y.f32", dtype=np.float32), golden[tag + "fir_out"]), tag
+    every = np.arange(-32768, 32768, dtype=np.int32).astype(np.int16)
+    every.tofile(tmp_path / "all.i16")
+    for inv in (0, 1):
+        run(exe, "scale", tmp_path / "all.i16", inv, tmp_path / "all.f32")
+        assert np.array_equal(np.fromfile(tmp_path / "all.f32", dtype=np.float32), ol.scale(every, invert=inv))
+
+
+def test_correlator_and_syncwords_equal_reference(exe, golden, tmp_path):
+    for tag in ("", "inv_", "dc_", "zero_"):
+        y = golden[tag + "fir_out"]
+        y.tofile(tmp_path / "y.f32")
+        run(exe, "corr", tmp_path / "y.f32", tmp_path / "c.f32")
+        out = np.fromfile(tmp_path / "c.f32", dtype=np.float32).reshape(17, -1)
+        assert np.array_equal(out[0], golden[tag + "corr_limit"]) and np.array_equal(out[1:5], golden[tag + "corr_values"]), tag
+        if tag == "":
+            for w in range(4):
+                assert np.array_equal(out[5 + 3 * w], golden[f"sync{w}_trig"]), w
+                assert np.array_equal(out[6 + 3 * w].astype(np.uint8), golden[f"sync{w}_timing"]), w
+                assert np.array_equal(out[7 + 3 * w].astype(np.int8), golden[f"sync{w}_updated"]), w
+    golden["fir_out"].tofile(tmp_path / "y.f32")
+    for n, si, mn, mx in golden["outer_levels"]:
+        a, b = run(exe, "outer", tmp_path / "y.f32", int(n), int(si)).split()
+        got = np.array([int(a, 16), int(b, 16)], dtype=np.uint32).view(np.float32)
+        assert (float(got[0]), float(got[1])) == (mn, mx)
+
+
+def test_sliding_dft_and_carrier_detect_equal_reference(exe, golden, tmp_path):
+    golden["sig_scaled"].tofile(tmp_path / "x.f32")
+    run(exe, "sdft", tmp_path / "x.f32", 600, tmp_path / "d.f32")
+    assert np.array_equal(np.fromfile(tmp_path / "d.f32", dtype=np.float32), golden["sdft_first600"])
+    for tag, inv in (("", 0), ("inv_", 1), ("dc_", 0), ("zero_", 0)):
+        ol.scale(golden[tag + "sig_i16"], invert=inv).tofile(tmp_path / "x.f32")
+        for period in (384, 960):
+            run(exe, "dcd", tmp_path / "x.f32", period, tmp_path / "l.f32")
+            out = np.fromfile(tmp_path / "l.f32", dtype=np.float32).reshape(-1, 2)
+            assert np.array_equal(out[:, 0], golden[f"{tag}dcd{period}_level"], equal_nan=True), (tag, period)
+            assert np.array_equal(out[:, 1].astype(np.uint8), golden[f"{tag}dcd{period}_trig"]), (tag, period)
+
+
+def test_slicer_and_evm_equal_reference(exe, golden, tmp_path):
+    golden["llr_in"].tofile(tmp_path / "s.f32")
+    run(exe, "llr", tmp_path / "s.f32", tmp_path / "l.i8", tmp_path / "e.f32")
+    assert np.array_equal(np.fromfile(tmp_path / "l.i8", dtype=np.int8), golden["llr_out"])
+    golden["llr_in"][4001:6001].tofile(tmp_path / "s.f32")
+    run(exe, "llr", tmp_path / "s.f32", tmp_path / "l.i8", tmp_path / "e.f32")
+    assert np.array_equal(np.fromfile(tmp_path / "e.f32", dtype=np.float32), golden["evm_out"])
+    # every float within +-64 ulp of each of the 43 table edges, NaN and infinities: the class == the oracle's table walk
+    import ctypes as C
+    edges = np.zeros(43, dtype=np.float32); l0 = np.zeros(43, np.int8); l1 = np.zeros(43, np.int8)
+    ol.oracle().m17o_llr_table(ol._p(edges), ol._p(l0), ol._p(l1))
+    near = []
+    for e in edges:
+        cur = np.float32(e)
+        for _ in range(64):
+            cur = np.nextafter(cur, np.float32(-10))
+        for _ in range(129):
+            near.append(cur)
+            cur = np.nextafter(cur, np.float32(10))
+    sym = np.concatenate([np.array(near, np.float32), np.array([np.nan, np.inf, -np.inf, -0.0, 0.0, 3.0, -3.0, 1e-45], np.float32)])
+    sym.tofile(tmp_path / "s.f32")
+    run(exe, "llr", tmp_path / "s.f32", tmp_path / "l.i8", tmp_path / "e.f32")
+    assert np.array_equal(np.fromfile(tmp_path / "l.i8", dtype=np.int8), ol.llr(sym))
+
+
+def _viterbi(exe, golden, tmp_path, mode):
+    golden["vit_in"].tofile(tmp_path / "v.i8")
+    golden["vit_meta"].astype(np.int64).tofile(tmp_path / "m.i64")
+    run(exe, mode, tmp_path / "v.i8", tmp_path / "m.i64", tmp_path / "o.u8", tmp_path / "c.i64")
+    out = np.fromfile(tmp_path / "o.u8", dtype=np.uint8).reshape(-1, 240)
+    cost = np.fromfile(tmp_path / "c.i64", dtype=np.int64)
+    for row, (IN, OUT, c) in enumerate(golden["vit_meta"]):
+        assert cost[row] == c and np.array_equal(out[row, :OUT], golden["vit_out"][row, :OUT]), row
+    # the reference's own LSF known-answer vector (tests/ViterbiTest.cpp:173-195)
+    exp = np.array(golden["kat"]["lsf_expected240"], dtype=np.uint8)
+    enc = np.array(golden["kat"]["lsf_encoded488"], dtype=np.int16)
+    enc[11] = 1
+    (enc * 14 - 7).astype(np.int8).tofile(tmp_path / "v.i8")
+    np.array([488, 240, 0], dtype=np.int64).tofile(tmp_path / "m.i64")
+    run(exe, mode, tmp_path / "v.i8", tmp_path / "m.i64", tmp_path / "o.u8", tmp_path / "c.i64")
+    assert np.fromfile(tmp_path / "c.i64", dtype=np.int64)[0] == 0
+    assert np.array_equal(np.fromfile(tmp_path / "o.u8", dtype=np.uint8)[:240], exp)
+
+
+def test_viterbi_equals_reference(exe, golden, tmp_path):
+    _viterbi(exe, golden, tmp_path, "viterbi")
+
+
+def test_frame_decoder_equals_reference_sequences(exe, golden, tmp_path):
+    """M17FrameDecoder objects (one per recorded sequence) fed the recorded frames: every callback, the decoder state, the LICH
+    bitmap, the LSF buffer, the stale depuncture byte [401] (Q4) and the cost as the reference's own M17FrameDecoder left them."""
+    seqs = golden["kat"]["frame_decoder_sequences"]
+    ids = {seed: i for i, seed in enumerate(sorted({e["seed"] for e in seqs}))}
+    rows = np.zeros((len(seqs), 370), dtype=np.int8)
+    for r, e in enumerate(seqs):
+        rows[r, 0], rows[r, 1], rows[r, 2:] = ids[e["seed"]], e["st"], np.array(e["llr"], dtype=np.int8)
+    rows.tofile(tmp_path / "f.i8")
+    lines = run(exe, "decoder", tmp_path / "f.i8").strip().split("\n")
+    blocks, cur = [], None
+    for ln in lines:
+        if ln.startswith("frame "):
+            cur = dict(cbs=[], state=None); blocks.append(cur)
+        elif ln.startswith("cb "):
+            _, t, cost, n, hx = ln.split()
+            cur["cbs"].append((int(t), int(cost), int(n), hx))
+        else:
+            _, st, lich, d401, cost, lsf = ln.split()
+            cur["state"] = (int(st), int(lich), int(d401), int(cost), lsf)
+    assert len(blocks) == len(seqs)
+    for e, b in zip(seqs, blocks):
+        exp_cbs = [(t, c, n, hx[: 2 * n]) for (t, c, n, hx) in (tuple(v) for v in e["recs"])]
+        assert b["cbs"] == exp_cbs, (e["seed"], e["f"])
+        assert b["state"] == (e["state"], e["lich"], e["d401"], e["cost"], bytes(e["lsf"]).hex()), (e["seed"], e["f"])
+
+
+def test_kalman_clock_and_deviation_classes_equal_the_oracle(exe, tmp_path):
+    """a9 / a10: the classes share core::kalman2_update with the kernels; against the oracle's restatement, every order."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    z = ((5.0 + rng.normal(0, 2.5, 300)) % 10.0).astype(np.float32)
+    dt = rng.choice([1920, 960, 3840, 17, 19200], 300).astype(np.uint32)
+    lv = (-5.2 * (1 + rng.normal(0, 0.05, 300))).astype(np.float32)
+    z.tofile(tmp_path / "z.f32"); dt.tofile(tmp_path / "dt.u32"); lv.tofile(tmp_path / "lv.f32")
+    np.full(300, 192, np.uint32).tofile(tmp_path / "d192.u32")
+    lib = ol.oracle()
+    try:
+        for order in range(8):
+            lib.m17o_set_kalman_order(C.c_int(order))
+            for wrap, zz, dd, z0, zf, df in ((10, z, dt, 4.0, "z.f32", "dt.u32"), (0, lv, np.full(300, 192, np.uint32), -5.0, "lv.f32", "d192.u32")):
+                exp = np.zeros((300, 6), dtype=np.float32)
+                lib.m17o_kalman_trace(ol._p(zz), ol._p(np.ascontiguousarray(dd, dtype=np.uint32)), C.c_size_t(300), C.c_int(wrap), C.c_float(z0), ol._p(exp))
+                run(exe, "kalman", order, wrap, z0, tmp_path / zf, tmp_path / df, tmp_path / "k.f32")
+                assert np.array_equal(np.fromfile(tmp_path / "k.f32", dtype=np.float32).reshape(300, 6), exp), (order, wrap)
+    finally:
+        lib.m17o_set_kalman_order(C.c_int(3))
+    op = rng.choice([0, 1, 1, 1, 2, 2], 400).astype(np.uint8); op[0] = 0
+    idx = rng.integers(0, 10, 400).astype(np.uint8)
+    cnt = rng.choice([1920, 1920, 10, 5, 960, 77], 400).astype(np.uint32)
+    si = np.zeros(400, np.uint8); ce = np.zeros(400, np.float32)
+    lib.m17o_clock(ol._p(op), ol._p(idx), ol._p(cnt), C.c_size_t(400), ol._p(si), ol._p(ce))
+    op.tofile(tmp_path / "op.u8"); idx.tofile(tmp_path / "idx.u8"); cnt.tofile(tmp_path / "cnt.u32")
+    run(exe, "clock", tmp_path / "op.u8", tmp_path / "idx.u8", tmp_path / "cnt.u32", tmp_path / "c.f32")
+    got = np.fromfile(tmp_path / "c.f32", dtype=np.float32).reshape(400, 2)
+    assert np.array_equal(got[:, 0].astype(np.uint8), si) and np.array_equal(got[:, 1], ce)
+    mn = (-5.2 + rng.normal(0, 0.3, 200)).astype(np.float32); mx = (5.2 + rng.normal(0, 0.3, 200)).astype(np.float32)
+    mn[50] = np.nan
+    rs = (rng.random(200) < 0.05).astype(np.uint8)
+    idev = np.zeros(200, np.float32); off = np.zeros(200, np.float32)
+    lib.m17o_freqdev(ol._p(mn), ol._p(mx), C.c_size_t(200), ol._p(rs), ol._p(idev), ol._p(off))
+    mn.tofile(tmp_path / "mn.f32"); mx.tofile(tmp_path / "mx.f32"); rs.tofile(tmp_path / "rs.u8")
+    run(exe, "freqdev", tmp_path / "mn.f32", tmp_path / "mx.f32", tmp_path / "rs.u8", tmp_path / "f.f32")
+    got = np.fromfile(tmp_path / "f.f32", dtype=np.float32).reshape(200, 2)
+    assert np.array_equal(got[:, 0], idev, equal_nan=True) and np.array_equal(got[:, 1], off, equal_nan=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU --
+@pytest.mark.gpu
+def test_batched_fir_through_the_mirror_equals_reference(exe, golden, tmp_path):
+    """BaseFirFilter<float,150>::operator()(batched::Device&, ...) -> m17hip_fir_rrc150 -> K1, against the reference's FIR output."""
+    for tag, inv in (("", 0), ("inv_", 1), ("dc_", 0)):
+        s = golden[tag + "sig_i16"]
+        np.stack([s, s, s]).tofile(tmp_path / "s.i16")
+        run(exe, "gpu_fir", tmp_path / "s.i16", 3, s.size, inv, tmp_path / "y.f32")
+        y = np.fromfile(tmp_path / "y.f32", dtype=np.float32).reshape(3, -1)
+        for c in range(3):
+            assert np.array_equal(y[c], golden[tag + "fir_out"]), (tag, c)
+
+
+@pytest.mark.gpu
+def test_batched_viterbi_through_the_mirror_equals_reference(exe, golden, tmp_path):
+    """Viterbi<Trellis<4,2>,4>::decode<IN,OUT>(batched::Device&, ...) -> m17hip_viterbi, golden frames of all four shapes + the LSF KAT."""
+    _viterbi(exe, golden, tmp_path, "gpu_viterbi")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,block", [(0, 1920), (1, 1920), (2, 5000), (1, 9600)])
+def test_gpu_backed_demodulator_delivers_the_reference_callback_sequence(exe, tmp_path, kind, block):
+    """mobilinkd::M17Demodulator<float> (GPU-backed) fed one sample per call like apps/m17-demod.cpp:484-490: the interleaved
+    sequence of frame and diagnostic callbacks — every one of them, in order, arguments bit for bit — equals the oracle's, for
+    block sizes that do and do not divide the stream; the destructor flushes the tail."""
+    p = ol.gen_params(seed=40 + kind, kind=kind, n_frames=9, lead_in=3072, noise_sigma=500.0, tail_sigma=500.0, lead_sigma=40000.0, total=33333)
+    x = ol.generate(p)
+    x.tofile(tmp_path / "x.i16")
+    lines = run(exe, "gpu_demod", tmp_path / "x.i16", block).strip().split("\n")
+    recs, _ = ol.demod(x)
+    log = ol.demod_diag_log(x)
+    events = [(int(r["sample_pos"]), 0, r) for r in recs] + [(int(d["pad"][0]) | (int(d["pad"][1]) << 32), 1, d) for d in log]
+    events.sort(key=lambda e: (e[0], e[1]))
+    exp = []
+    for _, k, e in events:
+        if k == 0:
+            exp.append(f"F {int(e['frame_type'])} {int(e['cost'])} {bytes(e['payload'][:int(e['len'])]).hex()}")
+        else:
+            w = [int(np.array(e[f], dtype=np.float32).view(np.uint32)) for f in ("evm", "deviation", "offset", "clock")]
+            exp.append(f"D {int(e['dcd'])} {w[0]:08x} {w[1]:08x} {w[2]:08x} {int(e['locked'])} {w[3]:08x} {int(e['sample_index'])} "
+                       f"{int(e['sync_index'])} {int(e['clock_index'])} {int(e['viterbi_cost'])}")
+    exp.append(f"END {log.size}")
+    assert len(recs) >= 5 and log.size > 30
+    assert lines == exp
