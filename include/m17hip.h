@@ -255,6 +255,9 @@ void m17hip_comm_destroy(m17hip_comm* comm);
 int m17hip_comm_last_error(const m17hip_comm* comm);
 int m17hip_gather_frames(m17hip_ctx* ctx, m17hip_comm* comm, int root, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* counts,
                          uint64_t* total);
+/* Same, with the root's destination in DEVICE memory on the root's GPU (the gathered set stays in HBM for a device-side consumer). */
+int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m17_frame_rec* recs_dev, uint64_t capacity, uint64_t* counts,
+                                uint64_t* total);
 
 /* Tuning knobs (performance only, never results).  key 0: waves (= channels) per workgroup of the sequential kernel
  * (0 = default 4; 1, 2, 4, 8).  key 1: per-channel tick counters of that kernel on/off (m17hip_debug_counters).

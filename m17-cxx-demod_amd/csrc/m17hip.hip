@@ -1277,8 +1277,8 @@ void m17hip_comm_destroy(m17hip_comm* m)
     delete m;
 }
 
-int m17hip_gather_frames(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* counts_host,
-                         uint64_t* total_out)
+static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* counts_host,
+                              uint64_t* total_out, bool dest_is_device)
 {
     if (!c || !m || m->ctx != c || root < 0 || root >= m->nranks || (m->rank == root && capacity && !recs_host)) return M17HIP_EINVAL;
     GUARD(c);
@@ -1326,7 +1326,7 @@ int m17hip_gather_frames(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame_rec*
         }
         RCCLCHK(R.GroupEnd());
         const uint64_t n = std::min(total, capacity);
-        if (n) HIPCHK(c, hipMemcpyAsync(recs_host, m->gathered, (size_t)n * sizeof(FrameRec), hipMemcpyDeviceToHost, c->stream));
+        if (n) HIPCHK(c, hipMemcpyAsync(recs_host, m->gathered, (size_t)n * sizeof(FrameRec), dest_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (overflow) return M17HIP_EOVERFLOW;
         return total > capacity ? M17HIP_ETRUNC : M17HIP_OK;
@@ -1339,6 +1339,15 @@ int m17hip_gather_frames(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame_rec*
     HIPCHK(c, hipStreamSynchronize(c->stream));
 #undef RCCLCHK
     return overflow ? M17HIP_EOVERFLOW : M17HIP_OK;
+}
+
+int m17hip_gather_frames(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* counts_host, uint64_t* total_out)
+{
+    return gather_frames_impl(c, m, root, recs_host, capacity, counts_host, total_out, false);
+}
+int m17hip_gather_frames_device(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame_rec* recs_dev, uint64_t capacity, uint64_t* counts_host, uint64_t* total_out)
+{
+    return gather_frames_impl(c, m, root, recs_dev, capacity, counts_host, total_out, true);
 }
 
 int m17hip_comm_last_error(const m17hip_comm* m) { return m ? m->last_rccl : 0; }

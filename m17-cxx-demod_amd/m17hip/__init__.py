@@ -38,7 +38,7 @@ EXPORTS = [
     "m17hip_slice_llr", "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_packets_fetch", "m17hip_packets_feed", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
     "m17hip_set_kalman_order", "m17hip_kalman_trace", "m17hip_set_channel_base", "m17hip_upload_wait", "m17hip_comm_get_id", "m17hip_comm_create",
-    "m17hip_comm_destroy", "m17hip_comm_last_error", "m17hip_gather_frames", "m17hip_diag_log_fetch",
+    "m17hip_comm_destroy", "m17hip_comm_last_error", "m17hip_gather_frames", "m17hip_gather_frames_device", "m17hip_diag_log_fetch",
 ]
 ETRUNC = -6
 COMM_ID_BYTES = 128
@@ -241,6 +241,14 @@ class Context:
         recs = np.empty(capacity, dtype=FRAME_REC) if is_root else None
         self._chk(self.lib.m17hip_gather_frames(self.h, comm.h, C.c_int(root), _ptr(recs), C.c_uint64(capacity), _ptr(counts), C.byref(total)))
         return (recs[: total.value] if is_root else None), counts
+
+    def gather_frames_device(self, comm, dev_ptr, capacity, root=0):
+        """Collective: like gather_frames, the root's copy written to device memory at dev_ptr.  Returns (total, counts per rank)."""
+        counts = np.zeros(comm.nranks, dtype=np.uint64)
+        total = C.c_uint64(0)
+        self._chk(self.lib.m17hip_gather_frames_device(self.h, comm.h, C.c_int(root), C.c_void_p(int(dev_ptr)), C.c_uint64(capacity), _ptr(counts),
+                                                       C.byref(total)))
+        return total.value, counts
 
     def reset(self):
         self._chk(self.lib.m17hip_demod_reset(self.h))
