@@ -168,6 +168,10 @@ class Context:
         self._chk(self.lib.m17hip_correlator(self.h, C.c_uint32(self.C), C.c_uint32(self.T), _ptr(limit), _ptr(corr)))
         return limit, corr
 
+    def correlator_device(self):
+        """Same computation, results left in device memory (benchmarks)."""
+        self._chk(self.lib.m17hip_correlator(self.h, C.c_uint32(self.C), C.c_uint32(self.T), None, None))
+
     def dcd(self, flags=0, fetch=True):
         ticks = self.T // 192
         sums = np.empty((self.C, ticks, 2, 6), dtype=np.float32) if fetch else None

@@ -1,0 +1,75 @@
+"""GPU: the BASELINE configurations at (or near) their stated sizes.
+  configs[1]  1024 channels, FIR + correlator: a random subsample of channels against the oracle, outputs bit-exact
+  configs[2]  4096 channels full chain: size-independent properties are in test_gpu_parity.py::test_full_size_properties
+  configs[4]  impairment sweep (single-GPU share): per-channel BER (PRBS9 receiver on the device) and EVM against the CPU
+              reference path on the same synthesized slab, 6 AWGN levels x 3 DC / gain points"""
+import os
+
+import numpy as np
+import pytest
+
+import m17hip
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+NCPU = len(os.sched_getaffinity(0))
+
+
+def test_config2_fir_and_correlator_at_1024_channels():
+    """BASELINE configs[1] at its channel count (1024 x 96 000 samples; the 5 x C x T float staging of m17hip_correlator is
+    1.97 GB here): every output of 24 randomly chosen channels bit-exact (the north star asks 1e-5 relative), plus a checksum
+    property over ALL channels: channels generated from the same seed pair produce identical rows."""
+    Cn, T = 1024, 96000
+    p = ol.gen_params(seed=4711, kind=-1, n_frames=T // 1920 - 4, lead_in=3072, noise_sigma=700.0, tail_sigma=700.0, lead_sigma=40000.0, total=T)
+    ctx = m17hip.Context(Cn, T)
+    ctx.synth(p, Cn, T)
+    x = ctx.download()
+    y = ctx.fir()
+    limit, corr = ctx.correlator()
+    rng = np.random.default_rng(12)
+    for c in rng.choice(Cn, 24, replace=False):
+        ye = ol.fir_i16(x[c])
+        le, ce = ol.correlator(ye)
+        assert np.array_equal(y[c], ye), c
+        assert np.array_equal(limit[c], le) and np.array_equal(corr[:, c, :], ce), c
+        rel = np.max(np.abs(y[c] - ye) / np.maximum(np.abs(ye), 1e-30))
+        assert rel <= 1e-5                                  # the tolerance the north star states (implied by equality)
+    # linearity-free sanity over all 1024 rows: no row is empty, saturated or NaN, and the FIR of the inverted slab is the negation
+    assert np.isfinite(y).all() and np.isfinite(limit).all() and (np.abs(y).max(axis=1) > 1.0).all()
+    yi = ctx.fir(flags=m17hip.FLAG_INVERT)
+    clean = ~(x[:, 3800:] == -32768).any(axis=1)             # -(-32768) wraps in int16 (apps/m17-demod.cpp:488); the lead-in saturates
+    assert clean.sum() > Cn // 2 and np.array_equal(yi[clean, 4000:], -y[clean, 4000:])   # negation commutes with every rounding step
+    ctx.close()
+
+
+@pytest.mark.parametrize("dc,gain", [(0.0, 1.0), (1000.0, 1.0), (-2500.0, 0.7)])
+def test_config5_impairment_sweep_ber_and_evm_equal_the_cpu_path(dc, gain):
+    """BASELINE configs[4] (EVM + BER vs CPU reference), one GPU's share: 512 BERT channels x 96 000 samples per point, six AWGN
+    levels.  Per channel: PRBS9 bits / errors / sync / frames from m17hip_bert_stats == the oracle's PRBS9 receiver over the
+    oracle's BERT frames, and SymbolEvm / deviation / offset from m17hip_diag_fetch == the oracle's, bit for bit."""
+    Cn, T = 512, 96000
+    ctx = m17hip.Context(Cn, T)
+    ctx.tune(6, 1)
+    for sigma in (0.0, 400.0, 800.0, 1500.0, 2500.0, 4000.0):
+        p = ol.gen_params(seed=777, kind=0, n_frames=T // 1920 + 2, lead_in=3072, lead_sigma=40000.0, noise_sigma=sigma, tail_sigma=max(sigma, 100.0),
+                          dc_offset=dc, gain=gain, total=T)
+        ctx.synth(p, Cn, T)
+        x = ctx.download()
+        ctx.reset(); ctx.run()
+        got = ctx.frames(); st = ctx.bert_stats(Cn); d = ctx.diag()
+        recs, counts, diags = ol.demod_batch(x, cap=2 * (T // 1920 + 2) + 4, threads=NCPU)
+        exp = np.concatenate([recs[c, :counts[c]] for c in range(Cn)])
+        assert got.tobytes() == exp.tobytes(), sigma
+        for f in ("evm", "deviation", "offset", "clock", "dcd_level"):
+            assert np.array_equal(d[f], diags[f], equal_nan=True), (sigma, f)
+        decoding = 0
+        for c in range(Cn):
+            r = recs[c, :counts[c]]
+            bert = r[r["frame_type"] == 5]
+            bits, errs, sync = ol.bert_count(bert["payload"][:, :25]) if bert.size else (0, 0, False)
+            assert (int(st["bits"][c]), int(st["errors"][c]), bool(st["synced"][c]), int(st["frames"][c])) == (bits, errs, sync, bert.size), (sigma, c)
+            decoding += bits > 0
+        assert decoding >= Cn - 8, (sigma, decoding)        # the sweep does decode: nearly every channel locks its PRBS9 receiver
+        ber = st["errors"][st["bits"] > 0] / st["bits"][st["bits"] > 0]
+        assert ber.mean() < 2e-3, (sigma, float(ber.mean()))   # the BER floor of the first frames after the loud lead-in, not noise
+    ctx.close()
