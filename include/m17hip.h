@@ -266,7 +266,8 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * (default 0 = like the others).  key 6: BERT statistics on/off (m17hip_bert_stats; default off).  key 7: packet reassembly, value = packets of room per run (m17hip_packets_fetch; default 0 = off).  key 5: segments the front end (K1, K3) may run ahead of the sequential kernel
  * (default 0 = unlimited).  key 8 (not a performance knob): record slots per channel and run actually used, 0 = all that were
  * allocated (2 per 1920 samples + 8, which a run cannot outgrow) — a smaller value makes M17HIP_EOVERFLOW reachable for tests.
- * key 9: diagnostic log, value = diagnostic callbacks of room per channel and run (m17hip_diag_log_fetch; default 0 = off). */
+ * key 9: diagnostic log, value = diagnostic callbacks of room per channel and run (m17hip_diag_log_fetch; default 0 = off).
+ * key 10: form of the carrier-detect kernel K3: 0 = four-wave pipeline (default), 1 = one wave per 32 channels. */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 
 /* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][24] =

@@ -67,6 +67,7 @@ struct m17hip_ctx {
     uint32_t diag_cap = 0;
     uint32_t kalman_order = 3;        // evaluation order of the Kalman updates (m17hip_set_kalman_order)
     uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
+    bool dcd_single_wave = false;     // tuning knob 10: K3 as one wave per 32 channels (dcd_kernel) instead of the four-wave pipeline
     bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     uint32_t seg0_len = 0;            // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others; measured neutral)
@@ -513,8 +514,12 @@ int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_
     Timed tm(c, KT_DCD, st);
     // table rows are numbered from the first tick of the RUN: a later segment continues where the previous one stopped
     const uint64_t row0 = (c->pos + t0) / TICK - c->pos / TICK;
-    hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW * DCD_WPB - 1) / (DCD_CPW * DCD_WPB)), dim3(64 * DCD_WPB), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
-                       c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
+    if (c->dcd_single_wave)
+        hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW * DCD_WPB - 1) / (DCD_CPW * DCD_WPB)), dim3(64 * DCD_WPB), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+                           c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
+    else
+        hipLaunchKernelGGL(dcd_pipe_kernel, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+                           c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
@@ -1395,6 +1400,9 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         HIPCHK(c, hipGetLastError());
         return M17HIP_OK;
     }
+    case 10:  // K3 form: 0 = four-wave pipeline (default), 1 = single wave per 32 channels
+        c->dcd_single_wave = value != 0;
+        return M17HIP_OK;
     case 9: {  // diagnostic log: room for `value` diagnostic callbacks per channel and run, 0 = off (m17hip_diag_log_fetch)
         if (value < 0 || value > (1 << 20)) return M17HIP_EINVAL;
         HIPCHK(c, hipStreamSynchronize(c->stream));
