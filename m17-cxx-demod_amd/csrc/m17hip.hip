@@ -67,6 +67,7 @@ struct m17hip_ctx {
     uint32_t diag_cap = 0;
     uint32_t kalman_order = 3;        // evaluation order of the Kalman updates (m17hip_set_kalman_order)
     uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
+    uint32_t front_first = 0;         // tuning knob 12: segments of K1 that must be complete before the first K5 starts (0 = its own only)
     bool dcd_single_wave = false;     // tuning knob 10: K3 as one wave per 32 channels (dcd_kernel) instead of the four-wave pipeline
     bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
@@ -514,11 +515,14 @@ int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_
     Timed tm(c, KT_DCD, st);
     // table rows are numbered from the first tick of the RUN: a later segment continues where the previous one stopped
     const uint64_t row0 = (c->pos + t0) / TICK - c->pos / TICK;
-    if (c->dcd_single_wave)
+    if (c->dcd_single_wave || T % DP_BLK != 0 || (c->pos + t0) % DP_BLK != 0 || t0 % 8 != 0 || T < 4 * DP_BLK)
         hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW * DCD_WPB - 1) / (DCD_CPW * DCD_WPB)), dim3(64 * DCD_WPB), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
                            c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
+    else if (flags & 1u)
+        hipLaunchKernelGGL(dcd_pipe_kernel<true>, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+                           c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
     else
-        hipLaunchKernelGGL(dcd_pipe_kernel, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+        hipLaunchKernelGGL(dcd_pipe_kernel<false>, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
                            c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
@@ -975,6 +979,10 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         const uint32_t t0 = seg_t0(k), len = seg_t0(k + 1) - t0;
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fir[k], 0));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dcd[k], 0));
+        if (k == 0 && c->front_first > 1 && ahead >= nseg) {   // the matched filter of the first `front_first` segments has the chip to itself
+            const uint32_t last = std::min(c->front_first, nseg) - 1u;
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fir[last], 0));
+        }
         if (c->speculate) {
             if (k == 0) {
                 if ((r = launch_gate(0, c->stream, false, false))) return r;
@@ -1398,6 +1406,20 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         hipLaunchKernelGGL(packet_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, (PacketState*)c->pkt_state, c->maxC);
         HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
         HIPCHK(c, hipGetLastError());
+        return M17HIP_OK;
+    }
+    case 12:  // segments of K1 complete before the first K5 (0 / 1 = its own only)
+        if (value < 0 || value > 1000) return M17HIP_EINVAL;
+        c->front_first = (uint32_t)value;
+        return M17HIP_OK;
+    case 11: {  // stream priorities of the front end: bit 0 = K1's stream lowest, bit 1 = K3's stream lowest, bit 2 = K3's stream highest
+        HIPCHK(c, hipDeviceSynchronize());
+        int least = 0, greatest = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        hipStreamDestroy(c->side); hipStreamDestroy(c->side2);
+        c->side = c->side2 = nullptr;
+        HIPCHK(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, (value & 2) ? least : ((value & 4) ? greatest : 0)));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, (value & 1) ? least : 0));
         return M17HIP_OK;
     }
     case 10:  // K3 form: 0 = four-wave pipeline (default), 1 = single wave per 32 channels

@@ -10,6 +10,12 @@ for p in (HERE, ROOT, os.path.join(ROOT, "m17-cxx-demod_amd")):
         sys.path.insert(0, p)
 
 
+try:   # torch first: it carries its own HIP runtime, and a process that has initialised the GPU through the system one (libm17hip.so)
+    import torch  # noqa: F401  before importing torch finds "no HIP GPUs" in torch afterwards (seen when a single GPU test file is run)
+except Exception:   # pragma: no cover
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

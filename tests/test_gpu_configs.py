@@ -69,7 +69,7 @@ def test_config5_impairment_sweep_ber_and_evm_equal_the_cpu_path(dc, gain):
             bits, errs, sync = ol.bert_count(bert["payload"][:, :25]) if bert.size else (0, 0, False)
             assert (int(st["bits"][c]), int(st["errors"][c]), bool(st["synced"][c]), int(st["frames"][c])) == (bits, errs, sync, bert.size), (sigma, c)
             decoding += bits > 0
-        assert decoding >= Cn - 8, (sigma, decoding)        # the sweep does decode: nearly every channel locks its PRBS9 receiver
+        assert decoding >= int(0.95 * Cn), (sigma, decoding)   # the sweep does decode: nearly every channel locks its PRBS9 receiver
         ber = st["errors"][st["bits"] > 0] / st["bits"][st["bits"] > 0]
         assert ber.mean() < 1e-2, (sigma, float(ber.mean()))   # the BER floor of the first frames after the loud lead-in (reference behaviour), not noise
     ctx.close()
