@@ -766,7 +766,10 @@ int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, 
     {
         Timed tm(c, KT_CORR);
         hipLaunchKernelGGL(correlate_kernel, dim3((T + 255) / 256, C), dim3(256), 0, c->stream, c->ybuf, c->ypitch, corr, C, T);
-        hipLaunchKernelGGL(limit_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
+        if (T % LP_TILE == 0 && T >= 4 * LP_TILE && (((size_t)C * T) & 3) == 0)
+            hipLaunchKernelGGL(limit_pipe_kernel, dim3((C + 63) / 64), dim3(320), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
+        else
+            hipLaunchKernelGGL(limit_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
     }
     HIPCHK(c, hipGetLastError());
     if (limit_host) HIPCHK(c, hipMemcpyAsync(limit_host, limit, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));

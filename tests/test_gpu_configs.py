@@ -42,6 +42,25 @@ def test_config2_fir_and_correlator_at_1024_channels():
     ctx.close()
 
 
+@pytest.mark.parametrize("Cn,T", [(70, 64 * 37), (1, 256), (64, 64 * 150), (129, 64 * 5), (33, 30000)])
+def test_correlator_limit_pipeline_and_single_wave_forms(Cn, T):
+    """m17hip_correlator picks the five-wave pipeline for the limit filter when the length is a multiple of 64 (>= 256) and the
+    one-lane-per-channel kernel otherwise: both against the oracle, channel counts that do and do not fill a workgroup, incl. a
+    burst that decays through the subnormal range."""
+    p = ol.gen_params(seed=900 + Cn, kind=-1, n_frames=max(1, T // 1920 - 2), lead_in=500, noise_sigma=800.0, tail_sigma=800.0, lead_sigma=30000.0, total=T)
+    x = ol.generate_batch(p, Cn, T, threads=8)
+    x[0, min(300, T // 2):] = 0                      # channel 0: exact zeros after a burst -> denormal decay of the IIR
+    ctx = m17hip.Context(Cn, T)
+    ctx.upload(x)
+    y = ctx.fir()
+    limit, corr = ctx.correlator()
+    for c in range(Cn):
+        le, ce = ol.correlator(y[c])
+        assert np.array_equal(limit[c], le), (Cn, T, c)
+        assert np.array_equal(corr[:, c, :], ce), (Cn, T, c)
+    ctx.close()
+
+
 @pytest.mark.parametrize("dc,gain", [(0.0, 1.0), (1000.0, 1.0), (-2500.0, 0.7)])
 def test_config5_impairment_sweep_ber_and_evm_equal_the_cpu_path(dc, gain):
     """BASELINE configs[4] (EVM + BER vs CPU reference), one GPU's share: 512 BERT channels x 96 000 samples per point, six AWGN
