@@ -267,7 +267,9 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * (default 0 = unlimited).  key 8 (not a performance knob): record slots per channel and run actually used, 0 = all that were
  * allocated (2 per 1920 samples + 8, which a run cannot outgrow) — a smaller value makes M17HIP_EOVERFLOW reachable for tests.
  * key 9: diagnostic log, value = diagnostic callbacks of room per channel and run (m17hip_diag_log_fetch; default 0 = off).
- * key 10: form of the carrier-detect kernel K3: 0 = four-wave pipeline (default), 1 = one wave per 32 channels. */
+ * key 10: form of the carrier-detect kernel K3: 0 = one wave per 32 channels (default), 1 = four-wave pipeline (1.8x faster alone,
+ * four times the wave slots).  key 11: stream priorities of the front end (bit 0: K1 lowest, bit 1: K3 lowest, bit 2: K3 highest).
+ * key 12: segments of K1 that must be complete before the first K5 starts (0 = its own only). */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 
 /* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][24] =

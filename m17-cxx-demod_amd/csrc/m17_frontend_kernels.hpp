@@ -343,7 +343,9 @@ __global__ __launch_bounds__(64 * DCD_WPB) void dcd_kernel(const int16_t* __rest
 
 
 // =====================================================================================================
-// K3 as a PIPELINE OF FOUR WAVES (the default; dcd_kernel above is kept as the single-wave form for A/B measurements).
+// K3 as a PIPELINE OF FOUR WAVES (m17hip_tune key 10 = 1; per-operator m17hip_dcd and the chain use dcd_kernel above by default:
+// measured in the chain the pipeline's four-fold wave count costs the kernels beside it more than its shorter chain gives back,
+// DESIGN.md §3.4).
 // The sliding-DFT recurrence is a latency chain: a lone wave issues one instruction per ~2.6 ns whatever it depends on, so the
 // time of this kernel is (instructions per sample ON THE WAVE THAT CARRIES THE RECURRENCE) x 2.6 ns x samples.  In dcd_kernel
 // that wave also converts the samples, squares the bins and feeds six running sums: ~13 instructions per sample, 16.8 ms per

@@ -68,7 +68,7 @@ struct m17hip_ctx {
     uint32_t kalman_order = 3;        // evaluation order of the Kalman updates (m17hip_set_kalman_order)
     uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
     uint32_t front_first = 0;         // tuning knob 12: segments of K1 that must be complete before the first K5 starts (0 = its own only)
-    bool dcd_single_wave = false;     // tuning knob 10: K3 as one wave per 32 channels (dcd_kernel) instead of the four-wave pipeline
+    bool dcd_pipeline = false;        // tuning knob 10: K3 as the four-wave pipeline (dcd_pipe_kernel) instead of one wave per 32 channels
     bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     uint32_t seg0_len = 0;            // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others; measured neutral)
@@ -515,7 +515,7 @@ int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_
     Timed tm(c, KT_DCD, st);
     // table rows are numbered from the first tick of the RUN: a later segment continues where the previous one stopped
     const uint64_t row0 = (c->pos + t0) / TICK - c->pos / TICK;
-    if (c->dcd_single_wave || T % DP_BLK != 0 || (c->pos + t0) % DP_BLK != 0 || t0 % 8 != 0 || T < 4 * DP_BLK)
+    if (!c->dcd_pipeline || T % DP_BLK != 0 || (c->pos + t0) % DP_BLK != 0 || t0 % 8 != 0 || T < 4 * DP_BLK)
         hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW * DCD_WPB - 1) / (DCD_CPW * DCD_WPB)), dim3(64 * DCD_WPB), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
                            c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
     else if (flags & 1u)
@@ -763,13 +763,19 @@ int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, 
     if (r) return r;
     float* limit = (float*)c->scratch;
     float* corr = limit + n;
-    {
+    {   // the limit filter is a handful of latency-bound workgroups, the correlations an HBM-bound elementwise pass: side by side
         Timed tm(c, KT_CORR);
-        hipLaunchKernelGGL(correlate_kernel, dim3((T + 255) / 256, C), dim3(256), 0, c->stream, c->ybuf, c->ypitch, corr, C, T);
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        hipLaunchKernelGGL(correlate_kernel, dim3((T + 255) / 256, C), dim3(256), 0, c->side, c->ybuf, c->ypitch, corr, C, T);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev_join, c->side));
         if (T % LP_TILE == 0 && T >= 4 * LP_TILE && (((size_t)C * T) & 3) == 0)
             hipLaunchKernelGGL(limit_pipe_kernel, dim3((C + 63) / 64), dim3(320), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
         else
             hipLaunchKernelGGL(limit_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
     HIPCHK(c, hipGetLastError());
     if (limit_host) HIPCHK(c, hipMemcpyAsync(limit_host, limit, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -1425,8 +1431,8 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         HIPCHK(c, hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, (value & 1) ? least : 0));
         return M17HIP_OK;
     }
-    case 10:  // K3 form: 0 = four-wave pipeline (default), 1 = single wave per 32 channels
-        c->dcd_single_wave = value != 0;
+    case 10:  // K3 form: 0 = one wave per 32 channels (default: best step time), 1 = four-wave pipeline (1.8x faster alone)
+        c->dcd_pipeline = value != 0;
         return M17HIP_OK;
     case 9: {  // diagnostic log: room for `value` diagnostic callbacks per channel and run, 0 = off (m17hip_diag_log_fetch)
         if (value < 0 || value > (1 << 20)) return M17HIP_EINVAL;

@@ -23,13 +23,15 @@ def _oracle_records(x, invert=0):
     return flat, counts, diags
 
 
-@pytest.fixture(scope="module", params=[1, 0], ids=["limit_ahead", "limit_inline"])
+@pytest.fixture(scope="module", params=[(1, 0), (0, 0), (1, 1)], ids=["limit_ahead", "limit_inline", "k3_pipeline"])
 def ctx(request):
-    """Every test runs twice: with the correlator's limit filter run ahead of the sequential kernel (K2, the default) and
-    with the sequential kernel carrying it itself (tuning knob 2 = 0, also the fallback of a dropped speculation)."""
+    """Every test runs three times: with the correlator's limit filter run ahead of the sequential kernel (K2, the default), with
+    the sequential kernel carrying it itself (tuning knob 2 = 0, also the fallback of a dropped speculation), and with the
+    carrier-detect kernel K3 in its four-wave pipeline form (tuning knob 10 = 1) instead of one wave per 32 channels."""
     c = m17hip.Context(256, 96000)
-    c.tune(2, request.param)
-    c.limit_ahead = bool(request.param)
+    c.tune(2, request.param[0])
+    c.tune(10, request.param[1])
+    c.limit_ahead = bool(request.param[0])
     yield c
     c.close()
 

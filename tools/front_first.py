@@ -9,7 +9,7 @@ ctx = m17hip.Context(C, T); ctx.synth(p, C, T); ctx.timing(True)
 buf = torch.zeros(C * (2 * (T // 1920 + 2) + 4) * 64, dtype=torch.uint8, device='cuda')
 for k3 in (0, 1):
     for ff in (0, 2, 4, 6, 8, 10):
-        ctx.tune(10, k3); ctx.tune(12, ff)
+        ctx.tune(10, 0 if k3 else 1); ctx.tune(12, ff)
         for rep in range(2):
             ctx.reset(); ctx.run(); ctx.frames_compact_device(buf.data_ptr(), buf.numel() // 64)
         ctx.timing_reset(); torch.cuda.synchronize(); t0 = time.perf_counter()

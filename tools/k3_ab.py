@@ -1,4 +1,4 @@
-"""K3 A/B on the GPU box: the four-wave pipeline (tune 10 = 0, default) against the single-wave kernel (tune 10 = 1): time alone per
+"""K3 A/B on the GPU box: the four-wave pipeline (tune 10 = 1) against the single-wave kernel (tune 10 = 0, default): time alone per
 launch over the whole slab and per 48 000-sample segment, the tables compared bit for bit; then the chain with each.
 Usage: k3_ab.py <channels> <samples>"""
 import sys, os, time, numpy as np
@@ -10,7 +10,7 @@ p = ol.gen_params(seed=20260101, kind=-1, n_frames=T // 1920 - 6, lead_in=3072, 
 ctx = m17hip.Context(C, T); ctx.synth(p, C, T); ctx.timing(True)
 tabs = {}
 for single in (1, 0):
-    ctx.tune(10, single)
+    ctx.tune(10, 0 if single else 1)
     ts = []
     for rep in range(3):
         ctx.timing_reset(); ctx.dcd(fetch=False); ts.append(ctx.timing_get('dcd')[0])
@@ -19,7 +19,7 @@ for single in (1, 0):
 print('tables identical:', tabs[0].tobytes() == tabs[1].tobytes(), flush=True)
 buf = torch.zeros(C * (2 * (T // 1920 + 2) + 4) * 64, dtype=torch.uint8, device='cuda')
 for single in (1, 0, 1, 0):
-    ctx.tune(10, single)
+    ctx.tune(10, 0 if single else 1)
     for rep in range(2):
         ctx.reset(); ctx.run(); ctx.frames_compact_device(buf.data_ptr(), buf.numel() // 64)
     ctx.timing_reset(); torch.cuda.synchronize(); t0 = time.perf_counter()

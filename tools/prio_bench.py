@@ -7,9 +7,9 @@ C, T = 4096, 480000
 p = ol.gen_params(seed=20260101, kind=-1, n_frames=T // 1920 - 6, lead_in=3072, noise_sigma=600., tail_sigma=600., lead_sigma=40000.0, total=T)
 ctx = m17hip.Context(C, T); ctx.synth(p, C, T); ctx.timing(True)
 buf = torch.zeros(C * (2 * (T // 1920 + 2) + 4) * 64, dtype=torch.uint8, device='cuda')
-for k3 in (1, 0):
-    for prio in (0, 1, 2, 3, 4, 5):
-        ctx.tune(10, k3); ctx.tune(11, prio)
+for k3, prio in [(1, 0), (1, 4), (0, 0), (0, 4), (1, 0), (1, 4), (0, 0), (0, 4), (1, 5), (0, 5), (1, 4), (0, 4)]:
+    if True:
+        ctx.tune(10, 0 if k3 else 1); ctx.tune(11, prio)
         for rep in range(2):
             ctx.reset(); ctx.run(); ctx.frames_compact_device(buf.data_ptr(), buf.numel() // 64)
         ctx.timing_reset(); torch.cuda.synchronize(); t0 = time.perf_counter()

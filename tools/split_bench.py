@@ -17,7 +17,7 @@ for G in [int(v) for v in sys.argv[3].split(',')]:
     for g in range(G):
         c = m17hip.Context(per, T); c.set_channel_base(g * per); c.synth(p, per, T, chan0=g * per)
         if G > 1: c.set_stream(streams[g].cuda_stream)
-        c.tune(2, spec); c.tune(10, k3s); c.tune(3, seg)
+        c.tune(2, spec); c.tune(10, 0 if k3s else 1); c.tune(3, seg)
         ctxs.append(c)
     bufs = [torch.zeros(per * (2 * (T // 1920 + 2) + 4) * 64, dtype=torch.uint8, device='cuda') for _ in range(G)]
     def step():
