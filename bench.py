@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--parity-channels", type=int, default=16)
     ap.add_argument("--h2d-steps", type=int, default=3, help="steps of the PCIe-inclusive leg (fresh pinned host input every step; 0 = skip)")
     ap.add_argument("--gather", choices=("auto", "cabi", "torch"), default="auto", help="N > 1: m17hip_gather_frames_device (C ABI) or m17hip/dist.py")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="m17hip_tune knob for experiments (e.g. 10=1: K3 as the four-wave pipeline); reported in config")
     args = ap.parse_args()
 
     import torch
@@ -100,6 +101,11 @@ def main():
                       tail_sigma=args.sigma, lead_sigma=40000.0, total=T)
     ctx = m17hip.Context(C, T, device=local_rank)
     ctx.set_channel_base(rank * C)     # records carry GLOBAL channel ids: the gathered set is the record set of one big run
+    tuned = {}
+    for kv in args.tune:
+        k_, v_ = kv.split("=")
+        ctx.tune(int(k_), int(v_))
+        tuned[k_] = int(v_)
     # generated ON the device, straight into the input slab (m17hip_synth_i16: m17-mod framing, RRC shaping, impairments; bit-identical to
     # the test generator ol.generate_batch, tests/test_gpu_parity.py::test_device_synthesis_bit_exact): inputs are resident in HBM
     ctx.synth(p, C, T, chan0=rank * C)
@@ -267,7 +273,7 @@ def main():
                    "frames_cost_lt_10": good, "parity_vs_oracle_first_channels": parity, "parity_channels": args.parity_channels,
                    "realtime_factor_per_channel": round(value * 1e6 / (C * world) / 48000.0, 1), "input_gen_s": round(t_gen, 1),
                    "parallelism": f"channels sharded contiguously over {world} GPU(s), global channel ids", "gather": gather_kind,
-                   "gathered_set_ordered_and_unique": gathered_ok},
+                   "gathered_set_ordered_and_unique": gathered_ok, "tune": tuned or None},
         "value_with_h2d": h2d["value_with_h2d"] if h2d else None, "h2d": h2d,
         "roofline": roofline, "cpu_baseline": cpu,
     }
