@@ -70,8 +70,12 @@ def main():
     ap.add_argument("--parity-channels", type=int, default=16)
     ap.add_argument("--h2d-steps", type=int, default=3, help="steps of the PCIe-inclusive leg (fresh pinned host input every step; 0 = skip)")
     ap.add_argument("--gather", choices=("auto", "cabi", "torch"), default="auto", help="N > 1: m17hip_gather_frames_device (C ABI) or m17hip/dist.py")
+    ap.add_argument("--in-flight", type=int, default=2, help="independent batches (contexts) whose steps overlap: the tail of one step (K2/K5 "
+                    "alternation, chip half idle) runs beside the front end of the next; 1 = one step after the other")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="m17hip_tune knob for experiments (e.g. 10=1: K3 as the four-wave pipeline); reported in config")
     args = ap.parse_args()
+    if args.in_flight > 1:   # streams of different contexts must not share a hardware queue (the runtime's default is 4 queues)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
     import torch
     import torch.distributed as dist
@@ -99,16 +103,24 @@ def main():
     t_gen = time.time()
     p = ol.gen_params(seed=20260101, kind=-1, n_frames=max(1, T // 1920 - 6), lead_in=3072, noise_sigma=args.sigma,
                       tail_sigma=args.sigma, lead_sigma=40000.0, total=T)
-    ctx = m17hip.Context(C, T, device=local_rank)
-    ctx.set_channel_base(rank * C)     # records carry GLOBAL channel ids: the gathered set is the record set of one big run
-    tuned = {}
-    for kv in args.tune:
-        k_, v_ = kv.split("=")
-        ctx.tune(int(k_), int(v_))
-        tuned[k_] = int(v_)
+    F = max(1, args.in_flight) if args.config == 3 else 1
+    ctxs, streams, tuned = [], [], {}
+    for f in range(F):   # F independent batches of C channels, each with its own device slabs and streams
+        c_ = m17hip.Context(C, T, device=local_rank)
+        c_.set_channel_base(rank * C)     # records carry GLOBAL channel ids: the gathered set is the record set of one big run
+        for kv in args.tune:
+            k_, v_ = kv.split("=")
+            c_.tune(int(k_), int(v_))
+            tuned[k_] = int(v_)
+        if F > 1:
+            streams.append(torch.cuda.Stream(device=dev))
+            c_.set_stream(streams[-1].cuda_stream)
+        ctxs.append(c_)
+    ctx = ctxs[0]
     # generated ON the device, straight into the input slab (m17hip_synth_i16: m17-mod framing, RRC shaping, impairments; bit-identical to
     # the test generator ol.generate_batch, tests/test_gpu_parity.py::test_device_synthesis_bit_exact): inputs are resident in HBM
-    ctx.synth(p, C, T, chan0=rank * C)
+    for c_ in ctxs:
+        c_.synth(p, C, T, chan0=rank * C)
     x = ctx.download() if rank == 0 else None   # host copy for the parity spot check, the cpu_baseline and the PCIe-inclusive leg (rank 0)
     t_gen = time.time() - t_gen
 
@@ -122,7 +134,8 @@ def main():
         return bench_front(args, ctx, ol, x, C, T, rank, world, dev, sync, ncpu, ncpu_affinity, cpu_quota, t_gen)
 
     rec_cap_local = C * (2 * (T // 1920 + 2) + 4)
-    rec_buf = torch.zeros(rec_cap_local * (world if rank == 0 else 1) * 64, dtype=torch.uint8, device=dev)
+    rec_bufs = [torch.zeros(rec_cap_local * (world if rank == 0 else 1) * 64, dtype=torch.uint8, device=dev) for _ in range(F)]
+    rec_buf = rec_bufs[0]
 
     # ---- the one exchange of the path (N > 1): frame records of every shard to rank 0 over RCCL --------------------------------
     gather_kind = "none (1 GPU)"
@@ -151,49 +164,70 @@ def main():
 
     last = {}
 
-    def step():
-        ctx.reset()
-        ctx.run()
+    def launch(k):            # one step = C fresh demodulators over C x T samples: queued, not waited for
+        c_ = ctxs[k % F]
+        c_.reset()
+        c_.run()
+
+    def finish(k):            # ... its records compacted on the device (N > 1: gathered to rank 0): waits for that step only
+        c_, buf = ctxs[k % F], rec_bufs[k % F]
+        last["buf"] = buf
         if world == 1:
-            return ctx.frames_compact_device(rec_buf.data_ptr(), rec_cap_local)
+            return c_.frames_compact_device(buf.data_ptr(), rec_cap_local)
         if comm is not None:
-            total, counts = ctx.gather_frames_device(comm, rec_buf.data_ptr() if rank == 0 else 0, rec_cap_local * world if rank == 0 else 0, root=0)
+            total, counts = c_.gather_frames_device(comm, buf.data_ptr() if rank == 0 else 0, rec_cap_local * world if rank == 0 else 0, root=0)
             last["counts"] = counts
             return int(total)
-        n = ctx.frames_compact_device(rec_buf.data_ptr(), rec_cap_local)
-        allrecs, counts = mdist.gather_records(rec_buf[: rec_cap_local * 64], n)
+        n = c_.frames_compact_device(buf.data_ptr(), rec_cap_local)
+        allrecs, counts = mdist.gather_records(buf[: rec_cap_local * 64], n)
         last["counts"], last["allrecs"] = counts, allrecs
         return int(allrecs.shape[0])
 
-    for _ in range(args.warmup):
-        step()
-    ctx.timing(True)
-    ctx.timing_reset()
+    def run_steps(n_steps):   # with F > 1 step k + 1 is queued before step k is waited for: its front end fills the gaps of k's tail
+        total = 0
+        if F == 1:
+            for k in range(n_steps):
+                launch(k)
+                total = finish(k)
+            return total
+        launch(0)
+        for k in range(1, n_steps):
+            launch(k)
+            total = finish(k - 1)
+        return finish(n_steps - 1)
+
+    if args.warmup:
+        run_steps(args.warmup)
+    for c_ in ctxs:
+        c_.timing(True)
+        c_.timing_reset()
     sync()
     t0 = time.perf_counter()
-    total_frames = 0
-    for _ in range(args.steps):
-        total_frames = step()
+    total_frames = run_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    ctx.timing(False)
+    for c_ in ctxs:
+        c_.timing(False)
 
     kern = {}
     for name in ("fir_rrc150", "dcd", "limit_track", "demod_seq", "compact"):
-        ms, n = ctx.timing_get(name)   # a run is processed in segments: several launches of each kernel per step
+        ms = n = 0   # a run is processed in segments: several launches of each kernel per step; summed over the batches in flight
+        for c_ in ctxs:
+            ms_, n_ = c_.timing_get(name)
+            ms, n = ms + ms_, n + n_
         kern[name] = {"ms_avg": (ms / n) if n else None, "launches": n, "ms_per_step": ms / args.steps}
 
     # ---- checks outside the timed region: parity spot check against the oracle; N > 1: the gathered set is one ordered set ----------
     parity = good = gathered_ok = None
     if rank == 0:
         if world == 1:
-            recs = ctx.frames()
+            recs = ctxs[(args.steps - 1) % F].frames()
         elif comm is not None:
-            recs = np.frombuffer(rec_buf[: total_frames * 64].cpu().numpy().tobytes(), dtype=m17hip.FRAME_REC)
+            recs = np.frombuffer(last["buf"][: total_frames * 64].cpu().numpy().tobytes(), dtype=m17hip.FRAME_REC)
         else:
             recs = np.frombuffer(last["allrecs"].cpu().numpy().tobytes(), dtype=m17hip.FRAME_REC)
         if world > 1:
@@ -273,6 +307,7 @@ def main():
                    "frames_cost_lt_10": good, "parity_vs_oracle_first_channels": parity, "parity_channels": args.parity_channels,
                    "realtime_factor_per_channel": round(value * 1e6 / (C * world) / 48000.0, 1), "input_gen_s": round(t_gen, 1),
                    "parallelism": f"channels sharded contiguously over {world} GPU(s), global channel ids", "gather": gather_kind,
+                   "steps_in_flight": F, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "gathered_set_ordered_and_unique": gathered_ok, "tune": tuned or None},
         "value_with_h2d": h2d["value_with_h2d"] if h2d else None, "h2d": h2d,
         "roofline": roofline, "cpu_baseline": cpu,

@@ -242,7 +242,8 @@ int m17hip_kalman_trace(m17hip_ctx* ctx, const float* z_host, const uint32_t* dt
 int m17hip_set_channel_base(m17hip_ctx* ctx, uint32_t channel_base);
 /* The one exchange of the path: the gather of the frame records of the last run to `root` over RCCL (xGMI inside a node).
  * Rank 0 obtains an id (ncclGetUniqueId) and hands its 128 bytes to the other ranks by any host-side channel; every rank then
- * creates its communicator (ncclCommInitRank; collective).  m17hip_gather_frames is collective: every rank compacts its
+ * creates its communicator (ncclCommInitRank; collective; any context of the same device may then gather through it, one call
+ * at a time).  m17hip_gather_frames is collective: every rank compacts its
  * records on the device, the counts are all-gathered, the records travel to `root` with their exact sizes (grouped
  * ncclSend / ncclRecv) and land in recs_host[capacity] rank after rank — with contiguous shards and channel bases set that is
  * global (channel, seq) order.  counts[nranks] (optional) and *total are filled on every rank; recs_host is only used on

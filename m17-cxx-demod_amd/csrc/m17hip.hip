@@ -104,7 +104,7 @@ struct m17hip_ctx {
 
 struct m17hip_comm {
     ncclComm_t comm = nullptr;
-    m17hip_ctx* ctx = nullptr;
+    int device = 0;                   // any context on this device may gather through the communicator (one call at a time)
     int rank = 0, nranks = 1;
     int last_rccl = 0;
     uint64_t* counts_dev = nullptr;   // [nranks]
@@ -1278,7 +1278,7 @@ int m17hip_comm_create(m17hip_ctx* c, const void* id128, int rank, int nranks, m
     if (!R.ok) return M17HIP_ECOMM;
     m17hip_comm* m = new (std::nothrow) m17hip_comm();
     if (!m) return M17HIP_ENOMEM;
-    m->ctx = c; m->rank = rank; m->nranks = nranks;
+    m->device = c->device; m->rank = rank; m->nranks = nranks;
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     const ncclResult_t r = R.CommInitRank(&m->comm, nranks, id, rank);
@@ -1292,17 +1292,20 @@ int m17hip_comm_create(m17hip_ctx* c, const void* id128, int rank, int nranks, m
 void m17hip_comm_destroy(m17hip_comm* m)
 {
     if (!m) return;
-    DeviceGuard guard_(m->ctx);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    hipSetDevice(m->device);
     if (m->counts_dev) hipFree(m->counts_dev);
     if (m->gathered) hipFree(m->gathered);
     if (m->comm) rccl().CommDestroy(m->comm);
+    if (prev >= 0) hipSetDevice(prev);
     delete m;
 }
 
 static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* counts_host,
                               uint64_t* total_out, bool dest_is_device)
 {
-    if (!c || !m || m->ctx != c || root < 0 || root >= m->nranks || (m->rank == root && capacity && !recs_host)) return M17HIP_EINVAL;
+    if (!c || !m || m->device != c->device || root < 0 || root >= m->nranks || (m->rank == root && capacity && !recs_host)) return M17HIP_EINVAL;
     GUARD(c);
     if (!c->have_run) return M17HIP_ESTATE;
     const Rccl& R = rccl();

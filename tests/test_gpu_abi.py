@@ -167,6 +167,27 @@ def test_channel_base_gives_global_channel_ids():
     assert (np.diff(key) > 0).all()                  # globally (channel, seq)-ordered, no duplicates
 
 
+def test_two_batches_in_flight_equal_one_after_the_other():
+    """bench.py's default: two contexts (independent batches) on their own streams, the second step queued before the first is
+    waited for, so that its front end runs beside the first one's tail.  Same records as the batches run one after the other."""
+    import torch
+    xs = [_signals(32, 96000, seed=61), _signals(32, 96000, seed=62, sigma=1200.0)]
+    exp = [_oracle_flat(x) for x in xs]
+    ctxs, streams = [], [torch.cuda.Stream(), torch.cuda.Stream()]
+    for x, st in zip(xs, streams):
+        c = m17hip.Context(32, 96000)
+        c.set_stream(st.cuda_stream)
+        c.upload(x)
+        ctxs.append(c)
+    for rep in range(3):
+        for c in ctxs:
+            c.reset(); c.run()          # both queued ...
+        for c, e in zip(ctxs, exp):
+            assert c.frames().tobytes() == e.tobytes(), rep   # ... then waited for
+    for c in ctxs:
+        c.close()
+
+
 def test_rccl_gather_single_rank():
     """m17hip_comm_* / m17hip_gather_frames with a 1-rank communicator: RCCL is bound, the counts all-gather and the
     compaction run, the root receives its own records."""
