@@ -221,6 +221,22 @@ def main():
             ms, n = ms + ms_, n + n_
         kern[name] = {"ms_avg": (ms / n) if n else None, "launches": n, "ms_per_step": ms / args.steps}
 
+    # ---- the same kernels with ONE step at a time (outside the timed region; N = 1): per-launch durations that are not stretched by
+    #      the other batch's kernels — the per-launch roofline of the timed region (two steps share the chip) next to this one
+    seq_kern = None
+    if F > 1 and world == 1:
+        ctx.timing(True); ctx.timing_reset()
+        ts = time.perf_counter()
+        for _ in range(2):
+            ctx.reset(); ctx.run(); ctx.frames_compact_device(rec_buf.data_ptr(), rec_cap_local)
+        torch.cuda.synchronize()
+        seq_ms = (time.perf_counter() - ts) / 2 * 1e3
+        seq_kern = {}
+        for name in ("fir_rrc150", "dcd", "limit_track", "demod_seq"):
+            ms_, n_ = ctx.timing_get(name)
+            seq_kern[name] = {"ms_avg": ms_ / n_ if n_ else None, "launches": n_, "ms_per_step": ms_ / 2}
+        ctx.timing(False)
+
     # ---- checks outside the timed region: parity spot check against the oracle; N > 1: the gathered set is one ordered set ----------
     parity = good = gathered_ok = None
     if rank == 0:
@@ -273,6 +289,13 @@ def main():
                 "kernel_design_GBs": round(DESIGN_BYTES[dom] * units / dom_s / 1e9, 2),
                 "chain_achieved_GBs": round(CHAIN_BYTES * C * T * args.steps / dt / 1e9 / world, 2),
                 "chain_frac": round(CHAIN_BYTES * C * T * args.steps / dt / 1e9 / world / HBM_PEAK_GBS, 6)}
+    if seq_kern:
+        sdom = max(seq_kern, key=lambda k: seq_kern[k]["ms_per_step"])
+        sl = seq_kern[sdom]["launches"] / 2
+        sa = CHAIN_BYTES * (C * T / sl) / (seq_kern[sdom]["ms_avg"] / 1e3) / 1e9
+        roofline["one_step_at_a_time"] = {"kernel": sdom, "achieved": round(sa, 2), "frac": round(sa / HBM_PEAK_GBS, 5), "ms_per_step": round(seq_ms, 3),
+                                          "kernel_ms_per_launch": {k: round(v["ms_avg"], 4) for k, v in seq_kern.items() if v["ms_avg"]},
+                                          "note": "2 extra steps outside the timed region with one batch in flight: launch durations not stretched by the other batch"}
 
     # ---- PCIe-inclusive rate (N = 1): every step gets fresh input from pinned host memory, upload of step k+1 overlapped --------
     h2d = None
