@@ -1,5 +1,6 @@
-// Convolutional-coder primitives of the reference (include/m17cxx/Convolution.h:11-23): one output bit = parity of the taps
-// selected by a polynomial; the shift register keeps K + 1 bits.
+// Convolutional-coder primitives of the reference (include/m17cxx/Convolution.h:11-23).  convolve_bit: one coded bit is the
+// parity of the register taps a generator polynomial selects.  update_memory<K, k>: shift k input bits into a register that
+// keeps K + 1 bits.  Both are the functions the Viterbi branch table (Viterbi.h, kernel K6) is built from.
 #pragma once
 
 #include <cstddef>
@@ -8,15 +9,23 @@
 namespace mobilinkd
 {
 
-inline constexpr uint32_t convolve_bit(uint32_t poly, uint32_t memory)
+namespace detail
 {
-    return uint32_t(__builtin_popcount(poly & memory) & 1);
+constexpr uint32_t parity32(uint32_t v)
+{
+    v ^= v >> 16; v ^= v >> 8; v ^= v >> 4;
+    return (0x6996u >> (v & 15u)) & 1u;
 }
+template <size_t BITS> constexpr uint32_t low_mask = BITS >= 32 ? ~0u : ((uint32_t(1) << BITS) - 1u);
+} // detail
+
+inline constexpr uint32_t convolve_bit(uint32_t poly, uint32_t memory) { return detail::parity32(poly & memory); }
 
 template <size_t K, size_t k = 1>
 inline constexpr uint32_t update_memory(uint32_t memory, uint32_t input)
 {
-    return ((memory << k) | input) & ((1u << (K + 1)) - 1u);
+    const uint32_t shifted = (memory << k) | input;
+    return shifted & detail::low_mask<K + 1>;
 }
 
 } // mobilinkd

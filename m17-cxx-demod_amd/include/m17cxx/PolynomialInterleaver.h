@@ -1,10 +1,11 @@
 // mobilinkd::PolynomialInterleaver — the M17 quadratic permutation polynomial interleaver (reference
-// include/m17cxx/PolynomialInterleaver.h:14-72): position i of the coded frame travels at (45 i + 92 i^2) mod 368.
+// include/m17cxx/PolynomialInterleaver.h:14-72): position i of the coded frame travels at (45 i + 92 i^2) mod 368.  The
+// permutation is tabulated once at compile time; the four entry points of the reference (soft bits and packed bytes, both
+// directions) are scatter / gather through that table.
 #pragma once
 
 #include "Util.h"
 
-#include <algorithm>
 #include <array>
 #include <cstddef>
 #include <cstdint>
@@ -18,35 +19,42 @@ struct PolynomialInterleaver
     using buffer_t = std::array<int8_t, K>;
     using bytes_t = std::array<uint8_t, K / 8>;
 
-    alignas(16) buffer_t buffer_;
+    static constexpr std::array<uint16_t, K> make_table()
+    {
+        std::array<uint16_t, K> t{};
+        for (size_t i = 0; i != K; ++i) t[i] = uint16_t((F1 * i + F2 * i * i) % K);
+        return t;
+    }
+    static constexpr std::array<uint16_t, K> table = make_table();
 
-    size_t index(size_t i) { return (F1 * i + F2 * i * i) % K; }
+    size_t index(size_t i) { return table[i]; }
 
     void interleave(buffer_t& data)
     {
-        buffer_.fill(0);
-        for (size_t i = 0; i != K; ++i) buffer_[index(i)] = data[i];
-        data = buffer_;
-    }
-
-    void interleave(bytes_t& data)
-    {
-        bytes_t shuffled{};
-        for (size_t i = 0; i != K; ++i) assign_bit_index(shuffled, index(i), get_bit_index(data, i));
-        data = shuffled;
+        buffer_t out{};
+        for (size_t i = 0; i != K; ++i) out[table[i]] = data[i];
+        data = out;
     }
 
     void deinterleave(buffer_t& frame)
     {
-        for (size_t i = 0; i != K; ++i) buffer_[i] = frame[index(i)];
-        frame = buffer_;
+        buffer_t out{};
+        for (size_t i = 0; i != K; ++i) out[i] = frame[table[i]];
+        frame = out;
+    }
+
+    void interleave(bytes_t& data)
+    {
+        bytes_t out{};
+        for (size_t i = 0; i != K; ++i) assign_bit_index(out, table[i], get_bit_index(data, i));
+        data = out;
     }
 
     void deinterleave(bytes_t& data)
     {
-        bytes_t restored{};
-        for (size_t i = 0; i != K; ++i) assign_bit_index(restored, i, get_bit_index(data, index(i)));
-        data = restored;
+        bytes_t out{};
+        for (size_t i = 0; i != K; ++i) assign_bit_index(out, i, get_bit_index(data, table[i]));
+        data = out;
     }
 };
 
