@@ -368,28 +368,45 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
         }
     }
     wave_lds_sync();
-    uint32_t I = (uint32_t)wl & 15u, w = 0, w_hi = 0;
+    // One step: the decision of position I sits at bit I (+ 16 for an odd step) of the step's word and becomes bit k of I.  The
+    // word is rotated beforehand (off the dependent chain) so that a rotation by I itself brings that bit to bit k; the chain
+    // is then two instructions per step, v_alignbit (rotate by I) and v_bfi (insert bit k).  After the four steps of a group
+    // I IS the four bits just decoded, first one in bit 0: the groups are collected as nibbles (w4) and the bit order inside
+    // the nibbles is put right once, at the end (nib_rev below).
+    uint32_t I = (uint32_t)wl & 15u, w4 = 0, w4_hi = 0;
     {
         // block b = wl >> 4 decodes message bits 64 b + 63 .. 64 b, i.e. steps hi = 64 b + 67 .. 64 b + 4: words 32 b + 33 .. 32 b + 2
         const M17_LDS uint32_t* hp = cw + 32 * (wl >> 4) + 2;
+        auto rotr = [](uint32_t x, uint32_t n) -> uint32_t { return __builtin_amdgcn_alignbit(x, x, n); };
+        auto take = [&](uint32_t prerot, uint32_t bit) {   // I <- I with `bit` replaced by that bit of (prerot rotated right by I)
+            const uint32_t r = rotr(prerot, I);
+            uint32_t out;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(out) : "v"(bit), "v"(r), "v"(I));   // (bit & r) | (~bit & I)
+            I = out;
+        };
 #pragma unroll
         for (int g = 0; g < 16; ++g) {   // four steps: hi = 3, 2, 1, 0 (mod 4) -> k = 0, 1, 2, 3
             const uint32_t wa = hp[31 - 2 * g], wb = hp[30 - 2 * g];
-            uint32_t v;
-            v = __builtin_amdgcn_ubfe(wa, I + 16u, 1u); w = (w << 1) | v; I = (I & ~1u) | v;
-            v = __builtin_amdgcn_ubfe(wa, I, 1u);       w = (w << 1) | v; I = (I & ~2u) | (v << 1);
-            v = __builtin_amdgcn_ubfe(wb, I + 16u, 1u); w = (w << 1) | v; I = (I & ~4u) | (v << 2);
-            v = __builtin_amdgcn_ubfe(wb, I, 1u);       w = (w << 1) | v; I = (I & ~8u) | (v << 3);
-            if (g == 7) { w_hi = w; w = 0; }
+            // bit k of rotr(rotr(word, c), I) = bit (k + c + I) of word: c = (16 or 0) - k
+            const uint32_t a0 = rotr(wa, 16u), a1 = rotr(wa, 31u), b2 = rotr(wb, 14u), b3 = rotr(wb, 29u);
+            take(a0, 1u);
+            take(a1, 2u);
+            take(b2, 4u);
+            take(b3, 8u);
+            w4 = (w4 << 4) | I;
+            if (g == 7) { w4_hi = w4; w4 = 0; }
         }
     }
+    auto nib_rev = [](uint32_t x) -> uint32_t {   // reverse the bit order inside every nibble
+        return ((x & 0x11111111u) << 3) | ((x & 0x22222222u) << 1) | ((x >> 1) & 0x22222222u) | ((x >> 3) & 0x11111111u);
+    };
     // chain the blocks from the top: the walk enters block 3 at the position of the best end state
     {
         uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane(rotr4(best, steps));
 #pragma unroll
         for (int b = 3; b >= 0; --b) {
             const int lane = 16 * b + (int)e;
-            const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)w_hi, lane), lo32 = (uint32_t)__builtin_amdgcn_readlane((int)w, lane);
+            const uint32_t hi32 = nib_rev((uint32_t)__builtin_amdgcn_readlane((int)w4_hi, lane)), lo32 = nib_rev((uint32_t)__builtin_amdgcn_readlane((int)w4, lane));
             e = (uint32_t)__builtin_amdgcn_readlane((int)I, lane);
             // message bit n -> byte n >> 3, bit 7 - (n & 7); four bytes per little-endian word; bits at and beyond OUT stay zero
             const int nh = OUT - (64 * b + 32), nl = OUT - 64 * b;

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     DL.soft = reinterpret_cast<int32_t*>(e2 + 96);           // [488] depunctured soft bits of the frame being decoded
     Hot* hot_lds = reinterpret_cast<Hot*>(DL.soft + 488);    // [64]  the channel's hot scalars (see below)
     static_assert(sizeof(Hot) <= 64 * 4, "Hot must fit its LDS slot");
+    static_assert(WV_WIN == 2 * WV_PF, "a prefetch granule is half the window");
     DL.src = srcmap;
     DL.lich_src = lichmap;
     DL.stride = 1;
@@ -147,17 +148,20 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     const uint64_t tick0 = P.tick_row0;
     FrameRec* rec_base = P.recs + (size_t)c * P.rec_cap;
     uint32_t t = 0;  // next sample (relative to this run)
+    // Loads go through a buffer resource over this channel's row [0, T): the bounds check is the hardware's (a dword at or beyond
+    // T reads 0.0) and the eight rows of a granule are one address computation plus instruction offsets.  `avail` is always a
+    // multiple of WV_PF, so a granule never wraps inside the (2 * WV_PF)-sample window: its LDS stores are one address too.
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)yr, 0, (int)(P.T * 4u), 0x00020000);
     auto pf_issue = [&]() {   // start loading [avail, avail + WV_PF): 8 coalesced 256-byte rows
+        const uint32_t voff = (avail + (uint32_t)wl) * 4u;
 #pragma unroll
-        for (int k = 0; k < WV_PF / 64; ++k) {
-            const uint32_t i = avail + 64u * k + wl;
-            pf[k] = i < P.T ? yr[i] : 0.f;
-        }
+        for (int k = 0; k < WV_PF / 64; ++k) pf[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrsrc, (int)(voff + 256u * k), 0, 0));
         pf_pending = true;
     };
     auto pf_commit = [&]() {  // the loads issued a whole granule ago have landed: move them into the window
+        float* dst = ywin + (avail & (WV_WIN - 1)) + wl;
 #pragma unroll
-        for (int k = 0; k < WV_PF / 64; ++k) ywin[(avail + 64u * k + wl) & (WV_WIN - 1)] = pf[k];
+        for (int k = 0; k < WV_PF / 64; ++k) dst[64 * k] = pf[k];
         avail += WV_PF;
         pf_pending = false;
         wave_lds_sync();
@@ -169,7 +173,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             if (avail < P.T) pf_issue();
         }
     };
-    auto window_reset = [&](uint32_t t0) { avail = t0; pf_pending = false; };  // after ybuf was patched / the window was used as scratch
+    // after ybuf was patched / the window was used as scratch: refill from the granule that holds t0
+    auto window_reset = [&](uint32_t t0) { avail = t0 & ~(uint32_t)(WV_PF - 1); pf_pending = false; };
     pf_issue();
 
     // ---------------- wave-uniform helpers ------------------------------------------------------------------------
@@ -496,8 +501,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             // (lane l checks anti-phase samples l and l + 64; the chunk is cut before the first one that would move it)
             for (uint32_t base = a1; base < n; base += 640u) {
                 const uint32_t a = base + 10u * wl;
-                bool bad = false;
-                if (a < n) bad = (uint32_t)(uint8_t)clock_predict(s.ck_sample_est, s.ck_clock_est, s.ck_count + a + 1u) != S;
+                const float v = core::clock_predict_arg(s.ck_sample_est, s.ck_clock_est, s.ck_count + a + 1u);
+                bool bad = a < n && !core::clock_predict_equals(v, (int32_t)S);
+                if (__ballot(a < n && !core::clock_predict_near(v)))   // (an estimate far outside 0..10: the general form)
+                    bad = a < n && (uint32_t)(uint8_t)clock_predict(s.ck_sample_est, s.ck_clock_est, s.ck_count + a + 1u) != S;
                 const unsigned long long mask = __ballot(bad);
                 if (mask != 0ull) {
                     n = base + 10u * (uint32_t)(__ffsll((long long)mask) - 1);

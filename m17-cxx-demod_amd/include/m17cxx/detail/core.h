@@ -268,6 +268,18 @@ M17_HD int32_t clock_predict(float sample_est, float clock_est, uint32_t count)
     else if (csw >= 10) csw -= 10;
     return wrap10((int32_t)__builtin_round(csw));
 }
+// The same question as a predicate, for the callers that only need "does the update leave sample_index at S?" (K5 checks every
+// anti-phase sample of a chunk at once): with v = sample_estimate_ + clock_estimate_ * count_ as the float the reference forms
+// (:78), and v in [-10, 19.5), fmod / the +-10 wrap / round-half-away reduce to exact interval tests on v itself:
+// clock_predict == S  <=>  v, v + 10 or v - 10 lies in [S - 0.5, S + 0.5)   (S = 0 picks up [9.5, 10) through the third one).
+// Outside that range (or NaN) clock_predict_near() is false and the caller has to evaluate clock_predict().
+M17_HD float clock_predict_arg(float sample_est, float clock_est, uint32_t count) { return sample_est + clock_est * (float)count; }
+M17_HD bool clock_predict_near(float v) { return v >= -10.f && v < 19.5f; }
+M17_HD bool clock_predict_equals(float v, int32_t S)
+{
+    const float lo = (float)S - 0.5f, hi = (float)S + 0.5f;   // exact: S is 0..9
+    return (v >= lo && v < hi) || (v >= lo - 10.f && v < hi - 10.f) || (v >= lo + 10.f && v < hi + 10.f);
+}
 // ClockRecovery::update(uint8_t) (:54-67): the sample index of a fresh filter estimate
 M17_HD int32_t clock_index_of(float sample_est) { return wrap10((int32_t)__builtin_round((double)sample_est)); }
 

@@ -296,6 +296,43 @@ int main(int argc, char** argv)
         save(argv[5], out);
         return 0;
     }
+    if (mode == "clockeq") {   // clockeq : the predicate form of ClockRecovery::update() against the function (detail/core.h), exhaustive near
+                               // every interval edge and random elsewhere; prints the number of arguments checked
+        uint64_t checked = 0;
+        auto check = [&](float v) {
+            if (!core::clock_predict_near(v)) return;
+            const int32_t want = core::clock_predict(v, 0.f, 0u);   // sample_est = v, clock_est * count = +0: the same float v
+            for (int32_t S = 0; S < 10; ++S)
+                if (core::clock_predict_equals(v, S) != (want == S)) { std::printf("MISMATCH v=%.9g S=%d want=%d\n", v, S, want); std::exit(1); }
+            ++checked;
+        };
+        for (int k = -21; k <= 41; ++k) {   // edges at k / 2: 2000 floats on either side of each
+            float lo = 0.5f * (float)k, hi = lo;
+            check(lo);
+            for (int i = 0; i < 2000; ++i) { lo = std::nextafterf(lo, -100.f); hi = std::nextafterf(hi, 100.f); check(lo); check(hi); }
+        }
+        uint32_t rng = 12345u;
+        for (int i = 0; i < 4000000; ++i) {
+            rng = rng * 1664525u + 1013904223u;
+            check(-10.f + 30.f * (float)(rng >> 8) * (1.f / 16777216.f));
+        }
+        const float specials[] = {-0.f, 0.f, -10.f, 19.999998f, std::nanf(""), 20.f, -10.000001f, 1e30f, -1e30f};
+        for (float v : specials) check(v);
+        // and through the two-argument form the kernel uses
+        for (int i = 0; i < 2000000; ++i) {
+            rng = rng * 1664525u + 1013904223u; const float est = 10.f * (float)(rng >> 8) * (1.f / 16777216.f);
+            rng = rng * 1664525u + 1013904223u; const float clk = ((float)(rng >> 8) * (1.f / 16777216.f) - 0.5f) * 0.02f;
+            rng = rng * 1664525u + 1013904223u; const uint32_t cnt = rng % 4000u;
+            const float v = core::clock_predict_arg(est, clk, cnt);
+            if (!core::clock_predict_near(v)) continue;
+            const int32_t want = core::clock_predict(est, clk, cnt);
+            for (int32_t S = 0; S < 10; ++S)
+                if (core::clock_predict_equals(v, S) != (want == S)) { std::printf("MISMATCH est=%.9g clk=%.9g cnt=%u S=%d want=%d\n", est, clk, cnt, S, want); std::exit(1); }
+            ++checked;
+        }
+        std::printf("clockeq ok %llu\n", (unsigned long long)checked);
+        return 0;
+    }
     if (mode == "freqdev") {   // freqdev mn.f32 mx.f32 reset.u8 out.f32 : FreqDevEstimator<float>; per step (idev, offset)
         auto mn = load<float>(argv[2]); auto mx = load<float>(argv[3]); auto rs = load<uint8_t>(argv[4]);
         FreqDevEstimator<float> d;

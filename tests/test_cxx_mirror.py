@@ -36,6 +36,13 @@ def test_reference_unit_test_values(exe):
     assert run(exe, "kat").strip() == "kat ok"
 
 
+def test_clock_update_predicate_equals_the_function(exe):
+    """detail/core.h: clock_predict_equals (what K5's chunk check evaluates) == (clock_predict == S), edges and random arguments"""
+    out = run(exe, "clockeq").strip()
+    assert out.startswith("clockeq ok"), out
+    assert int(out.split()[-1]) > 5_000_000
+
+
 def test_scaling_and_fir_equal_reference(exe, golden, tmp_path):
     for tag, inv in (("", 0), ("inv_", 1), ("dc_", 0), ("zero_", 0)):
         s = golden[tag + "sig_i16"]
