@@ -270,7 +270,9 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * key 9: diagnostic log, value = diagnostic callbacks of room per channel and run (m17hip_diag_log_fetch; default 0 = off).
  * key 10: form of the carrier-detect kernel K3: 0 = one wave per 32 channels (default), 1 = four-wave pipeline (1.8x faster alone,
  * four times the wave slots).  key 11: stream priorities of the front end (bit 0: K1 lowest, bit 1: K3 lowest, bit 2: K3 highest).
- * key 12: segments of K1 that must be complete before the first K5 starts (0 = its own only). */
+ * key 12: segments of K1 that must be complete before the first K5 starts (0 = its own only).
+ * key 13: form of the matched filter K1: 1 = rolled tap loop, 95 VGPRs (default: a workgroup of it fits beside the sequential kernel's
+ * waves on a SIMD, which is worth 9 % of the step with two batches in flight), 0 = straight-line tap loop (167 VGPRs), 2 = rolled, 64 VGPRs. */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 
 /* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][24] =

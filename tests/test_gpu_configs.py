@@ -92,3 +92,29 @@ def test_config5_impairment_sweep_ber_and_evm_equal_the_cpu_path(dc, gain):
         ber = st["errors"][st["bits"] > 0] / st["bits"][st["bits"] > 0]
         assert ber.mean() < 1e-2, (sigma, float(ber.mean()))   # the BER floor of the first frames after the loud lead-in (reference behaviour), not noise
     ctx.close()
+
+
+@pytest.mark.parametrize("Cn,T", [(5, 3840 * 3 + 17), (2, 100), (64, 48000)])
+def test_fir_rolled_form_equals_straight_line_form(Cn, T):
+    """K1 has two forms (m17hip_tune key 13): the straight-line tap loop (167 VGPRs) and the rolled one (three register banks);
+    same arithmetic in the same order, so their outputs are equal bit for bit — against each other and against the oracle,
+    incl. a ragged last tile, a run shorter than the filter and extreme inputs."""
+    rng = np.random.default_rng(77 + Cn)
+    x = rng.integers(-32768, 32768, size=(Cn, T), dtype=np.int64).astype(np.int16)
+    x[0, : min(T, 300)] = 32767
+    x[-1, : min(T, 300)] = -32768
+    ctx = m17hip.Context(Cn, T)
+    ctx.upload(x)
+    y0 = ctx.fir()
+    ctx.tune(13, 1)
+    y1 = ctx.fir()
+    y1i = ctx.fir(flags=m17hip.FLAG_INVERT)
+    ctx.tune(13, 0)
+    y0i = ctx.fir(flags=m17hip.FLAG_INVERT)
+    assert np.array_equal(y0.view(np.uint32), y1.view(np.uint32))
+    assert np.array_equal(y0i.view(np.uint32), y1i.view(np.uint32))
+    for c in (0, Cn - 1):
+        assert np.array_equal(y1[c], ol.fir_i16(x[c]))
+    with pytest.raises(m17hip.M17HipError):
+        ctx.tune(13, 3)
+    ctx.close()
