@@ -272,7 +272,8 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * four times the wave slots).  key 11: stream priorities of the front end (bit 0: K1 lowest, bit 1: K3 lowest, bit 2: K3 highest).
  * key 12: segments of K1 that must be complete before the first K5 starts (0 = its own only).
  * key 13: form of the matched filter K1: 1 = rolled tap loop, 95 VGPRs (default: a workgroup of it fits beside the sequential kernel's
- * waves on a SIMD, which is worth 9 % of the step with two batches in flight), 0 = straight-line tap loop (167 VGPRs), 2 = rolled, 64 VGPRs. */
+ * waves on a SIMD, which is worth 9 % of the step with two batches in flight), 0 = straight-line tap loop (167 VGPRs), 2 = rolled with
+ * 11 outputs per lane (62 VGPRs; measured slower than 1). */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 
 /* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][24] =

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(FIR_THREADS, 3) void fir_rrc150_kernel(const int16_
 
 // The same filter with the tap loop ROLLED.  Arithmetic and order are those of fir_rrc150_kernel; what changes is the register
 // footprint: the straight-line form keeps the whole 163-sample window of a lane in registers (167 VGPRs, three waves per
-// SIMD), this one keeps three banks of FIR_R samples and needs ~80, so that a workgroup of it fits into whatever the
+// SIMD), this one keeps three banks of R samples (R outputs per lane) and needs ~95 (R = 15) or ~64 (R = 11), so that a workgroup of it fits into whatever the
 // sequential kernel (128 VGPRs per wave) leaves free on a SIMD.
 // A block of FIR_R taps reads a 2 * FIR_R - 1 sample window with static offsets: output r at tap u of block b uses
 // W_b[FIR_R - 1 + r - u], W_b[k] = win[148 - FIR_R b - (FIR_R - 1) + k].  W_b = (X_b | X_{b-1}): a new bank X_b of FIR_R
@@ -96,20 +96,21 @@ __global__ __launch_bounds__(FIR_THREADS, 3) void fir_rrc150_kernel(const int16_
 // registers, so the two banks of a block have to be neighbours: banks P0 P1 P2, even blocks use (P1, P2), odd blocks (P0, P1),
 // and after an odd block P0 is copied to P2 (FIR_R - 1 moves per 2 * FIR_R * 2 * FIR_R useful instructions).  Taps come from the
 // tap table with scalar loads.
-template <int MINW>
+template <int R, int MINW>
 __global__ __launch_bounds__(FIR_THREADS, MINW) void fir_rrc150_rolled_kernel(const int16_t* __restrict__ x, size_t xpitch,
                                                                              float* __restrict__ y, size_t ypitch, uint32_t T,
                                                                              uint32_t flags, const float* __restrict__ taps)
 {
-    __shared__ __attribute__((aligned(16))) float win[FIR_WIN + 4];
+    constexpr int TILE = R * FIR_THREADS, WIN = TILE + NTAPS - 1;   // outputs per workgroup, staged samples
+    __shared__ __attribute__((aligned(16))) float win[WIN + 4];
     const int tid = threadIdx.x;
     const uint32_t c = blockIdx.y;
-    const uint32_t t0 = blockIdx.x * FIR_TILE;
+    const uint32_t t0 = blockIdx.x * TILE;
     const bool invert = flags & 1u;
     const int16_t* xr = x + (size_t)c * xpitch + XPRE;
     float* yr = y + (size_t)c * ypitch + YPRE;
     const int64_t w0 = (int64_t)t0 - (NTAPS - 1);
-    for (int k = tid; k < (FIR_WIN + 3) / 4; k += FIR_THREADS) {
+    for (int k = tid; k < (WIN + 3) / 4; k += FIR_THREADS) {
         const int64_t t = w0 + 4 * k;
         short4 v = make_short4(0, 0, 0, 0);
         if (t < (int64_t)T) v = *reinterpret_cast<const short4*>(xr + t);
@@ -121,7 +122,6 @@ __global__ __launch_bounds__(FIR_THREADS, MINW) void fir_rrc150_rolled_kernel(co
         *reinterpret_cast<float4*>(&win[4 * k]) = f;
     }
     __syncthreads();
-    constexpr int R = FIR_R;
     const float* base = win + tid * R;           // win[j] <-> sample t0 - 148 + j; output o = tid*R + r at tap i reads base[148 + r - i]
     float S[3 * R], acc[R];
 #pragma unroll
@@ -151,7 +151,10 @@ __global__ __launch_bounds__(FIR_THREADS, MINW) void fir_rrc150_rolled_kernel(co
 #pragma unroll
     for (int k = 0; k < R - 1; ++k) S[2 * R + k] = base[NTAPS + k];   // X_{-1}[0 .. R-2] -> P2 (the samples behind output 0's newest)
     S[3 * R - 1] = 0.0f;
-    constexpr int PAIRS = (NTAPS / R) / 2;       // 4 whole pairs of blocks (taps 0..119); blocks 8 (15 taps) and 9 (14 taps) follow
+    // whole pairs of blocks in the loop; an even block of R taps and an odd block of 1..R taps follow (R = 15: 4 pairs = taps
+    // 0..119, then blocks 8 (15 taps) and 9 (14 taps))
+    constexpr int PAIRS = (NTAPS - R - 1) / (2 * R);
+    static_assert(NTAPS - R * (2 * PAIRS + 1) >= 1 && NTAPS - R * (2 * PAIRS + 1) <= R, "tail = one whole block + one partial block");
 #pragma unroll 1
     for (int q = 0; q < PAIRS; ++q) {
         load_bank(S, 2 * q + 1);                  // X_{2q+1} -> P0 (in flight during the even block)
@@ -161,15 +164,15 @@ __global__ __launch_bounds__(FIR_THREADS, MINW) void fir_rrc150_rolled_kernel(co
         for (int k = 0; k < R - 1; ++k) S[2 * R + k] = S[k];   // P0 -> P2
         load_bank(S + R, 2 * q + 2);              // X_{2q+2} -> P1
     }
-    load_bank(S, 2 * PAIRS + 1, 1);           // (X_9[0] would be the sample before the window and is not used: 14 taps remain)
-    S[0] = 0.0f;
+    // the last bank: only the samples its remaining taps read (X[k], k >= R - n; a full bank would start before the window)
+    load_bank(S, 2 * PAIRS + 1, R - (NTAPS - R * (2 * PAIRS + 1)));
     block(S + R, 2 * PAIRS, R);
     block(S, 2 * PAIRS + 1, NTAPS - R * (2 * PAIRS + 1));
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) win[tid * R + r] = acc[r];
     __syncthreads();
-    for (int k = tid; k < FIR_TILE / 4; k += FIR_THREADS) {
+    for (int k = tid; k < TILE / 4; k += FIR_THREADS) {
         const uint32_t t = t0 + 4 * k;
         if (t + 3 < T) {
             *reinterpret_cast<float4*>(yr + t) = *reinterpret_cast<const float4*>(&win[4 * k]);

@@ -83,7 +83,7 @@ struct m17hip_ctx {
     uint64_t compact_cap = 0;
     DecodeTables* tables = nullptr;
     float* taps = nullptr;
-    int fir_form = 1;           // tune 13: 1 = rolled tap loop, 95 VGPRs (default: shares a SIMD with the sequential kernel), 0 = straight-line K1 (167 VGPRs), 2 = rolled, 64 VGPRs
+    int fir_form = 1;           // tune 13: 1 = rolled tap loop, 95 VGPRs (default: shares a SIMD with the sequential kernel), 0 = straight-line K1 (167 VGPRs), 2 = rolled, 11 outputs per lane, 62 VGPRs
     float* llr_edges = nullptr;
     void* scratch = nullptr;          // per-operator staging (correlator outputs, viterbi io)
     size_t scratch_bytes = 0;
@@ -508,9 +508,9 @@ int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_
     Timed tm(c, KT_FIR, st);
     dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C);
     if (c->fir_form == 1)
-        hipLaunchKernelGGL(fir_rrc150_rolled_kernel<4>, grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
+        hipLaunchKernelGGL((fir_rrc150_rolled_kernel<FIR_R, 4>), grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
     else if (c->fir_form == 2)
-        hipLaunchKernelGGL(fir_rrc150_rolled_kernel<8>, grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
+        hipLaunchKernelGGL((fir_rrc150_rolled_kernel<11, 8>), dim3((T + 11 * FIR_THREADS - 1) / (11 * FIR_THREADS), C), dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
     else
         hipLaunchKernelGGL(fir_rrc150_kernel, grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags);
     HIPCHK(c, hipGetLastError());
@@ -1440,7 +1440,7 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         HIPCHK(c, hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, (value & 1) ? least : 0));
         return M17HIP_OK;
     }
-    case 13:  // K1 form: 1 = rolled tap loop (default), 0 = straight-line (167 VGPRs), 2 = rolled with registers for 8 waves per SIMD
+    case 13:  // K1 form: 1 = rolled tap loop (default), 0 = straight-line (167 VGPRs), 2 = rolled with 11 outputs per lane (62 VGPRs)
         if (value < 0 || value > 2) return M17HIP_EINVAL;
         c->fir_form = (int)value;
         return M17HIP_OK;

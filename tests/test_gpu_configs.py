@@ -96,7 +96,8 @@ def test_config5_impairment_sweep_ber_and_evm_equal_the_cpu_path(dc, gain):
 
 @pytest.mark.parametrize("Cn,T", [(5, 3840 * 3 + 17), (2, 100), (64, 48000)])
 def test_fir_rolled_form_equals_straight_line_form(Cn, T):
-    """K1 has two forms (m17hip_tune key 13): the straight-line tap loop (167 VGPRs) and the rolled one (three register banks);
+    """K1 has three forms (m17hip_tune key 13): the straight-line tap loop (167 VGPRs) and the rolled one (three register banks)
+    with 15 or 11 outputs per lane;
     same arithmetic in the same order, so their outputs are equal bit for bit — against each other and against the oracle,
     incl. a ragged last tile, a run shorter than the filter and extreme inputs."""
     rng = np.random.default_rng(77 + Cn)
@@ -106,13 +107,15 @@ def test_fir_rolled_form_equals_straight_line_form(Cn, T):
     ctx = m17hip.Context(Cn, T)
     ctx.upload(x)
     y0 = ctx.fir()
-    ctx.tune(13, 1)
-    y1 = ctx.fir()
-    y1i = ctx.fir(flags=m17hip.FLAG_INVERT)
     ctx.tune(13, 0)
+    y0 = ctx.fir()
     y0i = ctx.fir(flags=m17hip.FLAG_INVERT)
-    assert np.array_equal(y0.view(np.uint32), y1.view(np.uint32))
-    assert np.array_equal(y0i.view(np.uint32), y1i.view(np.uint32))
+    for form in (1, 2):
+        ctx.tune(13, form)
+        y1 = ctx.fir()
+        y1i = ctx.fir(flags=m17hip.FLAG_INVERT)
+        assert np.array_equal(y0.view(np.uint32), y1.view(np.uint32)), form
+        assert np.array_equal(y0i.view(np.uint32), y1i.view(np.uint32)), form
     for c in (0, Cn - 1):
         assert np.array_equal(y1[c], ol.fir_i16(x[c]))
     with pytest.raises(m17hip.M17HipError):

@@ -6,6 +6,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import m17hip, oracle_lib as ol
+if os.environ.get('M17HIP_LIB'): m17hip.LIB_PATH = os.environ['M17HIP_LIB']   # experiment builds
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 480000
 trials = int(sys.argv[3]) if len(sys.argv) > 3 else 10
@@ -31,7 +32,7 @@ def steps(n):   # bench.py's overlapped loop: step k + 1 is queued before step k
     return (time.perf_counter() - t0) / n * 1e3
 
 steps(2)
-print("initial placement:        %.2f ms/step" % steps(6), flush=True)
+print("initial placement:        %.2f ms/step" % steps(10), flush=True)
 for i in range(trials):
     if i % 2 == 0:
         ctxs[1].tune(11, 0)            # new side / side2 streams (K3, K1) for context B
