@@ -11,7 +11,7 @@ def val(path, kern, ctr):
         if l.startswith('- ') and kern in l:
             return float(re.search(ctr + r'=([0-9.e+]+)', l).group(1))
     return None
-K = {'fir_rrc150': 'fir_rrc150_kernel', 'dcd': 'dcd_kernel', 'limit_track': 'limit_track_kernel', 'demod_seq': 'demod_wave_kernel'}
+K = {'fir_rrc150': 'fir_rrc150_', 'dcd': 'dcd_kernel', 'limit_track': 'limit_track_kernel', 'demod_seq': 'demod_wave_kernel'}
 j = {'channels': C, 'samples': T, 'launches_per_step': lps,
      'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh); per-dispatch averages in KB; '
                'FETCH_SIZE doubled per MI355X_MICROARCH.md; limit_track averages include the near-empty redo launches', 'kernels': {}}
