@@ -160,17 +160,17 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
         return o;
     };
-    auto iir_tick = [&]() {   // straight-line: 12 blocks of 16 samples, the next block's reads in flight
+    auto iir_tick = [&]() {   // straight-line: 24 blocks of 8 samples, the next block's reads in flight
         float m2 = IirCoef::a2 * h1;
         const float4* yv = reinterpret_cast<const float4*>(&yl[g][0]);
         float4* hv = reinterpret_cast<float4*>(&hl[g][0]);
-        float4 a0 = yv[0], a1 = yv[1], a2 = yv[2], a3 = yv[3];
+        float4 a0 = yv[0], a1 = yv[1];
 #pragma unroll
-        for (int b = 0; b < TICK / 16; ++b) {
-            float4 n0 = a0, n1 = a1, n2 = a2, n3 = a3;
-            if (b + 1 < TICK / 16) { n0 = yv[4 * b + 4]; n1 = yv[4 * b + 5]; n2 = yv[4 * b + 6]; n3 = yv[4 * b + 7]; }
-            hv[4 * b] = four(a0, m2); hv[4 * b + 1] = four(a1, m2); hv[4 * b + 2] = four(a2, m2); hv[4 * b + 3] = four(a3, m2);
-            a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+        for (int b = 0; b < TICK / 8; ++b) {
+            float4 n0 = a0, n1 = a1;
+            if (b + 1 < TICK / 8) { n0 = yv[2 * b + 2]; n1 = yv[2 * b + 3]; }
+            hv[2 * b] = four(a0, m2); hv[2 * b + 1] = four(a1, m2);
+            a0 = n0; a1 = n1;
         }
     };
     auto store_tick = [&]() {
@@ -249,7 +249,8 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
             if (fast) {
                 stage_tick();
             } else {
-                for (uint32_t i = r; i < n; i += GT_LPC) {
+#pragma clang loop unroll(disable) vectorize(disable)
+                for (uint32_t i = r; i < n; i += GT_LPC) {   // (a rare path: kept rolled so that it does not set the kernel's register count)
                     float v = 0.f;
                     if (feed) {
                         const int32_t j = (int32_t)(t + i) - pl_rs;   // position inside the run, meaningful while pl_valid
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
                 if (fast) {
                     store_tick();
                 } else {
+#pragma clang loop unroll(disable) vectorize(disable)
                     for (uint32_t i = r; i < n; i += GT_LPC) hr[t + i] = hl[g][i];
                 }
             }
