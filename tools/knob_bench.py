@@ -3,6 +3,7 @@ import sys, os, time, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import m17hip, oracle_lib as ol
+if os.environ.get('M17HIP_LIB'): m17hip.LIB_PATH = os.environ['M17HIP_LIB']   # experiment builds
 C, T = int(sys.argv[1]), int(sys.argv[2])
 p = ol.gen_params(seed=20260101, kind=-1, n_frames=T // 1920 - 6, lead_in=3072, noise_sigma=600., tail_sigma=600., lead_sigma=40000.0, total=T)
 ctx = m17hip.Context(C, T)

@@ -17,6 +17,8 @@ for f in range(2):
     streams.append(torch.cuda.Stream())
     c.set_stream(streams[-1].cuda_stream)
     c.synth(p, C, T)
+    for kv in os.environ.get('M17_TUNE', '').split(','):
+        if kv: c.tune(int(kv.split('=')[0]), int(kv.split('=')[1]))
     ctxs.append(c)
 
 def steps(n):   # bench.py's overlapped loop: step k + 1 is queued before step k is waited for
