@@ -88,13 +88,13 @@ __global__ __launch_bounds__(FIR_THREADS, 3) void fir_rrc150_kernel(const int16_
 
 // The same filter with the tap loop ROLLED.  Arithmetic and order are those of fir_rrc150_kernel; what changes is the register
 // footprint: the straight-line form keeps the whole 163-sample window of a lane in registers (167 VGPRs, three waves per
-// SIMD), this one keeps three banks of R samples (R outputs per lane) and needs ~95 (R = 15) or ~64 (R = 11), so that a workgroup of it fits into whatever the
-// sequential kernel (128 VGPRs per wave) leaves free on a SIMD.
-// A block of FIR_R taps reads a 2 * FIR_R - 1 sample window with static offsets: output r at tap u of block b uses
-// W_b[FIR_R - 1 + r - u], W_b[k] = win[148 - FIR_R b - (FIR_R - 1) + k].  W_b = (X_b | X_{b-1}): a new bank X_b of FIR_R
+// SIMD), this one keeps three banks of R samples (R outputs per lane) and needs 95 (R = 15) or 62 (R = 11), so that a
+// workgroup of it fits into whatever the sequential kernel (128 VGPRs per wave) leaves free on a SIMD.
+// A block of R taps reads a 2 R - 1 sample window with static offsets: output r at tap u of block b uses
+// W_b[R - 1 + r - u], W_b[k] = win[148 - R b - (R - 1) + k].  W_b = (X_b | X_{b-1}): a new bank X_b of R
 // samples per block in front of the previous one — the packed multiplies / adds take their operand pairs from ADJACENT
 // registers, so the two banks of a block have to be neighbours: banks P0 P1 P2, even blocks use (P1, P2), odd blocks (P0, P1),
-// and after an odd block P0 is copied to P2 (FIR_R - 1 moves per 2 * FIR_R * 2 * FIR_R useful instructions).  Taps come from the
+// and after an odd block P0 is copied to P2 (R - 1 moves per two blocks = 4 R (R + 1) / 2 useful instructions).  Taps come from the
 // tap table with scalar loads.
 template <int R, int MINW>
 __global__ __launch_bounds__(FIR_THREADS, MINW) void fir_rrc150_rolled_kernel(const int16_t* __restrict__ x, size_t xpitch,
@@ -102,7 +102,9 @@ __global__ __launch_bounds__(FIR_THREADS, MINW) void fir_rrc150_rolled_kernel(co
                                                                              uint32_t flags, const float* __restrict__ taps)
 {
     constexpr int TILE = R * FIR_THREADS, WIN = TILE + NTAPS - 1;   // outputs per workgroup, staged samples
-    __shared__ __attribute__((aligned(16))) float win[WIN + 4];
+    constexpr int PAD = (R + 3) & ~3;                               // the last bank of lane 0 starts up to R - 1 words before the window
+    __shared__ __attribute__((aligned(16))) float win_[PAD + WIN + 4];
+    float* win = win_ + PAD;
     const int tid = threadIdx.x;
     const uint32_t c = blockIdx.y;
     const uint32_t t0 = blockIdx.x * TILE;
@@ -127,10 +129,9 @@ __global__ __launch_bounds__(FIR_THREADS, MINW) void fir_rrc150_rolled_kernel(co
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0f;
     // X_b[k] = base[148 - R b - (R - 1) + k]
-    auto load_bank = [&](float* bank, int b, int k0 = 0) {
+    auto load_bank = [&](float* bank, int b) {
 #pragma unroll
-        for (int k = 0; k < R; ++k)
-            if (k >= k0) bank[k] = base[(NTAPS - 1) - R * b - (R - 1) + k];
+        for (int k = 0; k < R; ++k) bank[k] = base[(NTAPS - 1) - R * b - (R - 1) + k];
     };
     // taps R b .. R b + n - 1 on the window that starts at W[0]
     auto block = [&](const float* W, int b, int n) {
@@ -151,10 +152,9 @@ __global__ __launch_bounds__(FIR_THREADS, MINW) void fir_rrc150_rolled_kernel(co
 #pragma unroll
     for (int k = 0; k < R - 1; ++k) S[2 * R + k] = base[NTAPS + k];   // X_{-1}[0 .. R-2] -> P2 (the samples behind output 0's newest)
     S[3 * R - 1] = 0.0f;
-    // whole pairs of blocks in the loop; an even block of R taps and an odd block of 1..R taps follow (R = 15: 4 pairs = taps
-    // 0..119, then blocks 8 (15 taps) and 9 (14 taps))
-    constexpr int PAIRS = (NTAPS - R - 1) / (2 * R);
-    static_assert(NTAPS - R * (2 * PAIRS + 1) >= 1 && NTAPS - R * (2 * PAIRS + 1) <= R, "tail = one whole block + one partial block");
+    // NB blocks in all, the last one partial: whole pairs of blocks in the loop, then one (even) or two (even, odd) more
+    // (R = 15: 4 pairs = taps 0..119, then blocks 8 (15 taps) and 9 (14 taps); R = 14: 5 pairs, then block 10 (9 taps))
+    constexpr int NB = (NTAPS + R - 1) / R, PAIRS = (NB - 1) / 2, LAST = NTAPS - R * (NB - 1);
 #pragma unroll 1
     for (int q = 0; q < PAIRS; ++q) {
         load_bank(S, 2 * q + 1);                  // X_{2q+1} -> P0 (in flight during the even block)
@@ -162,12 +162,15 @@ __global__ __launch_bounds__(FIR_THREADS, MINW) void fir_rrc150_rolled_kernel(co
         block(S, 2 * q + 1, R);                   // odd block on (P0, P1)
 #pragma unroll
         for (int k = 0; k < R - 1; ++k) S[2 * R + k] = S[k];   // P0 -> P2
-        load_bank(S + R, 2 * q + 2);              // X_{2q+2} -> P1
+        load_bank(S + R, 2 * q + 2);              // X_{2q+2} -> P1 (the last bank may begin before the window: front padding)
     }
-    // the last bank: only the samples its remaining taps read (X[k], k >= R - n; a full bank would start before the window)
-    load_bank(S, 2 * PAIRS + 1, R - (NTAPS - R * (2 * PAIRS + 1)));
-    block(S + R, 2 * PAIRS, R);
-    block(S, 2 * PAIRS + 1, NTAPS - R * (2 * PAIRS + 1));
+    if constexpr (NB - 2 * PAIRS == 2) {
+        load_bank(S, 2 * PAIRS + 1);
+        block(S + R, 2 * PAIRS, R);
+        block(S, 2 * PAIRS + 1, LAST);
+    } else {
+        block(S + R, 2 * PAIRS, LAST);
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) win[tid * R + r] = acc[r];
