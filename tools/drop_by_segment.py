@@ -1,5 +1,6 @@
-"""Channels of the bench workload that drop the limit-filter speculation, per 48000-sample segment: the run is cut after segment k
-(profiling build: its counters are those of the last K5 launch).  drop_by_segment.py [C]"""
+"""When do channels of the bench workload drop the limit-filter speculation?  The profiling build processes a run as ONE segment
+and counts the first drop of every channel, so a run cut after 48000 k samples gives the channels that dropped somewhere in the
+first k segments (cumulative); the differences between consecutive lines are the drops per segment.  drop_by_segment.py [C]"""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -16,4 +17,4 @@ for k in range(1, 11):
     d = ctx.debug_counters(C)
     n = d[:, 17]
     wg = (n.reshape(-1, 16) > 0).any(axis=1)
-    print('segment %d: channels that dropped %4d (%.1f %%), K2 workgroups (16 channels) with one %3d of %d' % (k - 1, int((n > 0).sum()), 100.0 * (n > 0).mean(), int(wg.sum()), len(wg)), flush=True)
+    print('by the end of segment %d: channels that dropped %4d (%.1f %%), K2 workgroups (16 channels) with one %3d of %d' % (k - 1, int((n > 0).sum()), 100.0 * (n > 0).mean(), int(wg.sum()), len(wg)), flush=True)
