@@ -67,7 +67,7 @@ typedef struct m17_diag {
 
 typedef struct m17hip_ctx m17hip_ctx;
 
-#define M17HIP_FLAG_INVERT 1u /* apps/m17-demod.cpp:488 `if (invert_input) sample *= -1` */
+#define M17HIP_FLAG_INVERT 1u /* apps/m17-demod.cpp:488 `if (invert_input) sample *= -1`; the only flag: any other bit is M17HIP_EINVAL */
 
 const char* m17hip_strerror(int code);
 int m17hip_last_hip_error(const m17hip_ctx* ctx);

@@ -747,7 +747,7 @@ int m17hip_upload_i16_device(m17hip_ctx* c, const int16_t* dev, uint32_t C, uint
 
 int m17hip_fir_rrc150(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* out_host)
 {
-    if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT || (flags & ~M17HIP_FLAG_INVERT)) return M17HIP_EINVAL;
     GUARD(c);
     if (!c->uploaded) return M17HIP_ESTATE;
     int r = launch_fir(c, C, T, flags, c->stream);
@@ -793,6 +793,9 @@ int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, 
 int m17hip_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* sums_host, uint32_t* ticks_out)
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    // bits 4..7 switch roles of the K3 pipeline off (timing experiments, tools/k3_roles.py: the sums are wrong then): only with
+    // the diagnostics knob (m17hip_tune key 1) on
+    if ((flags & ~M17HIP_FLAG_INVERT) && !(c->profile && !(flags & ~(M17HIP_FLAG_INVERT | 0xF0u)))) return M17HIP_EINVAL;
     GUARD(c);
     if (!c->uploaded) return M17HIP_ESTATE;
     // operator-level call: always from a fresh DFT state at stream position 0
@@ -918,7 +921,7 @@ int m17hip_demod_reset(m17hip_ctx* c)
 
 int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
 {
-    if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT || (flags & ~M17HIP_FLAG_INVERT)) return M17HIP_EINVAL;
     GUARD(c);
     if (c->staged) {   // input staged by m17hip_upload_i16_async: swap the slabs, move the carried tail over
         if (C != c->stagedC || T != c->stagedT) return M17HIP_EINVAL;

@@ -45,6 +45,8 @@ def test_error_codes():
     c.upload(x)
     assert lib.m17hip_demod_run(c.h, 5, 4800, 0) == -1                              # EINVAL: beyond the context
     assert lib.m17hip_demod_run(c.h, 4, 4801, 0) == -1
+    assert lib.m17hip_demod_run(c.h, 4, 4800, 2) == -1 and lib.m17hip_fir_rrc150(c.h, 4, 4800, 16, None) == -1   # unknown flag bits
+    assert lib.m17hip_dcd(c.h, 4, 4800, 16, None, None) == -1                       # (role switches of K3: diagnostics knob only)
     assert lib.m17hip_upload_i16(c.h, x.ctypes.data_as(C.c_void_p), 4, 4800, C.c_size_t(100)) == -1   # pitch < samples
     assert lib.m17hip_set_kalman_order(c.h, 8) == -1 and lib.m17hip_set_kalman_order(c.h, 3) == 0
     assert lib.m17hip_tune(c.h, 99, 0) == -1 and lib.m17hip_tune(c.h, 0, 3) == -1
