@@ -269,22 +269,28 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
     M17_LDS uint32_t* hist = as_lds(L.hist);
     M17_LDS uint32_t* outb = as_lds(L.outb);
     {
-        const M17_LDS uint16_t* src = as_lds(L.src) + kind * 488;
+        // (the source maps stay in global memory: one frame reads <= 8 entries per lane, and the 2 KB LDS copy per workgroup is part of what kept a CU from holding anything beside four of the
+        // sequential kernel's workgroups)
+        const uint16_t* src = L.src + kind * 488;
         const M17_LDS uint32_t* llr = as_lds(L.llr);
-        auto soft = [&](int i) -> int {  // soft_at() on the wave's own LDS frame
-            const uint32_t e = src[i];
+        auto soft = [&](uint32_t e) -> int {  // soft_at() on the wave's own LDS frame
             if (e & 0x8000u) return 0;
             if (e & 0x4000u) return stale_io;
             const uint32_t idx = e & 0x1FFu;
             const int v = (int)(int8_t)(llr[idx >> 2] >> (8 * (idx & 3)));
             return (e & 0x200u) ? -v : v;
         };
+        // 64 steps per round (lane = step), the next round's two map entries in flight while this round's are used
+        uint32_t e0 = wl < steps ? src[2 * wl] : 0x8000u, e1 = wl < steps ? src[2 * wl + 1] : 0x8000u;
         for (int h = wl; h < steps; h += 64) {
-            const int s0 = soft(2 * h), s1 = soft(2 * h + 1);
+            const int hn = h + 64;
+            const uint32_t n0 = hn < steps ? src[2 * hn] : 0x8000u, n1 = hn < steps ? src[2 * hn + 1] : 0x8000u;
+            const int s0 = soft(e0), s1 = soft(e1);
             const int a = s0 ? abs(-7 - s0) : 0, b = s0 ? abs(7 - s0) : 0;  // |c - s0| for c = -7 / +7
             const int d = s1 ? abs(-7 - s1) : 0, e = s1 ? abs(7 - s1) : 0;
             cw[h] = (uint32_t)(a + d) | ((uint32_t)(a + e) << 8) | ((uint32_t)(b + d) << 16) | ((uint32_t)(b + e) << 24);
             if (h == 200) cw[480] = (uint32_t)s1;
+            e0 = n0; e1 = n1;
         }
     }
     for (int h = steps + wl; h < ((steps + 3) & ~3); h += 64) cw[h] = 0;  // the group load below reads whole groups of four

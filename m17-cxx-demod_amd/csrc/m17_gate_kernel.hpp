@@ -69,8 +69,10 @@ constexpr int GT_F4 = TICK / 4 / GT_LPC;  // float4 per lane per tick
 
 __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
 {
-    __shared__ __attribute__((aligned(16))) float yl[GT_CPW][TICK];   // matched-filter samples of the current piece
-    __shared__ __attribute__((aligned(16))) float hl[GT_CPW][TICK];   // h0 after each of them
+    // matched-filter samples of the current piece, replaced IN PLACE by h0 after each of them (the recurrence reads a sample, or the
+    // block of samples ahead of it, before it stores the history value over it): one 12 KB array instead of two
+    __shared__ __attribute__((aligned(16))) float yl[GT_CPW][TICK];
+    float (&hl)[GT_CPW][TICK] = yl;
     __shared__ float pl[GT_CPW][148];                                   // patched first outputs of the current run
     __shared__ float pw[298];                                           // patch window: 149 snapshot + 148 run samples
     __builtin_amdgcn_s_setprio(3);  // K5 of the next segment waits for this kernel: issue ahead of whatever shares the SIMD
@@ -160,24 +162,28 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
         return o;
     };
-    auto iir_tick = [&]() {   // straight-line: 24 blocks of 8 samples, the next block's reads in flight
+    auto iir_tick = [&]() {   // straight-line: 48 blocks of 4 samples, the next block's read in flight
         float m2 = IirCoef::a2 * h1;
         const float4* yv = reinterpret_cast<const float4*>(&yl[g][0]);
         float4* hv = reinterpret_cast<float4*>(&hl[g][0]);
-        float4 a0 = yv[0], a1 = yv[1];
+        float4 a0 = yv[0];
 #pragma unroll
-        for (int b = 0; b < TICK / 8; ++b) {
-            float4 n0 = a0, n1 = a1;
-            if (b + 1 < TICK / 8) { n0 = yv[2 * b + 2]; n1 = yv[2 * b + 3]; }
-            hv[2 * b] = four(a0, m2); hv[2 * b + 1] = four(a1, m2);
-            a0 = n0; a1 = n1;
+        for (int b = 0; b < TICK / 4; ++b) {
+            float4 n0 = a0;
+            if (b + 1 < TICK / 4) n0 = yv[b + 1];
+            hv[b] = four(a0, m2);
+            a0 = n0;
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the read-ahead at one block: the kernel has to fit beside K5's waves)
         }
     };
     auto store_tick = [&]() {
         float4* o = reinterpret_cast<float4*>(hr + t) + r;
         const float4* i4 = reinterpret_cast<const float4*>(&hl[g][0]) + r;
 #pragma unroll
-        for (int b = 0; b < GT_F4; ++b) o[GT_LPC * b] = i4[GT_LPC * b];
+        for (int b = 0; b < GT_F4; ++b) {
+            o[GT_LPC * b] = i4[GT_LPC * b];
+            if (b % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // three 16-byte rows in flight at a time (not all twelve: registers)
+        }
     };
     while (t < P.T) {
         // ---- steady state: every channel of the wave is inside a gated run, past its first 148 samples, and this tick holds
@@ -266,8 +272,10 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
                 } else {
                     float m2 = IirCoef::a2 * h1;
                     if ((n & 3u) == 0) {
+#pragma clang loop unroll(disable)
                         for (uint32_t i = 0; i < n; i += 4) *reinterpret_cast<float4*>(&hl[g][i]) = four(*reinterpret_cast<const float4*>(&yl[g][i]), m2);
                     } else {
+#pragma clang loop unroll(disable)
                         for (uint32_t i = 0; i < n; ++i) {
                             const float hn = iir_advance_pk(fabsf(yl[g][i]), h0, m2);
                             h2 = h1; h1 = h0; h0 = hn;

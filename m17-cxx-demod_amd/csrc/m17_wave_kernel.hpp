@@ -39,13 +39,14 @@
 namespace m17 {
 
 #ifndef M17_WAVE_MINW
-#define M17_WAVE_MINW 4  // waves per SIMD the register budget is sized for (4 = 4096 channels resident at once)
+#define M17_WAVE_MINW 5  // waves per SIMD the register budget is sized for: 96 VGPRs, so that four waves of this kernel (4096 channels
+                         // resident at once) leave 128 registers of every SIMD to the kernels that run beside it (K2, K1)
 #endif
 constexpr int WV_WIN = 1024;                                            // LDS window of upcoming matched-filter samples (circular)
 constexpr int WV_PF = 512;                                              // prefetch granule: 8 samples per lane in flight
 constexpr int WV_YCH = 480;                                             // largest bulk chunk (<= WV_PF)
-constexpr int WV_TAB_WORDS = 64 + 4 * 244 + 48 + 152;                   // per block: llr edges, source maps, lich map, FIR taps
-constexpr int WV_WAVE_WORDS = 80 + 40 + 92 + 122 + 8 + 8 + WV_WIN + 96 + 488 + 64 + 48; // per wave: ring, sync samples, llr, hist, outb, lsf, sample window, evm terms, decoder soft bits, hot state, cold state
+constexpr int WV_TAB_WORDS = 64;                                        // per block: llr edges (the decoder's source maps and the FIR taps stay in global memory)
+constexpr int WV_WAVE_WORDS = 80 + 40 + 92 + 122 + 8 + 8 + WV_WIN + 488 + 64 + 48; // per wave: ring, sync samples, llr, hist, outb, lsf, sample window, decoder soft bits (+ EVM terms), hot state, cold state
 constexpr int wave_lds_words(int waves_per_block) { return WV_TAB_WORDS + waves_per_block * WV_WAVE_WORDS; }
 
 // M17FrameDecoder::operator() on the wave's completed frame; returns (viterbi_cost, decoder state)
@@ -68,13 +69,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     float* edges = reinterpret_cast<float*>(lds);                        // [64] llr table edges (43 used)
-    uint16_t* srcmap = reinterpret_cast<uint16_t*>(edges + 64);          // [4][488] depuncture/deinterleave/derandomise maps
-    uint16_t* lichmap = srcmap + 4 * 488;                                // [96]
     for (int k = threadIdx.x; k < 43; k += 64 * WPB) edges[k] = P.llr_edges[k];
-    for (int k = threadIdx.x; k < 4 * 488; k += 64 * WPB) srcmap[k] = P.tables->src[k / 488][k % 488];
-    for (int k = threadIdx.x; k < 96; k += 64 * WPB) lichmap[k] = P.tables->lich_src[k];
-    float* taps = reinterpret_cast<float*>(lichmap + 96);              // [149] RRC taps (slow-FIR patch)
-    for (int k = threadIdx.x; k < NTAPS; k += 64 * WPB) taps[k] = P.taps[k];
+    const float* taps = P.taps;                                          // [149] RRC taps (slow-FIR patch: rare, read where they are)
     __syncthreads();  // the only block-level barrier: the waves of a block are independent from here on
 
     // the wave index is wave-uniform: tell the compiler, so that the channel's state, pointers and every branch of the state
@@ -92,13 +88,14 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     DL.outb = DL.hist + 122;                                 // [8]
     DL.lsf = DL.outb + 8;                                    // [8]   output_buffer.lsf
     float* ywin = reinterpret_cast<float*>(DL.lsf + 8);      // [WV_WIN] circular window: sample t lives at ywin[t & (WV_WIN-1)]
-    float* e2 = ywin + WV_WIN;                               // [96]  per-symbol EVM terms of a chunk
-    DL.soft = reinterpret_cast<int32_t*>(e2 + 96);           // [488] depunctured soft bits of the frame being decoded
+    DL.soft = reinterpret_cast<int32_t*>(ywin + WV_WIN);     // [488] depunctured soft bits of the frame being decoded
+    float* e2 = reinterpret_cast<float*>(DL.soft) + 304;     // [96]  per-symbol EVM terms of a chunk / limit-history window of the single-sample
+                                                             //       path: words 304..399 of the decoder array, which nothing else uses
     Hot* hot_lds = reinterpret_cast<Hot*>(DL.soft + 488);    // [64]  the channel's hot scalars (see below)
     static_assert(sizeof(Hot) <= 64 * 4, "Hot must fit its LDS slot");
     static_assert(WV_WIN == 2 * WV_PF, "a prefetch granule is half the window");
-    DL.src = srcmap;
-    DL.lich_src = lichmap;
+    DL.src = &P.tables->src[0][0];
+    DL.lich_src = P.tables->lich_src;
     DL.stride = 1;
     DL.prof = nullptr;
     if constexpr (PROF) {
@@ -728,6 +725,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         }
         if (corr_index() == 0 && flags_t != tt) clock_flags();   // (once per index-0 sample: a pending reset AND update take two of them)
         s.ck_count++;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r8[i] = 0.f;   // (dead outside this step: without the assignment the eight registers stay live across the whole loop)
         if (s.st <= ST_BERT_SYNC && !(s.st >= ST_STREAM_SYNC && s.sync_count + 1 < 78)) load_r8();  // states that correlate
         // update_values (M17Demodulator.h:233-241) is requested from seven places below and done once behind the switch (nothing
         // in between reads what it writes; where two requests meet in one sample — both words of do_unlocked — each resets the

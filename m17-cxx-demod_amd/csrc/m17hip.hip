@@ -503,6 +503,7 @@ __global__ void compact_kernel(const FrameRec* recs, uint32_t rec_cap, const uin
 }
 
 // t0: first sample of the slab to process (segment of a run); the kernels see the slab from there on
+constexpr size_t SEQ_LDS_BYTES_4 = 34816;   // see the K5 launch
 int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0)
 {
     Timed tm(c, KT_FIR, st);
@@ -1031,7 +1032,9 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         // one wave per channel; `seq_lanes` (tuning knob 0) = waves per workgroup
         const uint32_t wpb = (c->seq_lanes && !c->profile) ? c->seq_lanes : 4;  // the profiling build exists for 4 waves per workgroup
         const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
-        const size_t lds = (size_t)wave_lds_words((int)wpb) * 4;
+        // LDS: what the workgroup needs (31.8 KB for four waves), padded so that a CU holds FOUR of them and not five — the rest of
+        // the CU (24 KB, 128 VGPRs per SIMD) is where a K2 wave or a K1 workgroup runs beside them without taking a K5 slot
+        const size_t lds = std::max((size_t)wave_lds_words((int)wpb) * 4, wpb == 4 ? (size_t)SEQ_LDS_BYTES_4 : (size_t)0);
         P.dbg = c->profile ? c->dbg : nullptr;
         if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P);
         else switch (wpb) {
