@@ -83,6 +83,7 @@ struct m17hip_ctx {
     uint64_t compact_cap = 0;
     DecodeTables* tables = nullptr;
     float* taps = nullptr;
+    uint32_t seq_lds_bytes = 0; // tune 14: LDS bytes a workgroup of the sequential kernel asks for (0 = SEQ_LDS_BYTES_4 for four waves)
     int fir_form = 1;           // tune 13: 1 = rolled tap loop, 95 VGPRs (default: shares a SIMD with the sequential kernel), 0 = straight-line K1 (167 VGPRs), 2 = rolled, 11 outputs per lane, 62 VGPRs
     float* llr_edges = nullptr;
     void* scratch = nullptr;          // per-operator staging (correlator outputs, viterbi io)
@@ -1034,7 +1035,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
         // LDS: what the workgroup needs (31.8 KB for four waves), padded so that a CU holds FOUR of them and not five — the rest of
         // the CU (24 KB, 128 VGPRs per SIMD) is where a K2 wave or a K1 workgroup runs beside them without taking a K5 slot
-        const size_t lds = std::max((size_t)wave_lds_words((int)wpb) * 4, wpb == 4 ? (size_t)SEQ_LDS_BYTES_4 : (size_t)0);
+        const size_t lds = std::max((size_t)wave_lds_words((int)wpb) * 4, c->seq_lds_bytes ? (size_t)c->seq_lds_bytes : (wpb == 4 ? (size_t)SEQ_LDS_BYTES_4 : (size_t)0));
         P.dbg = c->profile ? c->dbg : nullptr;
         if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P);
         else switch (wpb) {
@@ -1446,6 +1447,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         HIPCHK(c, hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, (value & 1) ? least : 0));
         return M17HIP_OK;
     }
+    case 14:  // LDS bytes per workgroup of the sequential kernel (at least its need: decides how many of them share a CU), 0 = default
+        if (value < 0 || value > 65536) return M17HIP_EINVAL;
+        c->seq_lds_bytes = (uint32_t)value;
+        return M17HIP_OK;
     case 13:  // K1 form: 1 = rolled tap loop (default), 0 = straight-line (167 VGPRs), 2 = rolled with 11 outputs per lane (62 VGPRs)
         if (value < 0 || value > 2) return M17HIP_EINVAL;
         c->fir_form = (int)value;
