@@ -523,14 +523,17 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             ensure(n);
             float* W = reinterpret_cast<float*>(DL.soft);   // [80 + 64] correlator ring in time order, then the new samples
             float* hb = W + 160;                            // [3 + 64] h0 trajectory: hb[2], hb[1], hb[0] = h0, h1, h2 before the chunk
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
             for (uint32_t k = wl; k < 80u; k += 64) W[k] = ring[(s.prev_pos + 1u + k) % 80u];   // oldest first
             if (wl < n) W[80u + wl] = ywin[(t + wl) & (WV_WIN - 1)];
             if (s.spec_ok) {   // the trajectory is in hbuf: hb[k] = history after sample t - 3 + k
                 const int32_t off = (int32_t)t - 3 - hpf_base;
                 if (off >= 0 && off + (int32_t)n + 3 <= 64) {   // ... and already in LDS
                     hpf_ready();
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                     for (uint32_t k = wl; k < n + 3u; k += 64) hb[k] = hpf[off + (int32_t)k];
                 } else {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                     for (uint32_t k = wl; k < n + 3u; k += 64) hb[k] = hrow[(int64_t)t - 3 + k];
                 }
             } else {
@@ -577,6 +580,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 const uint32_t rp0 = s.ring_pos;
                 s.h0 = hb[2u + f]; s.h1 = hb[1u + f]; s.h2 = hb[f];
                 const uint32_t first = f > 80u ? f - 80u : 0u;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                 for (uint32_t o = first + wl; o < f; o += 64) ring[(s.ring_pos + o) % 80u] = W[80u + o];
                 s.prev_pos = (s.ring_pos + f - 1u) % 80u;
                 s.ring_pos = (s.ring_pos + f) % 80u;
@@ -615,6 +619,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             if (mode == BULK_FRAME) {
                 hw_base = 0x40000000;  // e2 is about to hold EVM terms
                 const uint32_t m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;  // payload symbols inside the chunk (<= 96)
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                 for (uint32_t k = wl; k < m; k += 64) {
                     float err;
                     const float sample = normalise(ywin[(t + o1 + 10u * k) & (WV_WIN - 1)], err);
@@ -674,6 +679,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 }
                 tk_iir += now() - b2;
                 const uint32_t first = n > 80u ? n - 80u : 0u;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                 for (uint32_t o = first + wl; o < n; o += 64) ring[(s.ring_pos + o) % 80u] = ywin[(t + o) & (WV_WIN - 1)];
                 s.prev_pos = (s.ring_pos + n - 1u) % 80u;
                 s.ring_pos = (s.ring_pos + n) % 80u;
