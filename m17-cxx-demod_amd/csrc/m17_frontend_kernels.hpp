@@ -308,7 +308,7 @@ __device__ __forceinline__ float scale_sample_mul(int s, bool invert)
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int DCD_BLK = 64;        // samples per block: conversion granule and straight-line length of the recurrence
+constexpr int DCD_BLK = 32;        // samples per block: conversion granule and straight-line length of the recurrence
 constexpr int DCD_CPW = 32;        // channels per wave
 constexpr int DCD_PITCH = DCD_BLK + 4;  // LDS row pitch in floats
 
@@ -390,13 +390,14 @@ __global__ __launch_bounds__(64 * DCD_WPB) void dcd_kernel(const int16_t* __rest
 
     uint32_t t = 0;
     while (t < T && (phase % DCD_BLK) != 0) { one_sample(t); ++t; }   // head: up to a block boundary of the tick
-    // whole blocks: lane (g, bin) converts samples [32 bin, 32 bin + 32) of its channel's block
+    // whole blocks: lane (g, bin) converts samples [HALF bin, HALF bin + HALF) of its channel's block
     if (t + DCD_BLK <= T) {
-        int4 pa[4], pb[4];
+        constexpr int HALF = DCD_BLK / 2, NQ = HALF / 8;
+        int4 pa[NQ], pb[NQ];
         auto issue = [&](uint32_t t0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int16_t* p = xr + (size_t)t0 + 32 * bin + 8 * q;
+            for (int q = 0; q < NQ; ++q) {
+                const int16_t* p = xr + (size_t)t0 + HALF * bin + 8 * q;
                 pa[q] = *reinterpret_cast<const int4*>(p);
                 pb[q] = *reinterpret_cast<const int4*>(p - 120);
             }
@@ -405,9 +406,9 @@ __global__ __launch_bounds__(64 * DCD_WPB) void dcd_kernel(const int16_t* __rest
         auto hi = [](int w) { return w >> 16; };
         issue(t);
         for (; t + DCD_BLK <= T; t += DCD_BLK) {
-            float* wrow = dl[g] + 32 * bin;
+            float* wrow = dl[g] + HALF * bin;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int4 a = pa[q], d = pb[q];
                 float4 u, v;
                 u.x = conv(lo(a.x)) - conv(lo(d.x)); u.y = conv(hi(a.x)) - conv(hi(d.x));
