@@ -281,8 +281,11 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
             return (e & 0x200u) ? -v : v;
         };
         // 64 steps per round (lane = step), the next round's two map entries in flight while this round's are used
-        uint32_t e0 = wl < steps ? src[2 * wl] : 0x8000u, e1 = wl < steps ? src[2 * wl + 1] : 0x8000u;
-        for (int h = wl; h < steps; h += 64) {
+        // (the lane id is made opaque here: the per-lane global addresses are otherwise computed once per kernel and kept, spilled)
+        int wlo = wl;
+        asm volatile("" : "+v"(wlo));
+        uint32_t e0 = wlo < steps ? src[2 * wlo] : 0x8000u, e1 = wlo < steps ? src[2 * wlo + 1] : 0x8000u;
+        for (int h = wlo; h < steps; h += 64) {
             const int hn = h + 64;
             const uint32_t n0 = hn < steps ? src[2 * hn] : 0x8000u, n1 = hn < steps ? src[2 * hn + 1] : 0x8000u;
             const int s0 = soft(e0), s1 = soft(e1);

@@ -77,6 +77,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // machine live in scalar registers / scalar branches instead of 64 identical vector copies
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wl = threadIdx.x & 63;
+    // the lane id as the COLD paths see it: opaque to the optimiser, so that what they derive from it (per-lane addresses of the
+    // diagnostic log, of state rows, lane predicates) is computed where it is used instead of being hoisted out of the main loop and
+    // kept — spilled — for the whole kernel
+    auto cold_lane = [&]() -> int { int l = wl; asm volatile("" : "+v"(l)); return l; };
     const uint32_t c = blockIdx.x * WPB + wave;
     if (c >= P.C) return;
     uint32_t* wb = lds + WV_TAB_WORDS + wave * WV_WAVE_WORDS;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     int32_t hpf_base = -0x40000000;
     bool hpf_wait = false;
     auto hpf_issue = [&](int32_t base) {
-        const int64_t i = min((int64_t)base + wl, (int64_t)P.T - 1);
+        const int64_t i = min((int64_t)base + cold_lane(), (int64_t)P.T - 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hrow + i), (__attribute__((address_space(3))) void*)hpf, 4, 0, 0);
         hpf_base = base;
         hpf_wait = true;
@@ -321,7 +325,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         dpf_tick = ~0ull;
         if (ten < (uint64_t)P.T && kn - tick0 < (uint64_t)P.ticks_cap) {
             const float* rown = tab + (size_t)(kn - tick0) * 12 + (size_t)((k + 1) % 5u);
-            if (wl < 2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rown + 6 * wl), (__attribute__((address_space(3))) void*)dpf, 4, 0, 0);
+            const int l = cold_lane();
+            if (l < 2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rown + 6 * l), (__attribute__((address_space(3))) void*)dpf, 4, 0, 0);
             dpf_tick = kn;
             hpf_wait = true;
         }
@@ -340,13 +345,14 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 const M17_LDS uint32_t* src = reinterpret_cast<const M17_LDS uint32_t*>(&cd->diag);
                 uint32_t* dst = reinterpret_cast<uint32_t*>(P.diag_log + ((size_t)c * P.diag_cap + n));
                 const uint64_t pos = P.pos0 + te;
-                if (wl < 16) {
-                    uint32_t w = src[wl];
-                    if (wl == 12) w = s.st;
-                    if (wl == 13) w = cd->seq;
-                    if (wl == 14) w = (uint32_t)pos;
-                    if (wl == 15) w = (uint32_t)(pos >> 32);
-                    dst[wl] = w;
+                const int l = cold_lane();
+                if (l < 16) {
+                    uint32_t w = src[l];
+                    if (l == 12) w = s.st;
+                    if (l == 13) w = cd->seq;
+                    if (l == 14) w = (uint32_t)pos;
+                    if (l == 15) w = (uint32_t)(pos >> 32);
+                    dst[l] = w;
                 }
             }
             cd->n_diag_run = n + 1;
@@ -378,11 +384,12 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         const unsigned long long p0 = now();
         const int r0 = s.run_pos;
         const int64_t rs = (int64_t)t0 - r0;                       // relative index of the run's first sample (>= -148)
-        for (int k = wl; k < 149; k += 64) ywin[k] = scale_sample((int)gs->hist[k], invert);
-        for (int k = wl; k < 148; k += 64)
+        const int l = cold_lane();
+        for (int k = l; k < 149; k += 64) ywin[k] = scale_sample((int)gs->hist[k], invert);
+        for (int k = l; k < 148; k += 64)
             if (rs + k < (int64_t)P.T) ywin[149 + k] = scale_sample((int)xr[rs + k], invert);
         wave_lds_sync();
-        for (int j = r0 + wl; j < 148; j += 64) {
+        for (int j = r0 + l; j < 148; j += 64) {
             if (rs + j >= (int64_t)P.T) break;
             float acc = 0.f;
             for (int i = 0; i < NTAPS; ++i) {                      // FirFilter.h:36-40: newest sample first
