@@ -190,6 +190,25 @@ def test_two_batches_in_flight_equal_one_after_the_other():
         c.close()
 
 
+def test_performance_knobs_do_not_change_results():
+    """m17hip_tune keys that only move work around (K1 form, K3 form, LDS request of the sequential kernel, waves per workgroup,
+    segment length, K2 on / off): the same records and diagnostics under every setting."""
+    x = _signals(48, 96000, seed=71, sigma=900.0)
+    exp = _oracle_flat(x)
+    c = m17hip.Context(48, 96000)
+    c.upload(x)
+    for settings in ({}, {13: 0}, {13: 2}, {10: 1}, {14: 1}, {14: 40000}, {0: 8}, {0: 1}, {3: 19200}, {2: 0}, {3: 0, 13: 0, 14: 65536}):
+        for k, v in settings.items():
+            c.tune(k, v)
+        c.reset(); c.run()
+        assert c.frames().tobytes() == exp.tobytes(), settings
+        for k in settings:
+            c.tune(k, {13: 1, 10: 0, 14: 0, 0: 0, 3: 48000, 2: 1}[k])   # back to the defaults
+    import ctypes as C_
+    assert c.lib.m17hip_tune(c.h, 14, C_.c_int64(70000)) == -1 and c.lib.m17hip_tune(c.h, 13, C_.c_int64(3)) == -1
+    c.close()
+
+
 def test_rccl_gather_single_rank():
     """m17hip_comm_* / m17hip_gather_frames with a 1-rank communicator: RCCL is bound, the counts all-gather and the
     compaction run, the root receives its own records."""
