@@ -173,8 +173,12 @@ __device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float
 {
     float mn, mx;
     core::outer_symbol_levels([&](uint32_t i) { return ring[i * stride + lane]; }, si, mn, mx);
-    kal_update(&cd->kmin, mn, 192u, 0, order);
-    kal_update(&cd->kmax, mx, 192u, 0, order);
+    // the two level filters are the same code on different data: even lanes carry the minimum's, odd lanes the maximum's, ONE
+    // update call for both (every lane runs the wave-uniform code anyway; lanes of one parity store identical values)
+    {
+        const bool odd = threadIdx.x & 1u;
+        kal_update(odd ? &cd->kmax : &cd->kmin, odd ? mx : mn, 192u, 0, order);
+    }
     const Kal2 a = lds_get(&cd->kmin), b = lds_get(&cd->kmax);
     float offset = core::freqdev_offset(b.x0, a.x0);
     float idev = core::freqdev_idev(b.x0, a.x0);
