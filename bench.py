@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--gather", choices=("auto", "cabi", "torch"), default="auto", help="N > 1: m17hip_gather_frames_device (C ABI) or m17hip/dist.py")
     ap.add_argument("--in-flight", type=int, default=2, help="independent batches (contexts) whose steps overlap: the tail of one step (K2/K5 "
                     "alternation, chip half idle) runs beside the front end of the next; 1 = one step after the other")
+    ap.add_argument("--prewarm", type=int, default=48, help="untimed steps before the --warmup steps (clock ramp of an idle GPU: about 1.3 s)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="m17hip_tune knob for experiments (e.g. 10=1: K3 as the four-wave pipeline); reported in config")
     args = ap.parse_args()
     if args.in_flight > 1:   # streams of different contexts must not share a hardware queue (the runtime's default is 4 queues)
@@ -196,6 +197,12 @@ def main():
             total = finish(k - 1)
         return finish(n_steps - 1)
 
+    # Untimed pre-warm before the W warm-up steps: a GPU that has been idle needs about a second of load before its clocks and the
+    # two batches' interleaving settle (measured: the first process on a fresh box ran 29.4 ms/step with 5 warm-up steps, 26.4 with 60)
+    # (a step count, not a time: every rank has to make the same number of gather calls)
+    if args.prewarm > 0:
+        run_steps(args.prewarm)
+        sync()
     if args.warmup:
         run_steps(args.warmup)
     for c_ in ctxs:
@@ -330,7 +337,7 @@ def main():
                    "frames_cost_lt_10": good, "parity_vs_oracle_first_channels": parity, "parity_channels": args.parity_channels,
                    "realtime_factor_per_channel": round(value * 1e6 / (C * world) / 48000.0, 1), "input_gen_s": round(t_gen, 1),
                    "parallelism": f"channels sharded contiguously over {world} GPU(s), global channel ids", "gather": gather_kind,
-                   "steps_in_flight": F, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "steps_in_flight": F, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "prewarm_steps": args.prewarm,
                    "gathered_set_ordered_and_unique": gathered_ok, "tune": tuned or None},
         "value_with_h2d": h2d["value_with_h2d"] if h2d else None, "h2d": h2d,
         "roofline": roofline, "cpu_baseline": cpu,
