@@ -431,6 +431,25 @@ __device__ __forceinline__ uint32_t viterbi_decode_wave(const DecodeLds& L, int 
     return cost;
 }
 
+// The wave decoder once more, with a run-time layout: the on-demand decode of a deferred frame (rare).
+__device__ __forceinline__ uint32_t viterbi_decode_wave_cold(const DecodeLds& L, int wl, int kind, int stale)
+{
+    return viterbi_decode_wave(L, wl, kind, stale);   // (inlined: an out-of-line call costs the kernel a stack and spills around the call)
+}
+// cost and payload of a (formerly deferred) record: the payload bytes as emit_record leaves them (zero at and beyond len)
+__device__ __forceinline__ void complete_record(uint32_t* w, uint32_t cost, const uint32_t* col, int stride, int lane, uint32_t len)
+{
+    w[4] = cost;
+    for (int q = 0; q < 8; ++q) {
+        uint32_t v = col[q * stride + lane];
+        const int lo = 4 * q;
+        if (lo + 4 > (int)len) v = (lo >= (int)len) ? 0u : (v & (0xFFFFFFFFu >> (8 * (lo + 4 - (int)len))));
+        w[6 + q] = v;
+    }
+    w[14] = 0;
+    w[15] = 0;
+}
+
 // Per-lane frame-decoder state (M17FrameDecoder members that persist between frames).
 struct DecoderRegs {
     uint32_t state;          // State enum: 0 LSF 1 STREAM 2 BASIC_PACKET 3 FULL_PACKET 4 BERT
@@ -447,7 +466,17 @@ struct RecSink {  // where callbacks go
     uint64_t sample_pos;
     uint32_t sync_type;
     uint32_t* overflow;
+    uint32_t* defer;  // wave decoder only: this channel's deferred-frame store [cap][92] (nullptr: every frame is decoded where it completes)
 };
+
+// A payload frame whose decoding is deferred (one-wave-per-channel demodulator, m17_wave_kernel.hpp): its 368 LLRs go to the
+// channel's store, its record gets the cost DEFER_TAG | slot and the marker below, and decode_deferred_kernel fills cost and
+// payload in after the run (one LANE per frame: a seventh of the instructions the wave decoder spends on it).  Real costs are
+// small, 128 or 0xFFFFFFFF ("size_t(-1)"), so bit 31 set with any other bit clear identifies a tag.
+constexpr uint32_t DEFER_TAG = 0x80000000u, DEFER_MARK = 0xDEFE77EDu;
+__device__ __forceinline__ bool cost_is_deferred(uint32_t cost) { return (cost & DEFER_TAG) && cost != 0xFFFFFFFFu; }
+__device__ __forceinline__ int kind_of_frame_type(uint32_t frame_type) { return frame_type == 5u ? 3 : 1; }   // BERT : STREAM
+__device__ __forceinline__ uint32_t len_of_kind(int kind) { return kind == 3 ? 25u : 18u; }
 
 __device__ __forceinline__ void emit_record(const RecSink& S, uint32_t& n_run, uint32_t& seq, uint32_t frame_type, int32_t cost,
                                             const uint32_t* col, int stride, int lane, uint32_t len)
@@ -473,6 +502,31 @@ __device__ __forceinline__ void emit_record(const RecSink& S, uint32_t& n_run, u
     }
     ++n_run;
     ++seq;
+}
+
+// Defer a payload frame (wave decoder): store its LLRs, reserve its record.  Returns the tag that stands for its cost, or 0 if the
+// record store is full (the caller then decodes in place so that the overflow path keeps its exact cost).
+__device__ __forceinline__ uint32_t defer_frame(const RecSink& S, uint32_t& n_run, uint32_t& seq, uint32_t frame_type, const DecodeLds& L,
+                                                int stale401, int wl)
+{
+    if (n_run >= S.cap) return 0u;
+    const uint32_t slot = n_run;
+    const M17_LDS uint32_t* llr = as_lds(L.llr);
+    uint32_t* dst = S.defer + (size_t)slot * 92;
+    for (int k = wl; k < 92; k += 64) dst[k] = llr[k];
+    uint32_t* w = reinterpret_cast<uint32_t*>(S.base + slot);
+    w[0] = S.channel;
+    w[1] = seq;
+    w[2] = (uint32_t)S.sample_pos;
+    w[3] = (uint32_t)(S.sample_pos >> 32);
+    w[4] = DEFER_TAG | slot;
+    w[5] = frame_type | (S.sync_type << 8) | (len_of_kind(kind_of_frame_type(frame_type)) << 16);
+    for (int q = 6; q < 14; ++q) w[q] = 0;
+    w[14] = (uint32_t)stale401;   // depunctured position 401 as this frame sees it (BERT reads it, Q4)
+    w[15] = DEFER_MARK;
+    ++n_run;
+    ++seq;
+    return DEFER_TAG | slot;
 }
 
 // M17FrameDecoder::operator() (M17FrameDecoder.h:353-392).  Returns the new viterbi_cost (unchanged when the
@@ -551,6 +605,12 @@ __device__ __forceinline__ uint32_t decode_frame(const DecodeTables* tb, const D
                 cost = 128;
             }
         } else if (D.state == 1) {  // decode_stream :276-289
+            if constexpr (WAVE) {
+                if (S.defer) {
+                    const uint32_t tag = defer_frame(S, n_run, seq, 2 /*STREAM*/, L, D.stale401, wl);
+                    if (tag) { cost = tag; break; }
+                }
+            }
             cost = run_viterbi(1);
             emit_record(S, n_run, seq, 2 /*STREAM*/, (int32_t)cost, L.outb, L.stride, lane, 18);
         } else {
@@ -568,6 +628,12 @@ __device__ __forceinline__ uint32_t decode_frame(const DecodeTables* tb, const D
         break;
     default:  // BERT: decode_bert :264-274
         D.state = 4;
+        if constexpr (WAVE) {
+            if (S.defer) {
+                const uint32_t tag = defer_frame(S, n_run, seq, 5 /*BERT*/, L, D.stale401, wl);
+                if (tag) { cost = tag; break; }
+            }
+        }
         cost = run_viterbi(3);
         emit_record(S, n_run, seq, 5 /*BERT*/, (int32_t)cost, L.outb, L.stride, lane, 25);
         break;

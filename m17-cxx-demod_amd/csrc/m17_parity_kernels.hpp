@@ -143,4 +143,72 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeFramesParams P)
     for (int k = 0; k < 30; ++k) P.lsf_io[(size_t)f * 30 + k] = (uint8_t)byte_at(L.lsf, 64, lane, k);
 }
 
+// Deferred frame decode (m17_wave_kernel.hpp hands payload frames of running stream / BERT transmissions over instead of decoding
+// them in the channel's wave): one workgroup per channel, one LANE per frame record — viterbi_decode, the lane-per-frame form of
+// Viterbi<Trellis<4,2>,4>::decode (Viterbi.h:162-239) with the same source maps — cost and payload go into the record the wave
+// reserved.  Then the tags that stood for those costs are replaced wherever the wave left one: the channel's saved viterbi_cost,
+// its last diagnostic callback, and the entries of its diagnostic log.
+struct DeferParams {
+    FrameRec* recs;               // [C][rec_cap]
+    uint32_t rec_cap;
+    const uint32_t* rec_count;    // [C] records of this run
+    const uint32_t* defer;        // [C][rec_cap][92]
+    const DecodeTables* tables;
+    SeqState* state;
+    Diag* diag_log;               // optional [C][diag_cap]
+    uint32_t diag_cap;
+    const uint32_t* diag_count;   // [C]
+    uint32_t C;
+};
+__global__ __launch_bounds__(64) void decode_deferred_kernel(DeferParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    DecodeLds L;
+    L.llr = lds;                // [92][64]
+    L.hist = lds + 92 * 64;     // [122][64]
+    L.outb = L.hist + 122 * 64; // [8][64]
+    L.lsf = nullptr;
+    L.stride = 64;
+    L.prof = nullptr;
+    L.soft = nullptr;
+    uint16_t* maps = reinterpret_cast<uint16_t*>(L.outb + 8 * 64);   // [4][488] source maps of the four layouts (every trellis step reads two entries)
+    const int lane = threadIdx.x;
+    for (int k = lane; k < 4 * 488; k += 64) maps[k] = P.tables->src[k / 488][k % 488];
+    __syncthreads();
+    L.src = maps;
+    L.lich_src = P.tables->lich_src;
+    const uint32_t c = blockIdx.x;
+    if (c >= P.C) return;
+    FrameRec* recs = P.recs + (size_t)c * P.rec_cap;
+    const uint32_t n = min(P.rec_count[c], P.rec_cap);
+    for (uint32_t slot = lane; slot < n; slot += 64) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(recs + slot);
+        if (!cost_is_deferred(w[4]) || w[15] != DEFER_MARK) continue;
+        const uint32_t* src = P.defer + ((size_t)c * P.rec_cap + slot) * 92;
+        for (int k = 0; k < 92; ++k) L.llr[k * 64 + lane] = src[k];
+        const int kind = kind_of_frame_type(w[5] & 0xFFu);
+        int stale = (int)w[14];
+        const uint32_t cost = viterbi_decode(P.tables, L, lane, kind, stale);
+        complete_record(w, cost, L.outb, 64, lane, len_of_kind(kind));
+    }
+    __threadfence_block();
+    __syncthreads();
+    auto settle = [&](int32_t& v) {
+        const uint32_t u = (uint32_t)v;
+        if (cost_is_deferred(u)) v = recs[u & ~DEFER_TAG].cost;
+    };
+    SeqState* st = P.state + c;
+    if (lane == 0) {
+        int32_t v = (int32_t)st->hot.viterbi_cost;
+        settle(v);
+        st->hot.viterbi_cost = (uint32_t)v;
+        settle(st->cold.diag.viterbi_cost);
+    }
+    if (P.diag_log) {
+        const uint32_t nd = min(P.diag_count[c], P.diag_cap);
+        Diag* log = P.diag_log + (size_t)c * P.diag_cap;
+        for (uint32_t e = lane; e < nd; e += 64) settle(log[e].viterbi_cost);
+    }
+}
+
 }  // namespace m17

@@ -51,10 +51,10 @@ constexpr int wave_lds_words(int waves_per_block) { return WV_TAB_WORDS + waves_
 
 // M17FrameDecoder::operator() on the wave's completed frame; returns (viterbi_cost, decoder state)
 __device__ __forceinline__ uint2 nf_decode_wave(const DecodeTables* tb, DecodeLds L, int wl, uint32_t sync_type, M17_LDS Cold* cd, uint32_t cost_in,
-                                             FrameRec* rec_base, uint32_t rec_cap, uint32_t channel, uint64_t pos, uint32_t* overflow)
+                                             FrameRec* rec_base, uint32_t rec_cap, uint32_t channel, uint64_t pos, uint32_t* overflow, uint32_t* defer)
 {
     DecoderRegs D{cd->dec_state, cd->lich_segments, cd->stale401};
-    RecSink S{rec_base, rec_cap, nullptr, nullptr, channel, pos, sync_type, overflow};
+    RecSink S{rec_base, rec_cap, nullptr, nullptr, channel, pos, sync_type, overflow, defer};
     uint32_t n_run = cd->n_run, seq = cd->seq;
     const uint32_t cost = decode_frame<true>(tb, L, 0, sync_type, D, cost_in, S, n_run, seq, wl);
     cd->dec_state = D.state; cd->lich_segments = D.lich_segments; cd->stale401 = D.stale401;
@@ -357,6 +357,28 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             }
             cd->n_diag_run = n + 1;
         }
+    };
+    // The Viterbi cost of the last frame is consulted only when a sync word is NOT found (below); if that frame's decoding was
+    // deferred (its cost is a tag), it is decoded here after all — from the deferred-frame store, on 92 words of scratch inside the
+    // decoder's array — and its record completed, so that decode_deferred_kernel skips it.
+    auto resolve_cost = [&]() {
+        if (!cost_is_deferred(s.viterbi_cost)) return;
+        const uint32_t slot = s.viterbi_cost & ~DEFER_TAG;
+        hpf_ready(); hpf_base = -0x40000000; hw_base = 0x40000000;   // the decoder takes the cost-word array, the scratch is e2's
+        uint32_t* w = reinterpret_cast<uint32_t*>(rec_base + slot);
+        const int kind = kind_of_frame_type(w[5] & 0xFFu);
+        const int stale = (int)w[14];
+        uint32_t* sc = reinterpret_cast<uint32_t*>(DL.soft) + 304;
+        const uint32_t* src = P.defer + ((size_t)c * P.rec_cap + slot) * 92;
+        const int l = cold_lane();
+        for (int k = l; k < 92; k += 64) sc[k] = src[k];
+        wave_lds_sync();
+        DecodeLds L2 = DL;
+        L2.llr = sc;
+        const uint32_t cost = viterbi_decode_wave_cold(L2, wl, kind, stale);
+        wave_lds_sync();
+        complete_record(w, cost, DL.outb, 1, 0, len_of_kind(kind));
+        s.viterbi_cost = cost;
     };
     auto dcd_point_on = [&](uint32_t te) {
         if (!s.dcd_trig) {  // update_dcd -> dcd_off :260-265 (dcd_ is on here)
@@ -819,6 +841,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 if (mode_st == ST_STREAM_SYNC) s.eot_flag = 0;
             } else if (s.sync_count > 86) {
                 const uint32_t limit = (mode_st == ST_PACKET_SYNC) ? 60u : 80u;
+                resolve_cost();
                 if (s.viterbi_cost < limit) {
                     if (!s.missing_sync_count) s.missing_sync_count = 1;
                     s.sync_word_type = swt; s.st = ST_FRAME;
@@ -870,7 +893,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         if (decode_due) {  // decoder(...) and the rest of do_frame (:619-642)
             const unsigned long long d0 = now();
             hpf_ready(); hpf_base = -0x40000000;   // the decoder takes the cost-word array
-            const uint2 r = nf_decode_wave(P.tables, DL, wl, s.sync_word_type, cd, s.viterbi_cost, rec_base, P.rec_cap, P.channel_base + c, P.pos0 + te, P.overflow);
+            const uint2 r = nf_decode_wave(P.tables, DL, wl, s.sync_word_type, cd, s.viterbi_cost, rec_base, P.rec_cap, P.channel_base + c, P.pos0 + te, P.overflow,
+                                           P.defer ? P.defer + (size_t)c * P.rec_cap * 92 : nullptr);
             s.viterbi_cost = r.x;
             s.st = (r.y == 1u || r.y == 0u) ? ST_STREAM_SYNC : (r.y == 4u ? ST_BERT_SYNC : ST_PACKET_SYNC);
             ++n_decode;
