@@ -275,8 +275,8 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * waves on a SIMD, which is worth 9 % of the step with two batches in flight), 0 = straight-line tap loop (167 VGPRs), 2 = rolled with
  * 11 outputs per lane (62 VGPRs; measured slower than 1).  key 14: LDS bytes a workgroup of the sequential kernel asks for (0 = default:
  * 34 816, which makes a CU hold four of them and leaves 24 KB and 128 VGPRs per SIMD to the kernels running beside them).
- * key 15: 1 = the sequential kernel leaves the payload frames of running stream / BERT transmissions undecoded (LLRs to a store, the
- * record reserved) and a lane-per-frame kernel decodes them after the run; 0 (default) = every frame is decoded where it completes. */
+ * key 15: 1 (default) = the sequential kernel leaves the payload frames of running stream / BERT transmissions undecoded (LLRs to a
+ * store, the record reserved) and a lane-per-frame kernel decodes them after the run; 0 = every frame is decoded where it completes. */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 
 /* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][24] =

@@ -72,13 +72,39 @@ __device__ __forceinline__ int llr_at(const uint32_t* llr, int stride, int lane,
     const uint32_t w = llr[(idx >> 2) * stride + lane];
     return (int)(int8_t)(w >> (8 * (idx & 3)));
 }
+// the same frame with the LLRs (-7 .. 7) packed two to a byte: element k of lane l at base[(k >> 3) * stride + l], nibble k & 7
+// (LQ: the LLR column and the source maps are KNOWN to be in LDS — ds_read instead of flat_load, whose s_waitcnt also waits for the
+// kernel's global stores)
+template <bool LQ = false>
+__device__ __forceinline__ int llr_at_nib(const uint32_t* llr, int stride, int lane, int idx)
+{
+    const uint32_t w = LQ ? as_lds(llr)[(idx >> 3) * stride + lane] : llr[(idx >> 3) * stride + lane];
+    return (int)(((w >> (4 * (idx & 7))) & 0xFu) ^ 8u) - 8;
+}
+template <bool NIB = false, bool LQ = false>
 __device__ __forceinline__ int soft_at(const uint16_t* src, const uint32_t* llr, int stride, int lane, int kind, int i, int stale)
 {
-    const uint32_t e = src[kind * 488 + i];
+    const uint32_t e = LQ ? as_lds(src)[kind * 488 + i] : src[kind * 488 + i];
     if (e & 0x8000u) return 0;
     if (e & 0x4000u) return stale;
-    const int v = llr_at(llr, stride, lane, (int)(e & 0x1FFu));
+    const int v = NIB ? llr_at_nib<LQ>(llr, stride, lane, (int)(e & 0x1FFu)) : llr_at(llr, stride, lane, (int)(e & 0x1FFu));
     return (e & 0x200u) ? -v : v;
+}
+// 368 LLR bytes (92 words) <-> 46 words of nibbles
+__device__ __forceinline__ uint32_t pack_llr_nibbles(uint32_t lo, uint32_t hi)   // bytes b0..b3 of lo, b4..b7 of hi -> eight nibbles
+{
+    auto four = [](uint32_t w) { return (w & 0xFu) | ((w >> 4) & 0xF0u) | ((w >> 8) & 0xF00u) | ((w >> 12) & 0xF000u); };
+    return four(lo) | (four(hi) << 16);
+}
+__device__ __forceinline__ uint32_t unpack_llr_nibbles(uint32_t packed, int half)    // half 0: b0..b3, 1: b4..b7, sign-extended bytes
+{
+    const uint32_t h = half ? packed >> 16 : packed & 0xFFFFu;
+    uint32_t w = 0;
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t n = (h >> (4 * q)) & 0xFu;
+        w |= ((uint32_t)(uint8_t)(int8_t)((int)(n ^ 8u) - 8)) << (8 * q);
+    }
+    return w;
 }
 __device__ __forceinline__ uint32_t byte_at(const uint32_t* col, int stride, int lane, int b)
 {
@@ -131,6 +157,7 @@ __device__ __forceinline__ bool golay_decode(const DecodeTables* tb, uint32_t in
 // Viterbi<Trellis<4,2>,4>::decode (Viterbi.h:162-239).  Returns cost; decoded bytes (to_byte_array, Util.h:300-318)
 // are left in L.outb.  `stale_io`: value of depunctured position 401 left by the previous frame (Q4); updated to this
 // frame's position-401 value when the layout writes it (LSF, packet).
+template <bool NIB = false, bool LQ = false>
 __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const DecodeLds& L, int lane, int kind, int& stale_io)
 {
     const int IN = DEC_IN[kind & 3], OUT = DEC_OUT[kind & 3];
@@ -141,10 +168,17 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
     for (int s = 0; s < 16; ++s) m[s] = MAXM;
     m[0] = 0;
     uint32_t prev_bits = 0;
+    // (the two soft bits of step h + 1 are fetched — map entry, then LLR: two dependent LDS round trips — while step h's sixteen
+    // add-compare-selects run; they do not depend on the metrics)
+    int ns0 = soft_at<NIB, LQ>(L.src, L.llr, L.stride, lane, kind, 0, stale_io);
+    int ns1 = soft_at<NIB, LQ>(L.src, L.llr, L.stride, lane, kind, 1, stale_io);
     for (int h = 0; h < steps; ++h) {
-        const int s0 = soft_at(L.src, L.llr, L.stride, lane, kind, 2 * h, stale_io);
-        const int s1 = soft_at(L.src, L.llr, L.stride, lane, kind, 2 * h + 1, stale_io);
+        const int s0 = ns0, s1 = ns1;
         if (2 * h == 400 && (kind & 3) != 3) stale_io = s1;  // this layout writes position 401
+        if (h + 1 < steps) {
+            ns0 = soft_at<NIB, LQ>(L.src, L.llr, L.stride, lane, kind, 2 * h + 2, stale_io);
+            ns1 = soft_at<NIB, LQ>(L.src, L.llr, L.stride, lane, kind, 2 * h + 3, stale_io);
+        }
         // branch metrics (Viterbi.h:181-200): an erased bit contributes 0
         const int a = s0 ? abs(-7 - s0) : 0, b = s0 ? abs(7 - s0) : 0;  // |c - s0| for c = -7 / +7
         const int d = s1 ? abs(-7 - s1) : 0, e = s1 ? abs(7 - s1) : 0;
@@ -183,7 +217,10 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
     const uint32_t cost = (uint32_t)roundf((float)best_cost / 7.0f);
     // chainback (Viterbi.h:226-236) fused with to_byte_array: bit n of the message -> byte n>>3, bit 7-(n&7)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) L.outb[q * L.stride + lane] = 0;
+    for (int q = 0; q < 8; ++q) {
+        if (LQ) as_lds(L.outb)[q * L.stride + lane] = 0;
+        else L.outb[q * L.stride + lane] = 0;
+    }
     uint32_t state = (uint32_t)best;
     uint32_t word = 0;
     int o = OUT;
@@ -197,7 +234,11 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
             --o;
             const int byte = o >> 3;
             word |= (state & 1u) << (8 * (byte & 3) + (7 - (o & 7)));
-            if ((o & 31) == 0) { L.outb[(byte >> 2) * L.stride + lane] = word; word = 0; }
+            if ((o & 31) == 0) {
+                if (LQ) as_lds(L.outb)[(byte >> 2) * L.stride + lane] = word;
+                else L.outb[(byte >> 2) * L.stride + lane] = word;
+                word = 0;
+            }
         }
         state = (state >> 1) + (v ? 8u : 0u);  // prevState_[s] = (s>>1, (s>>1)+8)
     }
@@ -466,7 +507,7 @@ struct RecSink {  // where callbacks go
     uint64_t sample_pos;
     uint32_t sync_type;
     uint32_t* overflow;
-    uint32_t* defer;  // wave decoder only: this channel's deferred-frame store [cap][92] (nullptr: every frame is decoded where it completes)
+    uint32_t* defer;  // wave decoder only: this channel's deferred-frame store [cap][46] (LLR nibbles; nullptr: every frame is decoded where it completes)
 };
 
 // A payload frame whose decoding is deferred (one-wave-per-channel demodulator, m17_wave_kernel.hpp): its 368 LLRs go to the
@@ -512,8 +553,10 @@ __device__ __forceinline__ uint32_t defer_frame(const RecSink& S, uint32_t& n_ru
     if (n_run >= S.cap) return 0u;
     const uint32_t slot = n_run;
     const M17_LDS uint32_t* llr = as_lds(L.llr);
-    uint32_t* dst = S.defer + (size_t)slot * 92;
-    for (int k = wl; k < 92; k += 64) dst[k] = llr[k];
+    uint32_t* dst = S.defer + (size_t)slot * 46;
+    int l = wl;
+    asm volatile("" : "+v"(l));   // (opaque: the per-lane addresses below are not worth registers across the kernel's main loop)
+    if (l < 46) dst[l] = pack_llr_nibbles(llr[2 * l], llr[2 * l + 1]);
     uint32_t* w = reinterpret_cast<uint32_t*>(S.base + slot);
     w[0] = S.channel;
     w[1] = seq;

@@ -152,7 +152,8 @@ struct DeferParams {
     FrameRec* recs;               // [C][rec_cap]
     uint32_t rec_cap;
     const uint32_t* rec_count;    // [C] records of this run
-    const uint32_t* defer;        // [C][rec_cap][92]
+    const uint32_t* defer;        // [C][rec_cap][46] LLR nibbles
+    uint32_t* hist;               // [C][101][64] decision words of the frames a workgroup is working on (global: LDS is what limits its waves)
     const DecodeTables* tables;
     SeqState* state;
     Diag* diag_log;               // optional [C][diag_cap]
@@ -160,35 +161,37 @@ struct DeferParams {
     const uint32_t* diag_count;   // [C]
     uint32_t C;
 };
+constexpr int DEFER_HIST_WORDS = 101;                                   // 201 trellis steps (BERT), two per word
+constexpr int DEFER_LDS_BYTES = (46 + 8) * 64 * 4 + 4 * 488 * 2;        // LLR nibbles, output bytes, source maps: 17.7 KB
 __global__ __launch_bounds__(64) void decode_deferred_kernel(DeferParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     DecodeLds L;
-    L.llr = lds;                // [92][64]
-    L.hist = lds + 92 * 64;     // [122][64]
-    L.outb = L.hist + 122 * 64; // [8][64]
+    L.llr = lds;                // [46][64] nibbles
+    L.outb = lds + 46 * 64;     // [8][64]
+    uint16_t* maps = reinterpret_cast<uint16_t*>(L.outb + 8 * 64);   // [4][488] source maps (every trellis step reads two entries)
     L.lsf = nullptr;
     L.stride = 64;
     L.prof = nullptr;
     L.soft = nullptr;
-    uint16_t* maps = reinterpret_cast<uint16_t*>(L.outb + 8 * 64);   // [4][488] source maps of the four layouts (every trellis step reads two entries)
     const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    L.hist = P.hist + (size_t)c * DEFER_HIST_WORDS * 64;
     for (int k = lane; k < 4 * 488; k += 64) maps[k] = P.tables->src[k / 488][k % 488];
     __syncthreads();
     L.src = maps;
     L.lich_src = P.tables->lich_src;
-    const uint32_t c = blockIdx.x;
     if (c >= P.C) return;
     FrameRec* recs = P.recs + (size_t)c * P.rec_cap;
     const uint32_t n = min(P.rec_count[c], P.rec_cap);
     for (uint32_t slot = lane; slot < n; slot += 64) {
         uint32_t* w = reinterpret_cast<uint32_t*>(recs + slot);
         if (!cost_is_deferred(w[4]) || w[15] != DEFER_MARK) continue;
-        const uint32_t* src = P.defer + ((size_t)c * P.rec_cap + slot) * 92;
-        for (int k = 0; k < 92; ++k) L.llr[k * 64 + lane] = src[k];
+        const uint32_t* src = P.defer + ((size_t)c * P.rec_cap + slot) * 46;
+        for (int k = 0; k < 46; ++k) as_lds(L.llr)[k * 64 + lane] = src[k];
         const int kind = kind_of_frame_type(w[5] & 0xFFu);
         int stale = (int)w[14];
-        const uint32_t cost = viterbi_decode(P.tables, L, lane, kind, stale);
+        const uint32_t cost = viterbi_decode<true, true>(P.tables, L, lane, kind, stale);
         complete_record(w, cost, L.outb, 64, lane, len_of_kind(kind));
     }
     __threadfence_block();

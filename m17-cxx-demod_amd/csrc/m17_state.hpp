@@ -127,7 +127,7 @@ struct SeqParams {
     uint32_t* diag_count;     // [C] entries written this run
     uint32_t kalman_order;    // evaluation order of the Kalman update (kal_update)
     uint32_t channel_base;    // global id of channel 0 of this context (written into the frame records)
-    uint32_t* defer;          // optional [C][rec_cap][92]: LLR frames whose decoding is deferred to decode_deferred_kernel (nullptr: none is)
+    uint32_t* defer;          // optional [C][rec_cap][46]: LLR frames (nibbles) whose decoding is deferred to decode_deferred_kernel (nullptr: none is)
 };
 
 // LDS words for a wave of `ls` channels: ring, sync samples, llr, hist, outb, lsf columns; edges, src maps, lich map

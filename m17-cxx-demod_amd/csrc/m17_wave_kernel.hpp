@@ -369,13 +369,13 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         const int kind = kind_of_frame_type(w[5] & 0xFFu);
         const int stale = (int)w[14];
         uint32_t* sc = reinterpret_cast<uint32_t*>(DL.soft) + 304;
-        const uint32_t* src = P.defer + ((size_t)c * P.rec_cap + slot) * 92;
+        const uint32_t* src = P.defer + ((size_t)c * P.rec_cap + slot) * 46;
         const int l = cold_lane();
-        for (int k = l; k < 92; k += 64) sc[k] = src[k];
+        for (int k = l; k < 92; k += 64) sc[k] = unpack_llr_nibbles(src[k >> 1], k & 1);
         wave_lds_sync();
         DecodeLds L2 = DL;
         L2.llr = sc;
-        const uint32_t cost = viterbi_decode_wave_cold(L2, wl, kind, stale);
+        const uint32_t cost = viterbi_decode_wave_cold(L2, l, kind, stale);   // (the opaque lane id: nothing of this copy is shared with the hot ones)
         wave_lds_sync();
         complete_record(w, cost, DL.outb, 1, 0, len_of_kind(kind));
         s.viterbi_cost = cost;
@@ -648,8 +648,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             if (mode == BULK_FRAME) {
                 hw_base = 0x40000000;  // e2 is about to hold EVM terms
                 const uint32_t m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;  // payload symbols inside the chunk (<= 96)
+                const uint32_t wls = (uint32_t)cold_lane();   // (opaque here too: the per-lane bases of the three arrays below, hoisted out of the
+                                                              //  main loop, were what the register allocator spilled; recomputing them is three instructions)
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-                for (uint32_t k = wl; k < m; k += 64) {
+                for (uint32_t k = wls; k < m; k += 64) {
                     float err;
                     const float sample = normalise(ywin[(t + o1 + 10u * k) & (WV_WIN - 1)], err);
                     e2[k] = (err * err) * alpha;
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             const unsigned long long d0 = now();
             hpf_ready(); hpf_base = -0x40000000;   // the decoder takes the cost-word array
             const uint2 r = nf_decode_wave(P.tables, DL, wl, s.sync_word_type, cd, s.viterbi_cost, rec_base, P.rec_cap, P.channel_base + c, P.pos0 + te, P.overflow,
-                                           P.defer ? P.defer + (size_t)c * P.rec_cap * 92 : nullptr);
+                                           P.defer ? P.defer + (size_t)c * P.rec_cap * 46 : nullptr);
             s.viterbi_cost = r.x;
             s.st = (r.y == 1u || r.y == 0u) ? ST_STREAM_SYNC : (r.y == 4u ? ST_BERT_SYNC : ST_PACKET_SYNC);
             ++n_decode;

@@ -83,8 +83,9 @@ struct m17hip_ctx {
     uint64_t compact_cap = 0;
     DecodeTables* tables = nullptr;
     float* taps = nullptr;
-    uint32_t* defer_llr = nullptr;   // [maxC][rec_cap_alloc][92]: LLR frames K5 leaves for decode_deferred_kernel (tune 15)
-    bool defer_decode = false;
+    uint32_t* defer_llr = nullptr;   // [maxC][rec_cap_alloc][46]: LLR frames (nibbles) K5 leaves for decode_deferred_kernel (tune 15)
+    uint32_t* defer_hist = nullptr;  // [maxC][101][64]: that kernel's decision words
+    bool defer_decode = true;
     uint32_t seq_lds_bytes = 0; // tune 14: LDS bytes a workgroup of the sequential kernel asks for (0 = SEQ_LDS_BYTES_4 for four waves)
     int fir_form = 1;           // tune 13: 1 = rolled tap loop, 95 VGPRs (default: shares a SIMD with the sequential kernel), 0 = straight-line K1 (167 VGPRs), 2 = rolled, 11 outputs per lane, 62 VGPRs
     float* llr_edges = nullptr;
@@ -593,7 +594,8 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->dcd_state, C * sizeof(DcdState));
     ALLOC(c->seq_state, C * sizeof(SeqState));
     ALLOC(c->recs, C * c->rec_cap * sizeof(FrameRec));
-    ALLOC(c->defer_llr, C * c->rec_cap * 92 * sizeof(uint32_t));
+    ALLOC(c->defer_llr, C * c->rec_cap * 46 * sizeof(uint32_t));
+    ALLOC(c->defer_hist, C * DEFER_HIST_WORDS * 64 * sizeof(uint32_t));
     ALLOC(c->rec_count, C * sizeof(uint32_t));
     ALLOC(c->rec_offsets, (C + 1) * sizeof(uint64_t));
     ALLOC(c->overflow, sizeof(uint32_t));
@@ -629,7 +631,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
         return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (122 + 122 + 16) * 64 * 4) != hipSuccess)
         return fail(M17HIP_EHIP);
-    if (hipFuncSetAttribute((const void*)decode_deferred_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (92 + 122 + 8) * 64 * 4 + 4 * 488 * 2) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)decode_deferred_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DEFER_LDS_BYTES) != hipSuccess)
         return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)decode_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (92 + 122 + 16) * 64 * 4) != hipSuccess)
         return fail(M17HIP_EHIP);
@@ -657,7 +659,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo, &c->ev_seq})
         for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr};
+                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -1057,10 +1059,10 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     HIPCHK(c, hipGetLastError());
     if (c->defer_decode) {   // the payload frames K5 did not decode itself, one lane per frame; then the cost tags K5 left are replaced
         DeferParams D{};
-        D.recs = c->recs; D.rec_cap = c->rec_cap; D.rec_count = c->rec_count; D.defer = c->defer_llr; D.tables = c->tables;
+        D.recs = c->recs; D.rec_cap = c->rec_cap; D.rec_count = c->rec_count; D.defer = c->defer_llr; D.hist = c->defer_hist; D.tables = c->tables;
         D.state = c->seq_state; D.diag_log = c->diag_cap ? c->diag_log : nullptr; D.diag_cap = c->diag_cap; D.diag_count = c->diag_count; D.C = C;
         Timed tm(c, KT_DEC);
-        hipLaunchKernelGGL(decode_deferred_kernel, dim3(C), dim3(64), (92 + 122 + 8) * 64 * 4 + 4 * 488 * 2, c->stream, D);
+        hipLaunchKernelGGL(decode_deferred_kernel, dim3(C), dim3(64), DEFER_LDS_BYTES, c->stream, D);
         HIPCHK(c, hipGetLastError());
     }
     if (c->bert)   // payload consumer: PRBS9 statistics over this run's BERT records
@@ -1461,7 +1463,7 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         HIPCHK(c, hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, (value & 1) ? least : 0));
         return M17HIP_OK;
     }
-    case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1), or in K5 (0, default)
+    case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1, default), or in K5 (0)
         c->defer_decode = value != 0;
         return M17HIP_OK;
     case 14:  // LDS bytes per workgroup of the sequential kernel (at least its need: decides how many of them share a CU), 0 = default
