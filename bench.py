@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="independent batches (contexts) whose steps overlap: the tail of one step (K2/K5 "
                     "alternation, chip half idle) runs beside the front end of the next; 1 = one step after the other")
     ap.add_argument("--prewarm", type=int, default=48, help="untimed steps before the --warmup steps (clock ramp of an idle GPU: about 1.3 s)")
+    ap.add_argument("--stagger", action="store_true", help="with --in-flight > 1: queue step k + 1 before waiting for step k (a pipeline) instead of "
+                    "launching the batches of a group together and waiting for them together (default)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="m17hip_tune knob for experiments (e.g. 10=1: K3 as the four-wave pipeline); reported in config")
     args = ap.parse_args()
     if args.in_flight > 1:   # streams of different contexts must not share a hardware queue (the runtime's default is 4 queues)
@@ -191,11 +193,19 @@ def main():
                 launch(k)
                 total = finish(k)
             return total
-        launch(0)
-        for k in range(1, n_steps):
-            launch(k)
-            total = finish(k - 1)
-        return finish(n_steps - 1)
+        if args.stagger:   # step k + 1 queued before step k is waited for: a pipeline whose batches drift half a step apart
+            launch(0)
+            for k in range(1, n_steps):
+                launch(k)
+                total = finish(k - 1)
+            return finish(n_steps - 1)
+        for k0 in range(0, n_steps, F):   # groups of F steps queued together and waited for together: the batches go through the same
+            ks = range(k0, min(k0 + F, n_steps))   # phases side by side (measured 6 % faster than half a step apart, tools/regime_bench.py)
+            for k in ks:
+                launch(k)
+            for k in ks:
+                total = finish(k)
+        return total
 
     # Untimed pre-warm before the W warm-up steps: a GPU that has been idle needs about a second of load before its clocks and the
     # two batches' interleaving settle (measured: the first process on a fresh box ran 29.4 ms/step with 5 warm-up steps, 26.4 with 60)
@@ -337,7 +347,7 @@ def main():
                    "frames_cost_lt_10": good, "parity_vs_oracle_first_channels": parity, "parity_channels": args.parity_channels,
                    "realtime_factor_per_channel": round(value * 1e6 / (C * world) / 48000.0, 1), "input_gen_s": round(t_gen, 1),
                    "parallelism": f"channels sharded contiguously over {world} GPU(s), global channel ids", "gather": gather_kind,
-                   "steps_in_flight": F, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "prewarm_steps": args.prewarm,
+                   "steps_in_flight": F, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "prewarm_steps": args.prewarm, "batches": "pipelined" if args.stagger else "launched and waited for in groups",
                    "gathered_set_ordered_and_unique": gathered_ok, "tune": tuned or None},
         "value_with_h2d": h2d["value_with_h2d"] if h2d else None, "h2d": h2d,
         "roofline": roofline, "cpu_baseline": cpu,
