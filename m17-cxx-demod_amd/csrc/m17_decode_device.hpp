@@ -47,6 +47,8 @@ struct DecodeLds {
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 template <typename T> __device__ __forceinline__ M17_LDS T* as_lds(T* p) { return (M17_LDS T*)p; }
 template <typename T> __device__ __forceinline__ const M17_LDS T* as_lds(const T* p) { return (const M17_LDS T*)p; }
+#define M17_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ M17_GLOBAL T* as_global(T* p) { return (M17_GLOBAL T*)p; }
 // whole-struct copies out of / into LDS (C++ copy constructors do not take address-space qualified objects)
 template <typename T> __device__ __forceinline__ T lds_get(const M17_LDS T* p)
 {
@@ -85,6 +87,11 @@ template <bool NIB = false, bool LQ = false>
 __device__ __forceinline__ int soft_at(const uint16_t* src, const uint32_t* llr, int stride, int lane, int kind, int i, int stale)
 {
     const uint32_t e = LQ ? as_lds(src)[kind * 488 + i] : src[kind * 488 + i];
+    if (LQ) {   // branch-free (the frame is in LDS: reading element 0 for an erasure costs nothing)
+        const int v = NIB ? llr_at_nib<LQ>(llr, stride, lane, (int)(e & 0x1FFu)) : llr_at(llr, stride, lane, (int)(e & 0x1FFu));
+        const int w = (e & 0x200u) ? -v : v;
+        return (e & 0x8000u) ? 0 : ((e & 0x4000u) ? stale : w);
+    }
     if (e & 0x8000u) return 0;
     if (e & 0x4000u) return stale;
     const int v = NIB ? llr_at_nib<LQ>(llr, stride, lane, (int)(e & 0x1FFu)) : llr_at(llr, stride, lane, (int)(e & 0x1FFu));
@@ -182,32 +189,41 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
         // branch metrics (Viterbi.h:181-200): an erased bit contributes 0
         const int a = s0 ? abs(-7 - s0) : 0, b = s0 ? abs(7 - s0) : 0;  // |c - s0| for c = -7 / +7
         const int d = s1 ? abs(-7 - s1) : 0, e = s1 ? abs(7 - s1) : 0;
-        // |c + s| = |(-c) - s| : the complement costs swap a<->b, d<->e
-        const int nn0 = a + d, nn1 = b + e;  // cost_[j] = (-7,-7): cost0, cost1
-        const int np0 = a + e, np1 = b + d;  // (-7,+7)
-        const int pn0 = b + d, pn1 = a + e;  // (+7,-7)
-        const int pp0 = b + e, pp1 = a + d;  // (+7,+7)
-        // cost_[0..7] = (-7,-7)(-7,7)(-7,7)(-7,-7)(7,-7)(7,7)(7,7)(7,-7)   (polys 031/027)
-        const int c0[8] = {nn0, np0, np0, nn0, pn0, pp0, pp0, pn0};
-        const int c1[8] = {nn1, np1, np1, nn1, pn1, pp1, pp1, pn1};
-        int32_t n[16];
+        // |c + s| = |(-c) - s| : the complement costs swap a<->b, d<->e.  The four distinct costs, doubled (see below):
+        // nn = (-7,-7), np = (-7,+7), pn = (+7,-7), pp = (+7,+7); the complement of nn is pp, of np is pn
+        const uint32_t nn = 2u * (uint32_t)(a + d), np = 2u * (uint32_t)(a + e), pn = 2u * (uint32_t)(b + d), pp = 2u * (uint32_t)(b + e);
+        // cost_[0..7] = nn np np nn pn pp pp pn   (polys 031/027); cost1 of a butterfly is the complement of its cost0
+        const uint32_t c0[8] = {nn, np, np, nn, pn, pp, pp, pn};
+        const uint32_t c1[8] = {pp, pn, pn, pp, np, nn, nn, np};
+        // Add-compare-select on DOUBLED metrics: the candidate through the lower predecessor is even, the other one odd
+        // (+ 1), so their minimum is the survivor (a tie keeps the lower predecessor, Viterbi.h:143-158: `m0 > m2` is strict) AND
+        // carries the decision in its lowest bit — no compare, no select.  v_alignbit shifts that bit into the decision word
+        // (state 0 first: it ends up in bit 16, state 15 in bit 31), a shift gives the metric back.  Unsigned: MAXM doubled is
+        // beyond INT32_MAX.
+        uint32_t n[16];
         uint32_t bits = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int32_t m0 = m[j] + c0[j], m1 = m[j] + c1[j];
-            const int32_t m2 = m[j + 8] + c1[j], m3 = m[j + 8] + c0[j];
-            const bool d0 = m0 > m2, d1 = m1 > m3;
-            bits |= (d0 ? 1u : 0u) << (2 * j);
-            bits |= (d1 ? 1u : 0u) << (2 * j + 1);
-            n[2 * j] = d0 ? m2 : m0;
-            n[2 * j + 1] = d1 ? m3 : m1;
+            const uint32_t lo = (uint32_t)m[j] << 1, hi = ((uint32_t)m[j + 8] << 1) + 1u;
+            const uint32_t n0 = min(lo + c0[j], hi + c1[j]);   // new state 2j:   m0 = m[j] + cost0, m2 = m[j+8] + cost1
+            const uint32_t n1 = min(lo + c1[j], hi + c0[j]);   // new state 2j+1: m1 = m[j] + cost1, m3 = m[j+8] + cost0
+            bits = __builtin_amdgcn_alignbit(n0, bits, 1);
+            bits = __builtin_amdgcn_alignbit(n1, bits, 1);
+            n[2 * j] = n0 >> 1;
+            n[2 * j + 1] = n1 >> 1;
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) m[s] = n[s];
-        if (h & 1) L.hist[(h >> 1) * L.stride + lane] = prev_bits | (bits << 16);
-        else prev_bits = bits;
+        for (int s = 0; s < 16; ++s) m[s] = (int32_t)n[s];
+        if (h & 1) {
+            const uint32_t hw = prev_bits | (bits & 0xFFFF0000u);
+            if (LQ) as_global(L.hist)[(h >> 1) * L.stride + lane] = hw;   // (LQ: the decision words are known to be in GLOBAL memory — a flat store would make every later LDS wait wait for it)
+            else L.hist[(h >> 1) * L.stride + lane] = hw;
+        } else prev_bits = bits >> 16;
     }
-    if (steps & 1) L.hist[(steps >> 1) * L.stride + lane] = prev_bits;
+    if (steps & 1) {
+        if (LQ) as_global(L.hist)[(steps >> 1) * L.stride + lane] = prev_bits;
+        else L.hist[(steps >> 1) * L.stride + lane] = prev_bits;
+    }
     // end state: first strict minimum scanning 0 -> 15 (Viterbi.h:211-221)
     int best = 0;
     int32_t best_cost = m[0];
@@ -227,7 +243,7 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
     int index = steps;
     for (int hi = steps; hi > 0 && o > 0;) {
         --hi;
-        const uint32_t hw = L.hist[(hi >> 1) * L.stride + lane];
+        const uint32_t hw = LQ ? as_global(L.hist)[(hi >> 1) * L.stride + lane] : L.hist[(hi >> 1) * L.stride + lane];
         const uint32_t hb = (hi & 1) ? (hw >> 16) : (hw & 0xFFFFu);
         const uint32_t v = (hb >> state) & 1u;
         if (index-- <= OUT) {
