@@ -60,7 +60,7 @@ def usable_cpus():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=3, choices=(2, 3), help="3 = BASELINE configs[2] full chain (headline); 2 = configs[1] FIR + correlator only")
     ap.add_argument("--channels", type=int, default=0, help="channels PER GPU (weak scaling); default 4096 (config 3) / 1024 (config 2)")
