@@ -89,12 +89,20 @@ int m17hip_upload_i16_device(m17hip_ctx* ctx, const int16_t* dev, uint32_t chann
  * computing.  The copy is queued on the context's own copy stream and starts as soon as the run before the current one has
  * released that slab; it should come from pinned memory (hipHostMalloc / hipHostRegister) to overlap.  The next
  * m17hip_demod_run (same channel / sample counts) makes the device wait for the copy, swaps the slabs (the carried 152-sample
- * tail is moved over) and runs on the staged input.  m17hip_demod_run does NOT wait on the host: the copy may still be in
+ * tail is moved over) and runs on the staged input.  (The first staging call of a context allocates the second set of per-run
+ * slabs: input, matched-filter output, limit-filter history, carrier-detect table.)  m17hip_demod_run does NOT wait on the host: the copy may still be in
  * flight when it returns.  The host buffer must stay valid AND unmodified until m17hip_upload_wait has returned (or until a
  * frames / diag fetch of the run that consumed it has returned — those synchronise with the run, which waited for the copy). */
 int m17hip_upload_i16_async(m17hip_ctx* ctx, const int16_t* host, uint32_t channels, uint32_t samples, size_t pitch);
-/* Block until the copy queued by the last m17hip_upload_i16_async has left the host buffer. */
+/* Block until the copy queued by the last m17hip_upload_i16_async / m17hip_upload_i16_device_async has left its source buffer. */
 int m17hip_upload_wait(m17hip_ctx* ctx);
+/* The same staging from DEVICE memory (a producer on the GPU hands a chunk over): a device-to-device copy on the context's copy
+ * stream, NOT complete when the call returns — `dev` must stay valid and unmodified until m17hip_upload_wait has returned. */
+int m17hip_upload_i16_device_async(m17hip_ctx* ctx, const int16_t* dev, uint32_t channels, uint32_t samples, size_t pitch);
+/* Staging without a copy: declares that the context's second input slab — the one the run BEFORE the latest run consumed, or
+ * that an earlier m17hip_upload_i16_async filled — already holds the next run's `channels` x `samples` input (two resident slabs
+ * that alternate, e.g. a replayed capture).  M17HIP_ESTATE if that slab holds no input of this shape. */
+int m17hip_input_alternate(m17hip_ctx* ctx, uint32_t channels, uint32_t samples);
 
 /* ---- per-operator batched entry points (config 2 parity) ---------------------------------------- */
 /* K1: sample scaling + BaseFirFilter<float,150> with the RRC taps, ungated, over the uploaded slab
@@ -131,6 +139,23 @@ int m17hip_demod_reset(m17hip_ctx* ctx);
 /* M17Demodulator<float>::operator() (M17Demodulator.h:657-753) for `samples` new samples of each channel of
  * the uploaded slab; frame callbacks become records, the last diagnostic callback becomes m17_diag. */
 int m17hip_demod_run(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint32_t flags);
+/* Streaming: pipelining of consecutive runs of the SAME channels.  apps/m17-demod.cpp:484-490 is one endless
+ * stream per channel; here the stream arrives in runs, and most of a run's arithmetic does not depend on how the run before it
+ * ended: the matched filter (FirFilter.h:28-43) needs only the carried 152-sample input tail, the sliding DFT
+ * (SlidingDFT.h:118-132) only its own end state.  With the next run's input STAGED (m17hip_upload_i16_async,
+ * m17hip_upload_i16_device_async or m17hip_input_alternate), m17hip_demod_front swaps the context's two sets of per-run slabs
+ * and queues that front end at once, on the context's side streams — while the state-machine half of the latest run (limit
+ * filter, clock recovery, slicer, Viterbi: everything that waits for M17Demodulator's state) is still at work.  The call
+ * sequence of a live feed:
+ *     stage(k + 1); m17hip_demod_front(k + 1);  m17hip_frames_fetch / _compact_device / m17hip_gather_frames (run k);
+ *     m17hip_demod_run(k + 1);  ...
+ * The m17hip_demod_run that follows must name the same channels / samples / flags (M17HIP_ESTATE otherwise) and queues the rest.
+ * Between the two calls the context's results are still those of run k; in-place uploads, per-operator entry points and
+ * m17hip_tune return M17HIP_ESTATE; m17hip_demod_reset abandons the queued front end.  Results are bit-identical to the same runs
+ * made one after the other (tests/test_gpu_streaming.py).  M17HIP_ESTATE if nothing is staged.
+ * (m17hip_demod_run on staged input without this call queues the same front end itself — then nothing is gained unless the host
+ * calls it before it has fetched the previous run's records, which it thereby gives up.) */
+int m17hip_demod_front(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint32_t flags);
 /* Number of records produced by the last run (all channels). */
 int m17hip_frames_count(m17hip_ctx* ctx, uint64_t* total);
 /* Records of the last run, ordered by (channel, seq).  Host destination.  *count = records the run produced; when that is
@@ -275,6 +300,8 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * waves on a SIMD, which is worth 9 % of the step with two batches in flight), 0 = straight-line tap loop (167 VGPRs), 2 = rolled with
  * 11 outputs per lane (62 VGPRs; measured slower than 1).  key 14: LDS bytes a workgroup of the sequential kernel asks for (0 = default:
  * 34 816, which makes a CU hold four of them and leaves 24 KB and 128 VGPRs per SIMD to the kernels running beside them).
+ * key 16 (not a performance knob): 1 = m17hip_upload_i16, m17hip_upload_i16_device and m17hip_synth_i16 write the context's STAGING slab
+ * (as m17hip_upload_i16_async does, but complete when they return) and stage it for the next run; 0 (default) = the current slab.
  * key 15: 1 (default) = the sequential kernel leaves the payload frames of running stream / BERT transmissions undecoded (LLRs to a
  * store, the record reserved) and a lane-per-frame kernel decodes them after the run; 0 = every frame is decoded where it completes. */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);

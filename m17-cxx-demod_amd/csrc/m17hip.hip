@@ -39,17 +39,38 @@ struct m17hip_ctx {
     hipStream_t side2 = nullptr;       // K1 of the segments of a run
     hipStream_t side3 = nullptr;       // K2 of segment k+1 while K5 works on segment k
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<hipEvent_t> ev_fir, ev_dcd, ev_gate, ev_redo, ev_seq;  // per segment: K1 / K3 / K2 (ahead) done, K2 redo done, K5 done
+    // per segment: K1 / K3 / K2 (ahead) done, K2 redo done, K5 done — one set per slab pair (consecutive staged runs alternate)
+    std::vector<hipEvent_t> ev_fir_[2], ev_dcd_[2], ev_gate_[2], ev_redo_[2], ev_seq_[2];
     uint32_t front_ahead = 0;         // tuning knob 5: segments the front end (K1, K3) may run ahead of K5 (0 = unlimited, measured best)
     uint32_t maxC = 0, maxT = 0;
     size_t xpitch = 0, ypitch = 0;
     uint32_t ticks_cap = 0, rec_cap = 0, rec_cap_alloc = 0;   // rec_cap: record slots per channel and run in use (<= allocated)
     int16_t* xbuf = nullptr;
-    int16_t* xstage = nullptr;        // second input slab: the next run's samples are copied here while the current run computes
-    hipStream_t copy = nullptr;
-    hipEvent_t ev_copy = nullptr, ev_run_begin = nullptr;
-    bool staged = false, run_begun = false;
+    // Streaming: a second set of the per-run slabs.  The input of the NEXT run is staged in `xstage` while the current
+    // run computes; that run's front end (K1 -> yalt, K3 -> dcd_alt) may start before the current run's K2/K5 chain has ended
+    // (m17hip_demod_front), and K2 / K5 of the next run then work on yalt / halt.  The pointers swap when a staged run begins.
+    int16_t* xstage = nullptr;
+    float* yalt = nullptr;
+    float* halt = nullptr;
+    float* dcd_alt = nullptr;
+    hipStream_t copy = nullptr;       // host -> device copies of staged input only
+    hipEvent_t ev_copy = nullptr;     // the staged copy has left its source buffer
+    hipEvent_t ev_in_ready = nullptr; // the staged slab and its carried 152-sample prefix are complete
+    hipEvent_t ev_end[2] = {nullptr, nullptr};   // the last run on slab pair 0 / 1 is done with its slabs
+    hipEvent_t ev_mark = nullptr;     // last main-stream operation a front end must not overtake (reset)
+    bool slot_used[2] = {false, false};
+    int slot = 0;                     // slab pair the pointers xbuf / ybuf / hbuf / dcd_table name
+    bool staged = false, staged_h2d = false;
+    bool stage_inputs = false;        // tuning knob 16: the in-place producers write the staging slab
+    void* synth_scratch = nullptr;    // symbol staging of m17hip_synth_i16
+    size_t synth_bytes = 0;
+    uint32_t runT = 0;                // samples of the latest run
     uint32_t stagedC = 0, stagedT = 0;
+    uint32_t slabC[2] = {0, 0}, slabT[2] = {0, 0};   // what the input slab of each pair holds (m17hip_input_alternate)
+    bool front_pending = false;       // m17hip_demod_front has queued the front end of the run that must follow
+    uint32_t frontC = 0, frontT = 0, front_flags = 0, front_segs = 0;
+    bool front_was_staged = false;    // the run whose front end is queued works on freshly swapped slabs (prefixes still to be carried)
+    uint32_t carryT = 0;              // length of the run whose tail those prefixes come from (0 = none since the reset)
     float* ybuf = nullptr;
     float* hbuf = nullptr;            // K2's limit-filter history, same pitch as ybuf
     float* final_h = nullptr;         // [2][maxC][4], by segment parity
@@ -94,7 +115,8 @@ struct m17hip_ctx {
     DcdCoef coef{};
     uint64_t pos = 0;          // samples consumed since reset
     uint32_t lastC = 0, lastT = 0;
-    bool have_run = false;
+    bool have_run = false;     // a run has been made since the last reset (the stream continues)
+    bool recs_valid = false;   // the record slots hold a finished run's records in the layout (rec_cap) they were written with
     bool uploaded = false;
     bool timing = false;
     uint32_t seq_lanes = 0;    // waves per workgroup in K5 (0 = default)
@@ -451,6 +473,16 @@ __global__ void copy_prefix_i16_kernel(const int16_t* src, int16_t* dst, size_t 
     for (int k = threadIdx.x; k < XPRE; k += blockDim.x) dst[(size_t)blockIdx.x * xpitch + k] = src[(size_t)blockIdx.x * xpitch + k];
 }
 
+// staged runs: the other slab's prefix = the last XPRE samples of the previous run's input (read where they lie: row[T .. T + XPRE))
+__global__ void copy_tail_i16_kernel(const int16_t* src, int16_t* dst, size_t xpitch, uint32_t T)
+{
+    for (int k = threadIdx.x; k < XPRE; k += blockDim.x) dst[(size_t)blockIdx.x * xpitch + k] = src[(size_t)blockIdx.x * xpitch + T + k];
+}
+__global__ void copy_prefix_f32_kernel(const float* src, float* dst, size_t ypitch)
+{
+    for (int k = threadIdx.x; k < YPRE; k += blockDim.x) dst[(size_t)blockIdx.x * ypitch + k] = src[(size_t)blockIdx.x * ypitch + k];
+}
+
 __global__ void carry_tail_f32_kernel(float* y, size_t ypitch, uint32_t T)
 {
     __shared__ float ys[YPRE];
@@ -558,7 +590,7 @@ const char* m17hip_strerror(int code)
     }
 }
 int m17hip_last_hip_error(const m17hip_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
-int m17hip_version(void) { return 200; }
+int m17hip_version(void) { return 300; }
 
 int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out)
 {
@@ -594,8 +626,6 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->dcd_state, C * sizeof(DcdState));
     ALLOC(c->seq_state, C * sizeof(SeqState));
     ALLOC(c->recs, C * c->rec_cap * sizeof(FrameRec));
-    ALLOC(c->defer_llr, C * c->rec_cap * 46 * sizeof(uint32_t));
-    ALLOC(c->defer_hist, C * DEFER_HIST_WORDS * 64 * sizeof(uint32_t));
     ALLOC(c->rec_count, C * sizeof(uint32_t));
     ALLOC(c->rec_offsets, (C + 1) * sizeof(uint64_t));
     ALLOC(c->overflow, sizeof(uint32_t));
@@ -627,6 +657,9 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
+    if (hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
+    for (int q = 0; q < 2; ++q)
+        if (hipEventCreateWithFlags(&c->ev_end[q], hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)demod_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, wave_lds_words(8) * 4) != hipSuccess)
         return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (122 + 122 + 16) * 64 * 4) != hipSuccess)
@@ -654,12 +687,14 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     if (c->side2) hipStreamDestroy(c->side2);
     if (c->side3) hipStreamDestroy(c->side3);
     if (c->copy) hipStreamDestroy(c->copy);
-    if (c->ev_copy) hipEventDestroy(c->ev_copy);
-    if (c->ev_run_begin) hipEventDestroy(c->ev_run_begin);
-    for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo, &c->ev_seq})
-        for (auto e : *v) hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_copy, c->ev_in_ready, c->ev_end[0], c->ev_end[1], c->ev_mark})
+        if (e) hipEventDestroy(e);
+    for (int q = 0; q < 2; ++q)
+        for (auto* v : {&c->ev_fir_[q], &c->ev_dcd_[q], &c->ev_gate_[q], &c->ev_redo_[q], &c->ev_seq_[q]})
+            for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist};
+                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist,
+                    c->yalt, c->halt, c->dcd_alt, c->synth_scratch};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -673,15 +708,65 @@ int m17hip_set_stream(m17hip_ctx* c, void* hip_stream)
     return M17HIP_OK;
 }
 
+// ---- staged input (streaming) -------------------------------------------------------------------------------------------
+// Second slab pair, streams and events: allocated the first time input is staged.
+static int stage_prepare(m17hip_ctx* c)
+{
+    if (!c->xstage) {
+        auto alloc = [&](void** p, size_t bytes) -> int {
+            const hipError_t e = hipMalloc(p, bytes);
+            if (e != hipSuccess) { c->last_hip = (int)e; return e == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP; }
+            return M17HIP_OK;
+        };
+        int r;
+        if ((r = alloc((void**)&c->yalt, (size_t)c->maxC * c->ypitch * sizeof(float)))) return r;
+        if ((r = alloc((void**)&c->halt, (size_t)c->maxC * c->ypitch * sizeof(float)))) return r;
+        if ((r = alloc((void**)&c->dcd_alt, (size_t)c->maxC * c->ticks_cap * 12 * sizeof(float)))) return r;
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_in_ready, hipEventDisableTiming));
+        if ((r = alloc((void**)&c->xstage, (size_t)c->maxC * c->xpitch * sizeof(int16_t)))) return r;   // last: its presence says "all of it is there"
+    }
+    return M17HIP_OK;
+}
+
+// Where an in-place producer (m17hip_upload_i16, m17hip_upload_i16_device, m17hip_synth_i16) writes: the current input slab on the
+// main stream, or — tuning knob 16 — the STAGING slab on the copy stream, as soon as the run before the latest one has released it.
+struct InputTarget { int16_t* x = nullptr; hipStream_t st = nullptr; bool stage = false; };
+static int input_target(m17hip_ctx* c, InputTarget& t)
+{
+    if (!c->stage_inputs) { t.x = c->xbuf; t.st = c->stream; t.stage = false; return M17HIP_OK; }
+    const int r = stage_prepare(c);
+    if (r) return r;
+    const int other = c->slot ^ 1;
+    if (c->slot_used[other]) HIPCHK(c, hipStreamWaitEvent(c->copy, c->ev_end[other], 0));
+    t.x = c->xstage; t.st = c->copy; t.stage = true;
+    return M17HIP_OK;
+}
+static void input_done(m17hip_ctx* c, const InputTarget& t, uint32_t C, uint32_t T)
+{
+    if (t.stage) {
+        c->staged = true; c->staged_h2d = false; c->stagedC = C; c->stagedT = T;
+        c->slabC[c->slot ^ 1] = C; c->slabT[c->slot ^ 1] = T;
+        return;
+    }
+    c->uploaded = true;
+    c->slabC[c->slot] = C; c->slabT[c->slot] = T;
+    c->lastC = C; c->lastT = T;
+}
+
 int m17hip_upload_i16(m17hip_ctx* c, const int16_t* host, uint32_t C, uint32_t T, size_t pitch)
 {
     if (!c || !host || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
     GUARD(c);
-    HIPCHK(c, hipMemcpy2DAsync(c->xbuf + XPRE, c->xpitch * sizeof(int16_t), host, pitch * sizeof(int16_t), (size_t)T * sizeof(int16_t), C,
-                               hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->uploaded = true;
-    c->lastC = C; c->lastT = T;
+    if (c->front_pending) return M17HIP_ESTATE;   // the slabs belong to the run m17hip_demod_front has started
+    InputTarget in;
+    int r = input_target(c, in);
+    if (r) return r;
+    HIPCHK(c, hipMemcpy2DAsync(in.x + XPRE, c->xpitch * sizeof(int16_t), host, pitch * sizeof(int16_t), (size_t)T * sizeof(int16_t), C,
+                               hipMemcpyHostToDevice, in.st));
+    HIPCHK(c, hipStreamSynchronize(in.st));
+    input_done(c, in, C, T);
     return M17HIP_OK;
 }
 
@@ -689,20 +774,46 @@ int m17hip_upload_i16_async(m17hip_ctx* c, const int16_t* host, uint32_t C, uint
 {
     if (!c || !host || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
     GUARD(c);
-    if (!c->xstage) {
-        hipError_t e = hipMalloc((void**)&c->xstage, (size_t)c->maxC * c->xpitch * sizeof(int16_t));
-        if (e != hipSuccess) { c->last_hip = (int)e; return e == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP; }
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_run_begin, hipEventDisableTiming));
-    }
-    // the staging slab was the input of the run BEFORE the one now queued / running: free once that run's work is done,
-    // which is where the current run began
-    if (c->run_begun) HIPCHK(c, hipStreamWaitEvent(c->copy, c->ev_run_begin, 0));
+    if (c->front_pending) return M17HIP_ESTATE;
+    int r = stage_prepare(c);
+    if (r) return r;
+    // the staging slab was the input of the run BEFORE the one now queued / running: free once that run is done with it
+    const int other = c->slot ^ 1;
+    if (c->slot_used[other]) HIPCHK(c, hipStreamWaitEvent(c->copy, c->ev_end[other], 0));
     HIPCHK(c, hipMemcpy2DAsync(c->xstage + XPRE, c->xpitch * sizeof(int16_t), host, pitch * sizeof(int16_t), (size_t)T * sizeof(int16_t), C,
                                hipMemcpyHostToDevice, c->copy));
     HIPCHK(c, hipEventRecord(c->ev_copy, c->copy));
-    c->staged = true; c->stagedC = C; c->stagedT = T;
+    c->staged = true; c->staged_h2d = true; c->stagedC = C; c->stagedT = T;
+    c->slabC[other] = C; c->slabT[other] = T;
+    return M17HIP_OK;
+}
+
+int m17hip_upload_i16_device_async(m17hip_ctx* c, const int16_t* dev, uint32_t C, uint32_t T, size_t pitch)
+{
+    if (!c || !dev || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
+    GUARD(c);
+    if (c->front_pending) return M17HIP_ESTATE;
+    int r = stage_prepare(c);
+    if (r) return r;
+    const int other = c->slot ^ 1;
+    if (c->slot_used[other]) HIPCHK(c, hipStreamWaitEvent(c->copy, c->ev_end[other], 0));
+    dim3 grid(((T + 7) / 8 + 255) / 256, C);
+    hipLaunchKernelGGL(copy_rows_i16_kernel, grid, dim3(256), 0, c->copy, dev, pitch, c->xstage, c->xpitch, T);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_copy, c->copy));
+    c->staged = true; c->staged_h2d = false; c->stagedC = C; c->stagedT = T;
+    c->slabC[other] = C; c->slabT[other] = T;
+    return M17HIP_OK;
+}
+
+int m17hip_input_alternate(m17hip_ctx* c, uint32_t C, uint32_t T)
+{
+    if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
+    GUARD(c);
+    if (c->front_pending) return M17HIP_ESTATE;
+    const int other = c->slot ^ 1;
+    if (!c->xstage || c->slabC[other] != C || c->slabT[other] != T) return M17HIP_ESTATE;   // the other slab does not hold such an input
+    c->staged = true; c->staged_h2d = false; c->stagedC = C; c->stagedT = T;
     return M17HIP_OK;
 }
 
@@ -710,23 +821,30 @@ int m17hip_synth_i16(m17hip_ctx* c, const m17_synth_params* params, uint32_t C, 
 {
     if (!c || !params || C == 0 || T == 0 || C > c->maxC || T > c->maxT || params->n_frames < 0 || params->kind > 4) return M17HIP_EINVAL;
     GUARD(c);
+    if (c->front_pending) return M17HIP_ESTATE;   // the slabs belong to the run m17hip_demod_front has started
     if (params->kind == 4 && (params->n_frames < 1 || params->n_frames > 33)) return M17HIP_EINVAL;   // 5-bit frame numbers
     static_assert(sizeof(ModParams) == sizeof(m17_synth_params), "parameter block layout");
     ModParams mp;
     std::memcpy(&mp, params, sizeof(mp));
     const size_t sym_pitch = round_up((size_t)mod_max_symbols(mp.n_frames, mp.n_preamble), 16);
     const size_t sym_bytes = round_up((size_t)C * sym_pitch, 256);
-    int r = ensure_scratch(c, sym_bytes + (size_t)C * 4);
+    InputTarget in;
+    int r = input_target(c, in);
     if (r) return r;
-    int8_t* sym = reinterpret_cast<int8_t*>(c->scratch);
-    uint32_t* nsym = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->scratch) + sym_bytes);
-    hipLaunchKernelGGL(mod_symbols_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, mp, C, chan0, sym, sym_pitch, nsym);
+    // the symbol staging lives in its own allocation: the per-operator scratch may be in use by work queued on the main stream
+    if (sym_bytes + (size_t)C * 4 > c->synth_bytes) {
+        if (c->synth_scratch) { HIPCHK(c, hipDeviceSynchronize()); hipFree(c->synth_scratch); c->synth_scratch = nullptr; c->synth_bytes = 0; }
+        HIPCHK(c, hipMalloc(&c->synth_scratch, sym_bytes + (size_t)C * 4));
+        c->synth_bytes = sym_bytes + (size_t)C * 4;
+    }
+    int8_t* sym = reinterpret_cast<int8_t*>(c->synth_scratch);
+    uint32_t* nsym = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->synth_scratch) + sym_bytes);
+    hipLaunchKernelGGL(mod_symbols_kernel, dim3((C + 63) / 64), dim3(64), 0, in.st, mp, C, chan0, sym, sym_pitch, nsym);
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(mod_shape_kernel, dim3((T + 255) / 256, C), dim3(256), 0, c->stream, mp, C, T, chan0, sym, sym_pitch, nsym, c->xbuf, c->xpitch);
+    hipLaunchKernelGGL(mod_shape_kernel, dim3((T + 255) / 256, C), dim3(256), 0, in.st, mp, C, T, chan0, sym, sym_pitch, nsym, in.x, c->xpitch);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->uploaded = true;
-    c->lastC = C; c->lastT = T;
+    HIPCHK(c, hipStreamSynchronize(in.st));
+    input_done(c, in, C, T);
     return M17HIP_OK;
 }
 
@@ -745,12 +863,15 @@ int m17hip_upload_i16_device(m17hip_ctx* c, const int16_t* dev, uint32_t C, uint
 {
     if (!c || !dev || C == 0 || T == 0 || C > c->maxC || T > c->maxT || pitch < T) return M17HIP_EINVAL;
     GUARD(c);
+    if (c->front_pending) return M17HIP_ESTATE;   // the slabs belong to the run m17hip_demod_front has started
+    InputTarget in;
+    int r = input_target(c, in);
+    if (r) return r;
     dim3 grid(((T + 7) / 8 + 255) / 256, C);
-    hipLaunchKernelGGL(copy_rows_i16_kernel, grid, dim3(256), 0, c->stream, dev, pitch, c->xbuf, c->xpitch, T);
+    hipLaunchKernelGGL(copy_rows_i16_kernel, grid, dim3(256), 0, in.st, dev, pitch, in.x, c->xpitch, T);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // `dev` belongs to the caller again when this returns
-    c->uploaded = true;
-    c->lastC = C; c->lastT = T;
+    HIPCHK(c, hipStreamSynchronize(in.st));   // `dev` belongs to the caller again when this returns
+    input_done(c, in, C, T);
     return M17HIP_OK;
 }
 
@@ -758,6 +879,7 @@ int m17hip_fir_rrc150(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, flo
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT || (flags & ~M17HIP_FLAG_INVERT)) return M17HIP_EINVAL;
     GUARD(c);
+    if (c->front_pending) return M17HIP_ESTATE;
     if (!c->uploaded) return M17HIP_ESTATE;
     int r = launch_fir(c, C, T, flags, c->stream);
     if (r) return r;
@@ -773,6 +895,7 @@ int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, 
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
     GUARD(c);
+    if (c->front_pending) return M17HIP_ESTATE;
     const size_t n = (size_t)C * T;
     int r = ensure_scratch(c, 5 * n * sizeof(float));
     if (r) return r;
@@ -806,6 +929,7 @@ int m17hip_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* sum
     // the diagnostics knob (m17hip_tune key 1) on
     if ((flags & ~M17HIP_FLAG_INVERT) && !(c->profile && !(flags & ~(M17HIP_FLAG_INVERT | 0xF0u)))) return M17HIP_EINVAL;
     GUARD(c);
+    if (c->front_pending) return M17HIP_ESTATE;
     if (!c->uploaded) return M17HIP_ESTATE;
     // operator-level call: always from a fresh DFT state at stream position 0
     HIPCHK(c, hipMemsetAsync(c->dcd_state, 0, (size_t)C * sizeof(DcdState), c->stream));
@@ -909,6 +1033,11 @@ int m17hip_demod_reset(m17hip_ctx* c)
 {
     if (!c) return M17HIP_EINVAL;
     GUARD(c);
+    if (c->front_pending) {   // a front end queued by m17hip_demod_front is abandoned: let it drain, its results are not used
+        HIPCHK(c, hipStreamSynchronize(c->side));
+        HIPCHK(c, hipStreamSynchronize(c->side2));
+        c->front_pending = false;
+    }
     hipLaunchKernelGGL(seq_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->dcd_state, c->maxC);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(zero_prefix_kernel, dim3(c->maxC), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, c->maxC);
@@ -923,8 +1052,116 @@ int m17hip_demod_reset(m17hip_ctx* c)
     }
     HIPCHK(c, hipMemsetAsync(c->rec_count, 0, (size_t)c->maxC * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->overflow, 0, 4, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));   // the front end of a staged run starts on its own streams: not before this
     c->pos = 0;
     c->have_run = false;
+    c->recs_valid = false;
+    return M17HIP_OK;
+}
+
+namespace {
+
+// How a run of T samples is cut into segments (tuning knobs 3, 4): segment k covers [t0(k), t0(k + 1)): a short first one (its front
+// end and K2 are all K5 has to wait for), then equal ones.
+struct SegPlan {
+    uint32_t T, seg_len, seg0, nseg;
+    SegPlan(const m17hip_ctx* c, uint32_t T_) : T(T_)
+    {
+        seg_len = (!c->profile && c->seg_len) ? c->seg_len : T;
+        seg0 = (seg_len < T && c->seg0_len && c->seg0_len < seg_len) ? c->seg0_len : seg_len;
+        nseg = T <= seg0 ? 1u : 1u + (T - seg0 + seg_len - 1) / seg_len;
+    }
+    uint32_t t0(uint32_t k) const { return k == 0 ? 0u : std::min(T, seg0 + (k - 1u) * seg_len); }
+};
+
+int ensure_seg_events(m17hip_ctx* c, int q, uint32_t nseg)
+{
+    while (c->ev_fir_[q].size() < nseg) {
+        for (auto* v : {&c->ev_fir_[q], &c->ev_dcd_[q], &c->ev_gate_[q], &c->ev_redo_[q], &c->ev_seq_[q]}) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            v->push_back(e);
+        }
+    }
+    return M17HIP_OK;
+}
+
+// K3 and K1 of segment k of the run being queued (slab pair c->slot), on the two side streams.
+// The front end of segment k may be held back until K5 of segment k - front_ahead is done (tuning knob 5), to spread it over
+// the step; measured, letting it run ahead freely is faster (K3 is a latency chain of 1.7 ms per segment: held back, it is
+// what K5 ends up waiting for).
+int launch_front_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, uint32_t C, uint32_t flags)
+{
+    if (k >= sp.nseg) return M17HIP_OK;
+    const int q = c->slot;
+    const uint32_t ahead = c->front_ahead ? c->front_ahead : sp.nseg;
+    const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
+    if (k >= ahead) {
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_seq_[q][k - ahead], 0));
+        HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_seq_[q][k - ahead], 0));
+    }
+    if (k == 1) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fir_[q][0], 0));   // segment 0's front end first: K2/K5 wait for it
+    int r2;
+    if ((r2 = launch_dcd(c, C, len, flags, c->side, t0))) return r2;
+    HIPCHK(c, hipEventRecord(c->ev_dcd_[q][k], c->side));
+    if ((r2 = launch_fir(c, C, len, flags, c->side2, t0))) return r2;
+    HIPCHK(c, hipEventRecord(c->ev_fir_[q][k], c->side2));
+    return M17HIP_OK;
+}
+
+// A staged run begins: the slab pairs swap, the 152-sample tail of the previous input is carried into the new slab's prefix, and the
+// front end (K1, K3: nothing in them depends on the outcome of the run before) is queued on the side streams — NOT ordered behind
+// the main stream, where K2 / K5 of the previous run may still have a long way to go.
+int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
+{
+    if (C != c->stagedC || T != c->stagedT) return M17HIP_EINVAL;
+    if (c->have_run && C != c->lastC) return M17HIP_EINVAL;  // a continued stream keeps its channel count
+    const int16_t* xprev = c->xbuf;
+    std::swap(c->xbuf, c->xstage);
+    std::swap(c->ybuf, c->yalt);
+    std::swap(c->hbuf, c->halt);
+    std::swap(c->dcd_table, c->dcd_alt);
+    c->slot ^= 1;
+    c->staged = false;
+    c->uploaded = true;
+    c->carryT = c->have_run ? c->runT : 0;
+    // the new slab's prefix, behind the staged copy on the copy stream; the slab pair itself is free since ev_end[slot] (the copy
+    // stream waited for it when the input was staged — m17hip_input_alternate stages without a copy, so wait here as well)
+    if (c->slot_used[c->slot]) HIPCHK(c, hipStreamWaitEvent(c->copy, c->ev_end[c->slot], 0));
+    if (c->carryT >= (uint32_t)XPRE)   // the tail of the previous input, where it lies (that slab is only read while its run is in flight)
+        hipLaunchKernelGGL(copy_tail_i16_kernel, dim3(C), dim3(64), 0, c->copy, xprev, c->xbuf, c->xpitch, c->carryT);
+    else if (c->carryT) {              // a run shorter than the prefix: its tail reaches into its own prefix, which its last kernel rewrites — wait for that
+        HIPCHK(c, hipStreamWaitEvent(c->copy, c->ev_end[c->slot ^ 1], 0));
+        hipLaunchKernelGGL(copy_prefix_i16_kernel, dim3(C), dim3(64), 0, c->copy, xprev, c->xbuf, c->xpitch);
+    } else HIPCHK(c, hipMemset2DAsync(c->xbuf, c->xpitch * sizeof(int16_t), 0, XPRE * sizeof(int16_t), C, c->copy));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_in_ready, c->copy));
+    for (hipStream_t st : {c->side, c->side2}) {
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_in_ready, 0));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_mark, 0));
+    }
+    const SegPlan sp(c, T);
+    int r = ensure_seg_events(c, c->slot, sp.nseg);
+    if (r) return r;
+    const uint32_t ahead = c->front_ahead ? c->front_ahead : sp.nseg;
+    c->front_segs = std::min(ahead, sp.nseg);
+    for (uint32_t k = 0; k < c->front_segs; ++k)
+        if ((r = launch_front_seg(c, sp, k, C, flags))) return r;
+    c->front_was_staged = true;
+    c->frontC = C; c->frontT = T; c->front_flags = flags;
+    return M17HIP_OK;
+}
+
+}  // namespace
+
+int m17hip_demod_front(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
+{
+    if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT || (flags & ~M17HIP_FLAG_INVERT)) return M17HIP_EINVAL;
+    GUARD(c);
+    if (c->front_pending || !c->staged) return M17HIP_ESTATE;
+    const int r = begin_staged(c, C, T, flags);
+    if (r) return r;
+    c->front_pending = true;
     return M17HIP_OK;
 }
 
@@ -932,65 +1169,58 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT || (flags & ~M17HIP_FLAG_INVERT)) return M17HIP_EINVAL;
     GUARD(c);
-    if (c->staged) {   // input staged by m17hip_upload_i16_async: swap the slabs, move the carried tail over
-        if (C != c->stagedC || T != c->stagedT) return M17HIP_EINVAL;
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
-        hipLaunchKernelGGL(copy_prefix_i16_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xstage, c->xpitch);
-        HIPCHK(c, hipGetLastError());
-        std::swap(c->xbuf, c->xstage);
-        c->staged = false;
-        c->uploaded = true;
+    int r;
+    bool staged_run = false;
+    if (c->front_pending) {   // the front end is already on its way (m17hip_demod_front): this call must be the run it was queued for
+        if (C != c->frontC || T != c->frontT || flags != c->front_flags) return M17HIP_ESTATE;
+        c->front_pending = false;
+        staged_run = true;
+    } else if (c->staged) {   // input staged by m17hip_upload_i16_async and friends: swap the slabs, queue the front end
+        if ((r = begin_staged(c, C, T, flags))) return r;
+        staged_run = true;
     }
     if (!c->uploaded) return M17HIP_ESTATE;
     if (c->have_run && C != c->lastC) return M17HIP_EINVAL;  // a continued stream keeps its channel count
-    int r;
-    if (c->ev_run_begin) { HIPCHK(c, hipEventRecord(c->ev_run_begin, c->stream)); c->run_begun = true; }
     // The run is processed in segments.  K1 (throughput-bound, the whole chip) and K3 (latency-bound lone waves) of ALL segments
     // are queued on two side streams; the main stream runs K2 -> K5 per segment as soon as that segment's K1 and K3 are done,
     // so the front end of segment k+1 fills the issue slots K5 of segment k leaves idle (its tail above all).
     // Every K2 starts a fresh speculation from K5's own state, so a channel that had to drop it (forced unlock) carries the
     // limit filter itself only until the end of its segment.
-    const uint32_t seg_len = (!c->profile && c->seg_len) ? c->seg_len : T;
-    // segment k covers [seg_t0(k), seg_t0(k + 1)): a short first one (its front end and K2 are all K5 has to wait for), then equal ones
-    const uint32_t seg0 = (seg_len < T && c->seg0_len && c->seg0_len < seg_len) ? c->seg0_len : seg_len;
-    const uint32_t nseg = T <= seg0 ? 1u : 1u + (T - seg0 + seg_len - 1) / seg_len;
-    auto seg_t0 = [&](uint32_t k) -> uint32_t { return k == 0 ? 0u : std::min(T, seg0 + (k - 1u) * seg_len); };
-    while (c->ev_fir.size() < nseg) {
-        for (auto* v : {&c->ev_fir, &c->ev_dcd, &c->ev_gate, &c->ev_redo, &c->ev_seq}) {
-            hipEvent_t e;
-            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            v->push_back(e);
-        }
-    }
-    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork, 0));
-    // The front end of segment k may be held back until K5 of segment k - front_ahead is done (tuning knob 5), to spread it over
-    // the step; measured, letting it run ahead freely is faster (K3 is a latency chain of 1.7 ms per segment: held back, it is
-    // what K5 ends up waiting for).
+    const SegPlan sp(c, T);
+    const uint32_t nseg = sp.nseg;
+    const int q = c->slot;
+    if ((r = ensure_seg_events(c, q, nseg))) return r;
+    auto& ev_fir = c->ev_fir_[q]; auto& ev_dcd = c->ev_dcd_[q]; auto& ev_gate = c->ev_gate_[q]; auto& ev_redo = c->ev_redo_[q]; auto& ev_seq = c->ev_seq_[q];
     const uint32_t ahead = c->front_ahead ? c->front_ahead : nseg;
-    auto launch_front = [&](uint32_t k) -> int {
-        if (k >= nseg) return M17HIP_OK;
-        const uint32_t t0 = seg_t0(k), len = seg_t0(k + 1) - t0;
-        if (k >= ahead) {
-            HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_seq[k - ahead], 0));
-            HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_seq[k - ahead], 0));
+    if (staged_run) {
+        // K2 / K5 read the input slab too (snapshots, spliced-history FIR outputs); the y / h prefixes (the correlator ring and the limit
+        // filter's history reach back into the previous run) come from the previous run's slabs, final now that its K5 is done
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in_ready, 0));
+        if (c->carryT) {   // (the previous run ended by carrying its tails into its own prefixes: copy those)
+            hipLaunchKernelGGL(copy_prefix_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->yalt, c->ybuf, c->ypitch);
+            hipLaunchKernelGGL(copy_prefix_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->halt, c->hbuf, c->ypitch);
+            HIPCHK(c, hipGetLastError());
+        } else {
+            HIPCHK(c, hipMemset2DAsync(c->ybuf, c->ypitch * sizeof(float), 0, YPRE * sizeof(float), C, c->stream));
+            HIPCHK(c, hipMemset2DAsync(c->hbuf, c->ypitch * sizeof(float), 0, YPRE * sizeof(float), C, c->stream));
         }
-        if (k == 1) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fir[0], 0));   // segment 0's front end first: K2/K5 wait for it
-        int r2;
-        if ((r2 = launch_dcd(c, C, len, flags, c->side, t0))) return r2;
-        HIPCHK(c, hipEventRecord(c->ev_dcd[k], c->side));
-        if ((r2 = launch_fir(c, C, len, flags, c->side2, t0))) return r2;
-        HIPCHK(c, hipEventRecord(c->ev_fir[k], c->side2));
-        return M17HIP_OK;
-    };
-    for (uint32_t k = 0; k < ahead && k < nseg; ++k)
-        if ((r = launch_front(k))) return r;
+    } else {
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork, 0));
+        c->front_segs = std::min(ahead, nseg);
+        for (uint32_t k = 0; k < c->front_segs; ++k)
+            if ((r = launch_front_seg(c, sp, k, C, flags))) return r;
+    }
+    if (c->defer_decode && !c->defer_llr) {   // the deferred-frame stores exist only where that mode is used (184 B per record slot)
+        HIPCHK(c, hipMalloc((void**)&c->defer_llr, (size_t)c->maxC * c->rec_cap_alloc * 46 * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->defer_hist, (size_t)c->maxC * DEFER_HIST_WORDS * 64 * sizeof(uint32_t)));
+    }
     c->dbg_waves = c->profile ? C : 0;
     // K2 launch: the whole segment from K5's state (first segment), ahead of K5 from K2's own state (later segments, on side3),
     // or the redo of the channels whose K5 dropped the speculation in the previous segment (from K5's state again)
     auto launch_gate = [&](uint32_t k, hipStream_t st, bool ahead, bool redo) -> int {
-        const uint32_t t0 = seg_t0(k), len = seg_t0(k + 1) - t0;
+        const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
         Timed tm(c, KT_GATE, st);
         GateParams G{};
         G.x = c->xbuf + t0; G.xpitch = c->xpitch; G.y = c->ybuf + t0; G.ypitch = c->ypitch; G.h = c->hbuf + t0;
@@ -1003,27 +1233,27 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         return M17HIP_OK;
     };
     for (uint32_t k = 0; k < nseg; ++k) {
-        const uint32_t t0 = seg_t0(k), len = seg_t0(k + 1) - t0;
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fir[k], 0));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dcd[k], 0));
+        const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, ev_fir[k], 0));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, ev_dcd[k], 0));
         if (k == 0 && c->front_first > 1 && ahead >= nseg) {   // the matched filter of the first `front_first` segments has the chip to itself
             const uint32_t last = std::min(c->front_first, nseg) - 1u;
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fir[last], 0));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, ev_fir[last], 0));
         }
         if (c->speculate) {
             if (k == 0) {
                 if ((r = launch_gate(0, c->stream, false, false))) return r;
             } else {
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gate[k], 0));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, ev_gate[k], 0));
                 if ((r = launch_gate(k, c->stream, false, true))) return r;
             }
             if (k + 1 < nseg) {   // the next segment's replay starts from this one's (now final) end state, beside K5
-                HIPCHK(c, hipEventRecord(c->ev_redo[k], c->stream));
-                HIPCHK(c, hipStreamWaitEvent(c->side3, c->ev_redo[k], 0));
-                HIPCHK(c, hipStreamWaitEvent(c->side3, c->ev_fir[k + 1], 0));
-                HIPCHK(c, hipStreamWaitEvent(c->side3, c->ev_dcd[k + 1], 0));
+                HIPCHK(c, hipEventRecord(ev_redo[k], c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->side3, ev_redo[k], 0));
+                HIPCHK(c, hipStreamWaitEvent(c->side3, ev_fir[k + 1], 0));
+                HIPCHK(c, hipStreamWaitEvent(c->side3, ev_dcd[k + 1], 0));
                 if ((r = launch_gate(k + 1, c->side3, true, false))) return r;
-                HIPCHK(c, hipEventRecord(c->ev_gate[k + 1], c->side3));
+                HIPCHK(c, hipEventRecord(ev_gate[k + 1], c->side3));
             }
         }
         Timed tm(c, KT_SEQ);
@@ -1053,8 +1283,8 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         default: hipLaunchKernelGGL(demod_wave_kernel<4>, grid, block, lds, c->stream, P); break;
         }
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(c->ev_seq[k], c->stream));
-        if ((r = launch_front(k + ahead))) return r;
+        HIPCHK(c, hipEventRecord(ev_seq[k], c->stream));
+        if (k + ahead < nseg && (r = launch_front_seg(c, sp, k + ahead, C, flags))) return r;
     }
     HIPCHK(c, hipGetLastError());
     if (c->defer_decode) {   // the payload frames K5 did not decode itself, one lane per frame; then the cost tags K5 left are replaced
@@ -1072,12 +1302,17 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         hipLaunchKernelGGL(packet_asm_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->recs, c->rec_cap, c->rec_count, (PacketState*)c->pkt_state, C,
                            (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count, c->channel_base);
     }
+    // the tails a run that continues in THESE slabs (input uploaded in place) will find as its prefixes; a staged run takes them from
+    // here into the other slab pair itself
     hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
     if (c->speculate) hipLaunchKernelGGL(carry_tail_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->hbuf, c->ypitch, T);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_end[q], c->stream));
+    c->slot_used[q] = true;
     c->pos += T;
-    c->lastC = C; c->lastT = T;
+    c->lastC = C; c->lastT = T; c->runT = T;
     c->have_run = true;
+    c->recs_valid = true;
     return M17HIP_OK;
 }
 
@@ -1111,7 +1346,7 @@ int m17hip_frames_count(m17hip_ctx* c, uint64_t* total)
 {
     if (!c || !total) return M17HIP_EINVAL;
     GUARD(c);
-    if (!c->have_run) return M17HIP_ESTATE;
+    if (!c->recs_valid) return M17HIP_ESTATE;
     return compact_into(c, nullptr, 0, total);
 }
 
@@ -1119,7 +1354,7 @@ int m17hip_frames_compact_device(m17hip_ctx* c, m17_frame_rec* recs_dev, uint64_
 {
     if (!c || !recs_dev) return M17HIP_EINVAL;
     GUARD(c);
-    if (!c->have_run) return M17HIP_ESTATE;
+    if (!c->recs_valid) return M17HIP_ESTATE;
     return compact_into(c, (FrameRec*)recs_dev, capacity, count);
 }
 
@@ -1127,7 +1362,7 @@ int m17hip_frames_fetch(m17hip_ctx* c, m17_frame_rec* recs_host, uint64_t capaci
 {
     if (!c || !recs_host) return M17HIP_EINVAL;
     GUARD(c);
-    if (!c->have_run) return M17HIP_ESTATE;
+    if (!c->recs_valid) return M17HIP_ESTATE;
     // one compaction into the context's dense buffer; it is sized for the caller's capacity (records beyond it are not
     // wanted anyway), so a second pass is never needed
     const uint64_t want = std::max<uint64_t>(std::min<uint64_t>(capacity, (uint64_t)c->lastC * c->rec_cap), 1024);
@@ -1160,7 +1395,7 @@ int m17hip_diag_log_fetch(m17hip_ctx* c, m17_diag* log_host, uint32_t* counts_ho
 {
     if (!c || !log_host || !counts_host || C == 0 || C > c->maxC || capacity == 0) return M17HIP_EINVAL;
     GUARD(c);
-    if (!c->diag_cap || !c->have_run) return M17HIP_ESTATE;
+    if (!c->diag_cap || !c->recs_valid) return M17HIP_ESTATE;
     HIPCHK(c, hipMemcpyAsync(counts_host, c->diag_count, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
     const uint32_t n = std::min(capacity, c->diag_cap);
     HIPCHK(c, hipMemcpy2DAsync(log_host, (size_t)capacity * sizeof(Diag), c->diag_log, (size_t)c->diag_cap * sizeof(Diag), (size_t)n * sizeof(Diag), C,
@@ -1311,7 +1546,7 @@ int m17hip_comm_create(m17hip_ctx* c, const void* id128, int rank, int nranks, m
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     const ncclResult_t r = R.CommInitRank(&m->comm, nranks, id, rank);
-    if (r != ncclSuccess) { m->last_rccl = (int)r; delete m; return M17HIP_ECOMM; }
+    if (r != ncclSuccess) { c->last_hip = 0x10000 | (int)r; delete m; return M17HIP_ECOMM; }   // (no communicator to ask: the ncclResult_t is left in m17hip_last_hip_error, | 0x10000)
     const hipError_t e = hipMalloc((void**)&m->counts_dev, (size_t)nranks * sizeof(uint64_t));
     if (e != hipSuccess) { c->last_hip = (int)e; R.CommDestroy(m->comm); delete m; return M17HIP_ENOMEM; }
     *out = m;
@@ -1336,49 +1571,77 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
 {
     if (!c || !m || m->device != c->device || root < 0 || root >= m->nranks || (m->rank == root && capacity && !recs_host)) return M17HIP_EINVAL;
     GUARD(c);
-    if (!c->have_run) return M17HIP_ESTATE;
     const Rccl& R = rccl();
-    // 1. this rank's records, dense and (channel, seq)-ordered, in the context's compaction buffer
+    // 1. this rank's records, dense and (channel, seq)-ordered, in the context's compaction buffer.  Whatever goes wrong on THIS rank
+    //    from here on is carried through the collective as a status word (every rank makes the same calls and returns together): a
+    //    rank that left early would leave the others waiting in the all-gather.
     uint64_t mine = 0;
-    int r = compact_into(c, c->compact, c->compact_cap, &mine);
-    if (r == M17HIP_ETRUNC || (r == M17HIP_OK && !c->compact && mine)) {
-        if (c->compact) hipFree(c->compact);
-        c->compact = nullptr; c->compact_cap = 0;
-        const uint64_t want = std::max<uint64_t>(mine + mine / 8, 1024);
-        HIPCHK(c, hipMalloc((void**)&c->compact, (size_t)want * sizeof(FrameRec)));
-        c->compact_cap = want;
-        r = compact_into(c, c->compact, c->compact_cap, &mine);
+    int local = c->recs_valid ? M17HIP_OK : M17HIP_ESTATE;
+    bool overflow = false;
+    if (local == M17HIP_OK) {
+        int r = compact_into(c, c->compact, c->compact_cap, &mine);
+        // the dense buffer must hold ALL of this rank's records before anything is sent from it, whatever the first pass said
+        // (an overflowed run reports EOVERFLOW before the truncation is looked at)
+        if ((r == M17HIP_OK || r == M17HIP_ETRUNC || r == M17HIP_EOVERFLOW) && mine > c->compact_cap) {
+            if (c->compact) hipFree(c->compact);
+            c->compact = nullptr; c->compact_cap = 0;
+            const uint64_t want = std::max<uint64_t>(mine + mine / 8, 1024);
+            const hipError_t e = hipMalloc((void**)&c->compact, (size_t)want * sizeof(FrameRec));
+            if (e != hipSuccess) { c->last_hip = (int)e; r = e == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP; }
+            else { c->compact_cap = want; r = compact_into(c, c->compact, c->compact_cap, &mine); }
+        }
+        overflow = r == M17HIP_EOVERFLOW;
+        if (r && !overflow) { local = r; mine = 0; }
     }
-    const bool overflow = r == M17HIP_EOVERFLOW;
-    if (r && !overflow) return r;
-    // 2. every rank learns every rank's count
+    // 2. every rank learns every rank's count and status: word = count | (error code, negated) << 56
 #define RCCLCHK(expr) do { const ncclResult_t q_ = (expr); if (q_ != ncclSuccess) { m->last_rccl = (int)q_; return M17HIP_ECOMM; } } while (0)
-    std::vector<uint64_t> counts((size_t)m->nranks, 0);
-    HIPCHK(c, hipMemcpyAsync(m->counts_dev + m->rank, &mine, 8, hipMemcpyHostToDevice, c->stream));
+    std::vector<uint64_t> words((size_t)m->nranks, 0);
+    const uint64_t word = (mine & 0x00FFFFFFFFFFFFFFull) | ((uint64_t)(uint8_t)(-local) << 56);
+    HIPCHK(c, hipMemcpyAsync(m->counts_dev + m->rank, &word, 8, hipMemcpyHostToDevice, c->stream));
     RCCLCHK(R.AllGather(m->counts_dev + m->rank, m->counts_dev, 1, ncclUint64, m->comm, c->stream));
-    HIPCHK(c, hipMemcpyAsync(counts.data(), m->counts_dev, (size_t)m->nranks * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(words.data(), m->counts_dev, (size_t)m->nranks * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> counts((size_t)m->nranks, 0);
     uint64_t total = 0;
-    for (uint64_t v : counts) total += v;
+    int remote = M17HIP_OK;
+    for (int k = 0; k < m->nranks; ++k) {
+        counts[k] = words[k] & 0x00FFFFFFFFFFFFFFull;
+        total += counts[k];
+        const int code = -(int)(words[k] >> 56);
+        if (code && !remote) remote = code;
+    }
     if (counts_host) std::memcpy(counts_host, counts.data(), counts.size() * 8);
     if (total_out) *total_out = total;
+    if (local) return local;
+    if (remote) return M17HIP_ECOMM;   // some other rank could not deliver its records: nobody sends, everybody returns
     // 3. the records travel to the root with their exact sizes, rank after rank = global channel order
+    int rc = M17HIP_OK;
     if (m->rank == root) {
         if (total > m->gathered_cap) {
             if (m->gathered) hipFree(m->gathered);
             m->gathered = nullptr; m->gathered_cap = 0;
             const uint64_t want = std::max<uint64_t>(total + total / 8, 1024);
-            HIPCHK(c, hipMalloc((void**)&m->gathered, (size_t)want * sizeof(FrameRec)));
-            m->gathered_cap = want;
+            const hipError_t e = hipMalloc((void**)&m->gathered, (size_t)want * sizeof(FrameRec));
+            if (e != hipSuccess) { c->last_hip = (int)e; rc = e == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP; }
+            else m->gathered_cap = want;
         }
-        RCCLCHK(R.GroupStart());
+        if (rc) return rc;   // (no room for the gathered set on the root: the other ranks' sends stay unmatched — fatal for the communicator)
+        ncclResult_t q = R.GroupStart();
         uint64_t off = 0;
-        for (int k = 0; k < m->nranks; ++k) {
-            if (k != root && counts[k]) RCCLCHK(R.Recv(m->gathered + off, (size_t)counts[k] * sizeof(FrameRec), ncclUint8, k, m->comm, c->stream));
-            if (k == root && mine) HIPCHK(c, hipMemcpyAsync(m->gathered + off, c->compact, (size_t)mine * sizeof(FrameRec), hipMemcpyDeviceToDevice, c->stream));
+        hipError_t he = hipSuccess;
+        for (int k = 0; k < m->nranks && q == ncclSuccess; ++k) {
+            if (k != root && counts[k]) q = R.Recv(m->gathered + off, (size_t)counts[k] * sizeof(FrameRec), ncclUint8, k, m->comm, c->stream);
             off += counts[k];
         }
-        RCCLCHK(R.GroupEnd());
+        const ncclResult_t qe = R.GroupEnd();   // the group is closed whatever happened inside it
+        if (q == ncclSuccess) q = qe;
+        if (q != ncclSuccess) { m->last_rccl = (int)q; return M17HIP_ECOMM; }
+        off = 0;
+        for (int k = 0; k < m->nranks; ++k) {   // the root's own share: a plain copy, outside the group
+            if (k == root && mine) he = hipMemcpyAsync(m->gathered + off, c->compact, (size_t)mine * sizeof(FrameRec), hipMemcpyDeviceToDevice, c->stream);
+            off += counts[k];
+        }
+        if (he != hipSuccess) { c->last_hip = (int)he; return M17HIP_EHIP; }
         const uint64_t n = std::min(total, capacity);
         if (n) HIPCHK(c, hipMemcpyAsync(recs_host, m->gathered, (size_t)n * sizeof(FrameRec), dest_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1386,9 +1649,11 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
         return total > capacity ? M17HIP_ETRUNC : M17HIP_OK;
     }
     if (mine) {
-        RCCLCHK(R.GroupStart());
-        RCCLCHK(R.Send(c->compact, (size_t)mine * sizeof(FrameRec), ncclUint8, root, m->comm, c->stream));
-        RCCLCHK(R.GroupEnd());
+        ncclResult_t q = R.GroupStart();
+        if (q == ncclSuccess) q = R.Send(c->compact, (size_t)mine * sizeof(FrameRec), ncclUint8, root, m->comm, c->stream);
+        const ncclResult_t qe = R.GroupEnd();
+        if (q == ncclSuccess) q = qe;
+        if (q != ncclSuccess) { m->last_rccl = (int)q; return M17HIP_ECOMM; }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
 #undef RCCLCHK
@@ -1410,6 +1675,7 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
 {
     if (!c) return M17HIP_EINVAL;
     GUARD(c);
+    if (c->front_pending) return M17HIP_ESTATE;
     switch (key) {
     case 0:  // waves (= channels) per workgroup of the sequential kernel: 0 (default 4), 1, 2, 4 or 8
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return M17HIP_EINVAL;
@@ -1465,6 +1731,11 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     }
     case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1, default), or in K5 (0)
         c->defer_decode = value != 0;
+        if (!c->defer_decode && c->defer_llr) {   // give the stores back (a run in flight may still use them: wait for it)
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->defer_llr); hipFree(c->defer_hist);
+            c->defer_llr = nullptr; c->defer_hist = nullptr;
+        }
         return M17HIP_OK;
     case 14:  // LDS bytes per workgroup of the sequential kernel (at least its need: decides how many of them share a CU), 0 = default
         if (value < 0 || value > 65536) return M17HIP_EINVAL;
@@ -1492,6 +1763,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 8:  // record slots per channel and run actually used (0 = all that were allocated): exercises M17HIP_EOVERFLOW
         if (value < 0 || value > (int64_t)c->rec_cap_alloc) return M17HIP_EINVAL;
         c->rec_cap = value ? (uint32_t)value : c->rec_cap_alloc;
+        c->recs_valid = false;   // the slots of the last run were written with the old stride: nothing to fetch until the next run
+        return M17HIP_OK;
+    case 16:  // the in-place producers (m17hip_upload_i16, m17hip_upload_i16_device, m17hip_synth_i16) write the STAGING slab instead
+        c->stage_inputs = value != 0;
         return M17HIP_OK;
     case 4:  // samples of the first segment of a run (0 = like the others)
         if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;

@@ -17,6 +17,7 @@ class BatchedDemodulator
 {
     m17hip_ctx* ctx_ = nullptr;
     uint32_t channels_ = 0, samples_ = 0, room_ = 0, diag_room_ = 0;
+    uint64_t last_frames_ = 0;
 
     static void check(int code, const char* what)
     {
@@ -43,16 +44,31 @@ public:
     void reset() { check(m17hip_demod_reset(ctx_), "m17hip_demod_reset"); }
     void run(uint32_t flags = 0) { check(m17hip_demod_run(ctx_, channels_, samples_, flags), "m17hip_demod_run"); }
 
+    // records of the last run, ordered by (channel, seq): one compaction and one synchronisation when the guessed capacity suffices
+    // (M17HIP_ETRUNC reports the real count; the fetch is then repeated once)
     std::vector<m17_frame_rec> frames()
     {
-        uint64_t n = 0;
-        check(m17hip_frames_count(ctx_, &n), "m17hip_frames_count");
-        std::vector<m17_frame_rec> out(n ? n : 1);
+        std::vector<m17_frame_rec> out(last_frames_ + last_frames_ / 4 + 1024);
         uint64_t got = 0;
-        check(m17hip_frames_fetch(ctx_, out.data(), out.size(), &got), "m17hip_frames_fetch");
+        int code = m17hip_frames_fetch(ctx_, out.data(), out.size(), &got);
+        if (code == M17HIP_ETRUNC && got > out.size()) {
+            out.resize(got);
+            code = m17hip_frames_fetch(ctx_, out.data(), out.size(), &got);
+        }
+        check(code, "m17hip_frames_fetch");
         out.resize(got);
+        last_frames_ = got;
         return out;
     }
+    // Streaming (include/m17hip.h, m17hip_demod_front): stage the next run's input from pinned host memory while the current run
+    // computes, start its front end beside the current run's state-machine half, collect the current run's frames(), then run().
+    void stage(const int16_t* pinned_host, uint32_t channels, uint32_t samples, size_t pitch)
+    {
+        check(m17hip_upload_i16_async(ctx_, pinned_host, channels, samples, pitch), "m17hip_upload_i16_async");
+        channels_ = channels; samples_ = samples;
+    }
+    void front(uint32_t flags = 0) { check(m17hip_demod_front(ctx_, channels_, samples_, flags), "m17hip_demod_front"); }
+    void stage_wait() { check(m17hip_upload_wait(ctx_), "m17hip_upload_wait"); }
     // BERT statistics per channel (apps/m17-demod.cpp:286-304 + PRBS9): counted over the runs made after enable_bert(true)
     void enable_bert(bool on) { check(m17hip_tune(ctx_, 6, on ? 1 : 0), "m17hip_tune"); }
     std::vector<m17_bert_stat> bert_stats()

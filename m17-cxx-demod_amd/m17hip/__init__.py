@@ -39,6 +39,7 @@ EXPORTS = [
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_packets_fetch", "m17hip_packets_feed", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
     "m17hip_set_kalman_order", "m17hip_kalman_trace", "m17hip_set_channel_base", "m17hip_upload_wait", "m17hip_comm_get_id", "m17hip_comm_create",
     "m17hip_comm_destroy", "m17hip_comm_last_error", "m17hip_gather_frames", "m17hip_gather_frames_device", "m17hip_diag_log_fetch",
+    "m17hip_upload_i16_device_async", "m17hip_input_alternate", "m17hip_demod_front",
 ]
 ETRUNC = -6
 COMM_ID_BYTES = 128
@@ -136,6 +137,21 @@ class Context:
         self.C, self.T = int(channels), int(samples)
         self._chk(self.lib.m17hip_upload_i16_async(self.h, C.c_void_p(int(host_ptr)), C.c_uint32(self.C), C.c_uint32(self.T),
                                                    C.c_size_t(self.T if pitch is None else pitch)))
+
+    def upload_device_async(self, dev_ptr, channels, samples, pitch=None):
+        """Stage the input of the NEXT run from device memory at `dev_ptr` (kept alive and unmodified by the caller until upload_wait)."""
+        self.C, self.T = int(channels), int(samples)
+        self._chk(self.lib.m17hip_upload_i16_device_async(self.h, C.c_void_p(int(dev_ptr)), C.c_uint32(self.C), C.c_uint32(self.T),
+                                                          C.c_size_t(self.T if pitch is None else pitch)))
+
+    def input_alternate(self, channels=None, samples=None):
+        """Stage, without a copy, the input the context's second slab still holds (two resident slabs that alternate)."""
+        self._chk(self.lib.m17hip_input_alternate(self.h, C.c_uint32(channels or self.C), C.c_uint32(samples or self.T)))
+
+    def front(self, flags=0, channels=None, samples=None):
+        """Queue the front end (matched filter, carrier-detect sums) of the STAGED run now, beside the latest run's state-machine half;
+        the run() that follows (same arguments) queues the rest."""
+        self._chk(self.lib.m17hip_demod_front(self.h, C.c_uint32(channels or self.C), C.c_uint32(samples or self.T), C.c_uint32(flags)))
 
     def upload_wait(self):
         """Block until the copy queued by upload_async has left the host buffer."""
@@ -266,11 +282,19 @@ class Context:
         return n.value
 
     def frames(self):
-        n = self.frames_count()
-        recs = np.zeros(max(n, 1), dtype=FRAME_REC)
-        got = C.c_uint64(0)
-        self._chk(self.lib.m17hip_frames_fetch(self.h, _ptr(recs), C.c_uint64(recs.size), C.byref(got)))
-        return recs[: got.value]
+        """Records of the last run, ordered by (channel, seq).  One compaction and one synchronisation when the guessed capacity (the
+        previous fetch's count plus a margin) suffices; M17HIP_ETRUNC reports the real count and the fetch is repeated once."""
+        cap = max(1024, getattr(self, "_last_frames", 0) * 5 // 4 + 64)
+        while True:
+            recs = np.zeros(cap, dtype=FRAME_REC)
+            got = C.c_uint64(0)
+            code = self.lib.m17hip_frames_fetch(self.h, _ptr(recs), C.c_uint64(recs.size), C.byref(got))
+            if code == ETRUNC and got.value > cap:
+                cap = int(got.value)
+                continue
+            self._chk(code)
+            self._last_frames = int(got.value)
+            return recs[: got.value]
 
     def frames_compact_device(self, dev_ptr, capacity):
         n = C.c_uint64(0)

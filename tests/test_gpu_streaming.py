@@ -1,0 +1,250 @@
+"""GPU tests of the streaming pipeline (include/m17hip.h m17hip_demod_front): consecutive runs of the SAME channels,
+state carried, with the front end (matched filter, carrier-detect sums) of run k + 1 queued while the state-machine half of run k is
+still at work.  The reference's use is one endless stream per channel (apps/m17-demod.cpp:484-490): whatever the chunking and
+however the chunks are staged, the frame records must be those of the oracle over the whole stream, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import m17hip
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+ESTATE, EINVAL = -4, -1
+
+
+def _signals(Cn, T, seed=77, sigma=500.0, kind=-1, lead_in=3072, n_frames=None, tail_sigma=None):
+    p = ol.gen_params(seed=seed, kind=kind, n_frames=max(1, T // 1920 - 4) if n_frames is None else n_frames, lead_in=lead_in, noise_sigma=sigma,
+                      tail_sigma=sigma if tail_sigma is None else tail_sigma, lead_sigma=40000.0, total=T)
+    return ol.generate_batch(p, Cn, T, threads=8)
+
+
+def _oracle(x):
+    recs, counts, diags = ol.demod_batch(x, cap=2 * (x.shape[1] // 1920 + 2) + 4, threads=8)
+    flat = np.concatenate([recs[c, : counts[c]] for c in range(x.shape[0])]) if counts.sum() else recs[0, :0]
+    return flat, diags
+
+
+def _sorted(parts):
+    got = np.concatenate(parts)
+    return got[np.lexsort((got["seq"], got["channel"]))]
+
+
+@pytest.fixture(scope="module", params=[{}, {2: 0}, {10: 1, 15: 0}, {3: 7001}], ids=["default", "limit_inline", "k3_pipeline_decode_in_k5", "seg7001"])
+def ctx(request):
+    c = m17hip.Context(64, 48000)
+    for k, v in request.param.items():
+        c.tune(k, v)
+    yield c
+    c.close()
+
+
+def _pipelined(ctx, Cn, lengths, stage):
+    """The call sequence of a live feed: stage(k + 1), front(k + 1), fetch run k, run(k + 1)."""
+    ctx.reset()
+    stage(0)
+    ctx.run(channels=Cn, samples=lengths[0])
+    parts = []
+    for k in range(len(lengths)):
+        if k + 1 < len(lengths):
+            stage(k + 1)
+            ctx.front(channels=Cn, samples=lengths[k + 1])
+        parts.append(ctx.frames().copy())          # still run k's records: the front end touches none of them
+        if k + 1 < len(lengths):
+            ctx.run(channels=Cn, samples=lengths[k + 1])
+    return _sorted(parts)
+
+
+def _check_diag(ctx, Cn, diags):
+    d = ctx.diag(Cn)
+    for f in ("dcd", "locked", "sample_index", "viterbi_cost", "n_diag", "demod_state", "n_frames", "evm", "deviation", "offset", "clock"):
+        assert np.array_equal(d[f], diags[f], equal_nan=True), f
+
+
+def test_pipelined_runs_from_pinned_host_memory(ctx):
+    import torch
+    Cn, T, n = 64, 24000, 5
+    x = _signals(Cn, n * T, seed=101, sigma=600.0)
+    exp, diags = _oracle(x)
+    pinned = [torch.from_numpy(np.ascontiguousarray(x[:, k * T:(k + 1) * T])).pin_memory() for k in range(n)]
+    got = _pipelined(ctx, Cn, [T] * n, lambda k: ctx.upload_async(pinned[k].data_ptr(), Cn, T))
+    assert got.tobytes() == exp.tobytes() and got.size > 3 * Cn
+    _check_diag(ctx, Cn, diags)
+
+
+def test_pipelined_runs_from_device_memory(ctx):
+    """m17hip_upload_i16_device_async: the chunks are handed over by a producer on the GPU (pitch > samples: a view into its buffer)."""
+    import torch
+    Cn, T, n = 48, 19200, 6
+    x = _signals(Cn, n * T, seed=102, sigma=800.0)
+    exp, diags = _oracle(x)
+    dev = torch.from_numpy(x).cuda()               # [Cn][n * T]: chunk k = columns [k T, (k + 1) T), row pitch n * T
+    got = _pipelined(ctx, Cn, [T] * n, lambda k: ctx.upload_device_async(dev.data_ptr() + 2 * k * T, Cn, T, pitch=n * T))
+    ctx.upload_wait()
+    assert got.tobytes() == exp.tobytes() and got.size > 3 * Cn
+    _check_diag(ctx, Cn, diags)
+
+
+def test_two_resident_slabs_alternate_without_copies(ctx):
+    """m17hip_input_alternate: slab A, slab B, A, B, ... — the regime of bench.py's single-stream leg.  The stream the channels see
+    is A B A B A B; the oracle demodulates exactly that."""
+    import torch
+    Cn, T = 32, 48000
+    a = _signals(Cn, T, seed=103, sigma=600.0)
+    b = _signals(Cn, T, seed=104, sigma=900.0, kind=1)
+    exp, diags = _oracle(np.concatenate([a, b, a, b, a, b], axis=1))
+    pb = torch.from_numpy(b).pin_memory()
+
+    def stage(k):
+        if k == 0:
+            ctx.upload(a)                          # in place: slab pair 0 ...
+            return
+        if k == 1:
+            ctx.upload_async(pb.data_ptr(), Cn, T)  # ... slab pair 1 ...
+            return
+        ctx.input_alternate(Cn, T)                 # ... and from then on no copy at all
+
+    ctx.reset()
+    ctx.upload(a)
+    ctx.run()
+    parts = []
+    for k in range(6):
+        if k + 1 < 6:
+            stage(k + 1)
+            ctx.front(channels=Cn, samples=T)
+        parts.append(ctx.frames().copy())
+        if k + 1 < 6:
+            ctx.run(channels=Cn, samples=T)
+    got = _sorted(parts)
+    assert got.tobytes() == exp.tobytes() and got.size > 6 * Cn
+    _check_diag(ctx, Cn, diags)
+
+
+def test_pipelined_ragged_chunks_and_mixed_staging(ctx):
+    """Chunks shorter than the carried prefixes (152 input samples, 96 filter outputs), not multiples of 8 / 192 / 1920, staged runs
+    with and without m17hip_demod_front and in-place runs in between."""
+    import torch
+    Cn, T = 32, 40000
+    x = _signals(Cn, T, seed=105, sigma=700.0)
+    exp, diags = _oracle(x)
+    ctx.reset()
+    parts, pos, keep = [], 0, []
+    for i, n in enumerate((1, 7, 95, 149, 153, 1919, 3841, 9601, 5000, 333, 12345, T)):
+        n = min(n, T - pos)
+        if n <= 0:
+            break
+        chunk = np.ascontiguousarray(x[:, pos: pos + n])
+        mode = i % 3
+        if mode == 0:                              # in place
+            ctx.upload(chunk)
+            ctx.run()
+        else:
+            pin = torch.from_numpy(chunk).pin_memory()
+            keep.append(pin)
+            ctx.upload_async(pin.data_ptr(), Cn, n)
+            if mode == 1:
+                ctx.front(channels=Cn, samples=n)
+            ctx.run(channels=Cn, samples=n)
+        parts.append(ctx.frames().copy())
+        pos += n
+    assert pos == T
+    ctx.upload_wait()
+    got = _sorted(parts)
+    assert got.tobytes() == exp.tobytes()
+    _check_diag(ctx, Cn, diags)
+
+
+def test_pipelined_lost_sync_across_run_boundaries(ctx):
+    """Bursts followed by loud noise: sync is lost, dcd.unlock() is forced (K2's speculation is dropped), the gated FIR restarts —
+    with run boundaries falling anywhere in that."""
+    import torch
+    Cn, T, n = 32, 9600, 10
+    x = _signals(Cn, n * T, seed=106, sigma=500.0, n_frames=14, tail_sigma=3000.0)
+    exp, diags = _oracle(x)
+    pinned = [torch.from_numpy(np.ascontiguousarray(x[:, k * T:(k + 1) * T])).pin_memory() for k in range(n)]
+    got = _pipelined(ctx, Cn, [T] * n, lambda k: ctx.upload_async(pinned[k].data_ptr(), Cn, T))
+    assert got.tobytes() == exp.tobytes() and got.size > Cn
+    _check_diag(ctx, Cn, diags)
+
+
+def test_front_call_sequence_errors():
+    import torch
+    Cn, T = 8, 9600
+    x = _signals(Cn, 3 * T, seed=107)
+    exp, _ = _oracle(x)
+    c = m17hip.Context(Cn, T)
+    lib, h = c.lib, c.h
+    front = lambda C_, T_, fl=0: lib.m17hip_demod_front(h, C.c_uint32(C_), C.c_uint32(T_), C.c_uint32(fl))  # noqa: E731
+    run = lambda C_, T_, fl=0: lib.m17hip_demod_run(h, C.c_uint32(C_), C.c_uint32(T_), C.c_uint32(fl))      # noqa: E731
+    assert front(Cn, T) == ESTATE                                   # nothing staged
+    assert lib.m17hip_input_alternate(h, C.c_uint32(Cn), C.c_uint32(T)) == ESTATE   # no second slab yet
+    pins = [torch.from_numpy(np.ascontiguousarray(x[:, k * T:(k + 1) * T])).pin_memory() for k in range(3)]
+    c.reset()
+    c.upload_async(pins[0].data_ptr(), Cn, T)
+    assert front(Cn, T // 2) == EINVAL                              # not the staged shape
+    assert front(Cn, T, 2) == EINVAL                                # unknown flag
+    assert front(Cn, T) == 0
+    assert front(Cn, T) == ESTATE                                   # already queued
+    assert lib.m17hip_upload_i16_async(h, C.c_void_p(pins[1].data_ptr()), C.c_uint32(Cn), C.c_uint32(T), C.c_size_t(T)) == ESTATE
+    assert lib.m17hip_upload_i16(h, C.c_void_p(pins[1].data_ptr()), C.c_uint32(Cn), C.c_uint32(T), C.c_size_t(T)) == ESTATE
+    assert lib.m17hip_fir_rrc150(h, C.c_uint32(Cn), C.c_uint32(T), C.c_uint32(0), None) == ESTATE
+    assert lib.m17hip_tune(h, C.c_int(3), C.c_int64(4800)) == ESTATE
+    assert run(Cn, T, 1) == ESTATE and run(Cn, T // 2) == ESTATE     # the run must be the one the front end was queued for
+    assert run(Cn, T) == 0
+    parts = [c.frames().copy()]
+    # a reset abandons a queued front end; the stream then starts over and must decode as a fresh one
+    c.upload_async(pins[1].data_ptr(), Cn, T)
+    assert front(Cn, T) == 0
+    c.reset()
+    parts = []
+    for k in range(3):
+        c.upload_async(pins[k].data_ptr(), Cn, T)
+        c.run(channels=Cn, samples=T)
+        parts.append(c.frames().copy())
+    c.upload_wait()
+    assert _sorted(parts).tobytes() == exp.tobytes()
+    c.close()
+
+
+def test_pipelined_full_size_run_properties():
+    """At bench size per channel (480 000 samples, ten segments per run) on 256 channels: three pipelined runs over alternating resident
+    slabs == the same three runs made one after the other in a second context (records and diagnostics), and the first 8 channels
+    == the oracle."""
+    Cn, T = 256, 480000
+    p = ol.gen_params(seed=20260101, kind=-1, n_frames=T // 1920 - 6, lead_in=3072, noise_sigma=600.0, tail_sigma=600.0, lead_sigma=40000.0, total=T)
+    a, b = m17hip.Context(Cn, T), m17hip.Context(Cn, T)
+    import torch
+    for c_ in (a, b):
+        c_.synth(p, Cn, T)
+    x = a.download()
+    # reference order: in place, one run after the other
+    b.reset()
+    seq_parts = []
+    for k in range(3):
+        b.run()
+        seq_parts.append(b.frames().copy())
+    # pipelined: the same slab in both slab pairs
+    pin = torch.from_numpy(x).pin_memory()
+    a.reset()
+    a.run()
+    parts = []
+    for k in range(3):
+        if k + 1 < 3:
+            if k == 0:
+                a.upload_async(pin.data_ptr(), Cn, T)
+            else:
+                a.input_alternate(Cn, T)
+            a.front(channels=Cn, samples=T)
+        parts.append(a.frames().copy())
+        if k + 1 < 3:
+            a.run(channels=Cn, samples=T)
+    a.upload_wait()
+    for k in range(3):
+        assert parts[k].tobytes() == seq_parts[k].tobytes(), k
+    assert a.diag(Cn).tobytes() == b.diag(Cn).tobytes()
+    exp, _ = _oracle(np.tile(x[:8], (1, 3)))
+    got = _sorted(parts)
+    assert got[got["channel"] < 8].tobytes() == exp.tobytes()
+    a.close(); b.close()

@@ -14,6 +14,10 @@ class _LazyRef:
     """The reference-header shim, bound at first use: collecting this module (e.g. under -m gpu) must not load it."""
 
     def __getattr__(self, name):
+        # pytest's collection probes every module global for attributes such as `_pytestfixturefunction`, `__wrapped__`, `pytestmark`:
+        # none of those may bind the library (round-2 VERDICT: it was mapped into the -m gpu process that way)
+        if not (name.startswith("ref_") or name.startswith("m17")):
+            raise AttributeError(name)
         return getattr(ol.ref(), name)
 
 
