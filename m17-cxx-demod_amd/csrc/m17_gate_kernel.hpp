@@ -86,6 +86,9 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         if (!__ballot(valid)) return;   // nothing to redo for these four channels
     }
     const bool invert = P.flags & 1u;
+    // flags bit 1: a replay whose history values nobody will read (the channels K5 serves itself, m17_wave_kernel.hpp): only the
+    // replay's end state is wanted, hbuf is left alone (K5 is writing those very rows)
+    const bool store = !(P.flags & 2u);
     const SeqState* gs = P.state + c;
     const int16_t* xr = P.x + (size_t)c * P.xpitch + XPRE;
     const float* yr = P.y + (size_t)c * P.ypitch + YPRE;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
     // Started from K5's state: the three slots in front of the segment get the history it starts with.  (What is there is the
     // previous segment's or run's tail, which is void if K5 had dropped the speculation there; a replay that continues from its own
     // state finds its own output there.)
-    if (!P.chain_in && r == 0 && valid) { hr[-1] = h0; hr[-2] = h1; hr[-3] = h2; }
+    if (!P.chain_in && r == 0 && valid && store) { hr[-1] = h0; hr[-2] = h1; hr[-3] = h2; }
     bool pl_valid = false;     // pl[g] holds the patched outputs of the current run
     int32_t pl_rs = 0;         // relative index of that run's first sample
 
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
                 lds_sync();
                 if (r == 0) iir_tick();
                 lds_sync();
-                if (valid) store_tick();
+                if (valid && store) store_tick();
                 lds_sync();
                 count += TICK;
                 t += TICK;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
                 }
             }
             lds_sync();
-            if (feed && valid) {
+            if (feed && valid && store) {
                 if (fast) {
                     store_tick();
                 } else {
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
                     on = 1;
                     run_pos = 0;
                     pl_valid = false;
-                    if (r == 0 && valid) {   // the history the run inherits, where its first samples will look for it
+                    if (r == 0 && valid && store) {   // the history the run inherits, where its first samples will look for it
                         hr[(int64_t)te] = h0; hr[(int64_t)te - 1] = h1; hr[(int64_t)te - 2] = h2;
                     }
                 }

@@ -121,7 +121,8 @@ struct SeqParams {
     unsigned long long* dbg;  // optional [channels][24] counters (diagnostics)
     const float* h;           // K2's limit-filter history, pitch ypitch (nullptr: no speculation, K5 runs the filter itself)
     const float* final_h;     // [C][4] K2's filter history after the last fed sample of the run
-    uint32_t* dropped;        // [C] out: this segment dropped the speculation (K2 must redo the channel's next segment from K5's state)
+    uint32_t* dropped;        // [C] out: this segment left K2's replay (K2 redoes the replay's state from K5's; K5 serves itself meanwhile)
+    const uint32_t* dropped_in;   // [C] the same flags of the PREVIOUS segment (nullptr: first segment of a run): set = hbuf holds nothing for this channel
     Diag* diag_log;           // optional [C][diag_cap]: one entry per diagnostic callback of the run (m17hip_tune key 9), else nullptr
     uint32_t diag_cap;
     uint32_t* diag_count;     // [C] entries written this run

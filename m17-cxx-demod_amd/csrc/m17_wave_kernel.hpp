@@ -62,9 +62,73 @@ __device__ __forceinline__ uint2 nf_decode_wave(const DecodeTables* tb, DecodeLd
     return make_uint2(cost, D.state);
 }
 
+// Correlator::sample x (to - from) for ONE channel as a tight pass (Correlator.h:43-49, IirFilter.h:26-42): the limit filter's
+// history after every sample of [from, to) goes to the channel's hbuf row, exactly where K2 would have left it.  Used by a wave whose
+// gate has left K2's replay (a forced dcd.unlock(), M17Demodulator.h:396-404, 470-478 ...): instead of carrying the recurrence sample
+// by sample through every chunk of the state machine, the wave serves itself one stretch of certainly-fed samples at a time and
+// then runs its usual hbuf-reading paths over it.  256-sample blocks staged in LDS (B, replaced in place by the history values),
+// the next block's loads in flight during the recurrence.  h[3] = history after sample from - 1 on entry, after to - 1 on exit.
+struct Hist3 { float h0, h1, h2; };
+typedef float m17_v4f __attribute__((ext_vector_type(4)));
+__device__ __noinline__ Hist3 nf_serve_limit(const float* yr, float* hr, M17_LDS float* B, uint32_t from, uint32_t to, float h0, float h1, float h2)
+{
+    const uint32_t l = threadIdx.x & 63u;
+#ifdef M17_V5
+    {   // simplest form (debugging): every lane runs the chain from global memory, lane 0 stores
+        float m2s = IirCoef::a2 * h1;
+        for (uint32_t i = from; i < to; ++i) {
+            const float hn = iir_advance_pk(fabsf(yr[i]), h0, m2s);
+            h2 = h1; h1 = h0; h0 = hn;
+            if (l == 0) hr[i] = hn;
+        }
+#ifdef M17_V6
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+#else
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#endif
+        return Hist3{h0, h1, h2};
+    }
+#endif
+    float nx[4];
+    auto load = [&](uint32_t b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t i = b + l + 64u * j; nx[j] = i < to ? yr[i] : 0.f; }
+    };
+    load(from);
+    float m2 = IirCoef::a2 * h1;
+    for (uint32_t b = from; b < to; b += 256u) {
+        const uint32_t n = min(256u, to - b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) B[l + 64u * j] = nx[j];
+        wave_lds_sync();
+        if (b + 256u < to) load(b + 256u);
+        uint32_t i = 0;
+        for (; i + 4 <= n; i += 4) {
+            const m17_v4f v = *reinterpret_cast<const M17_LDS m17_v4f*>(B + i);
+            m17_v4f o;
+            o.x = iir_advance_pk(fabsf(v.x), h0, m2); h2 = h1; h1 = h0; h0 = o.x;
+            o.y = iir_advance_pk(fabsf(v.y), h0, m2); h2 = h1; h1 = h0; h0 = o.y;
+            o.z = iir_advance_pk(fabsf(v.z), h0, m2); h2 = h1; h1 = h0; h0 = o.z;
+            o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
+            *reinterpret_cast<M17_LDS m17_v4f*>(B + i) = o;
+        }
+        for (; i < n; ++i) {
+            const float hn = iir_advance_pk(fabsf(B[i]), h0, m2);
+            h2 = h1; h1 = h0; h0 = hn;
+            B[i] = hn;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t i2 = l + 64u * j; if (i2 < n) hr[b + i2] = B[i2]; }
+        wave_lds_sync();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the history values are read back by this wave (other lanes, later loads)
+    return Hist3{h0, h1, h2};
+}
+
 // PROF: compile the 100 MHz section timers and counters in (diagnostics, tools/seq_ablate.py); the production
 // instantiation carries none of them.
-template <int WPB, bool PROF = false>
+template <int WPB, bool PROF = false, bool TIMED = false>
 __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(SeqParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -235,13 +299,33 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         const int o = tt - hw_base;
         return iir_output(e2[o], e2[o - 1], e2[o - 2]);
     };
-    // leave the speculation (a forced dcd.unlock() K2 could not foresee): pick the filter history up at sample `tt`
+    // A forced dcd.unlock() is the one thing K2's replay of the gate could not foresee.  The gate itself does not move before the next
+    // update point (the unlock clears the trigger; dcd_ falls when update_dcd sees it, M17Demodulator.h:275-286, 742-752), and K2 feeds
+    // those samples too: its history stays right up to there (h_until).  Beyond it the wave is on its own for the rest of the segment
+    // (`diverged`): it serves itself — nf_serve_limit over every stretch of samples that is certain to be fed (up to its next update
+    // point) — and keeps reading hbuf like everybody else.  The next segment starts from a fresh replay (K2 redoes the channel from this
+    // wave's state).  While diverged, s.h0..h2 = the filter's history after the last sample served / fed.
     unsigned long long n_despec = 0;
-    auto despec = [&](uint32_t tt) {
-        if (s.spec_ok) {
+    bool diverged = false;
+    unsigned long long n_serve = 0, served = 0, tt_div = 0, cnt_div = 0;
+    uint32_t h_until = P.T;   // hbuf holds this channel's true history for every fed sample below this (relative) index
+    auto pick_hist = [&](uint32_t tt) {   // the history after sample tt, from hbuf (tt < h_until)
+        s.h0 = hrow[(int64_t)tt]; s.h1 = hrow[(int64_t)tt - 1]; s.h2 = hrow[(int64_t)tt - 2];
+    };
+    auto despec = [&](uint32_t tt) {      // tt: the sample being processed; s.count already counts it
+#ifdef M17_V3
+        if (s.spec_ok) { ++n_despec; pick_hist(tt); s.spec_ok = 0; }
+        if (false) {
+#else
+        if (s.spec_ok && !diverged) {
+#endif
             ++n_despec;
-            s.h0 = hrow[(int64_t)tt]; s.h1 = hrow[(int64_t)tt - 1]; s.h2 = hrow[(int64_t)tt - 2];
-            s.spec_ok = 0;
+            diverged = true; tt_div = tt; cnt_div = s.count;
+#ifdef M17_DBG_A
+            h_until = tt + 1u; pick_hist(tt);
+#else
+            h_until = min(P.T, tt + (960u - min((uint32_t)s.count, 960u)) + 1u);
+#endif
         }
     };
     auto sw_triggered = [&](int w) -> float {  // Correlator.h:150-157
@@ -382,6 +466,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     };
     auto dcd_point_on = [&](uint32_t te) {
         if (!s.dcd_trig) {  // update_dcd -> dcd_off :260-265 (dcd_ is on here)
+            if (diverged) pick_hist(te);   // the history freezes here; the next gated run of this segment starts from it
             s.st = ST_UNLOCKED;
             s.dcd_on = 0;
             nf_snapshot_hist(gs->hist, xr, te);
@@ -394,6 +479,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     unsigned long long n_bulk = 0, n_bulk_samples = 0, n_scalar = 0, n_flip = 0, n_decode = 0;
     auto now = [&]() -> unsigned long long { if constexpr (PROF) return wall_clock64(); else return 0ull; };
     const unsigned long long tk0 = now();
+    // wave timing (tuning knob 19; the production code in an instantiation of its own): how long THIS wave works on its segment, in 10 ns ticks, with the launch's
+    // duration = the slowest wave's.  Slot = segment index (flags bits 8..12).
+    // (the start time waits in the slot itself: nothing of this stays in registers across the kernel)
+    if constexpr (TIMED) if (wl == 0) P.dbg[(size_t)c * 24 + ((P.flags >> 8) & 31u)] = wall_clock64();
     unsigned long long tk_bulk = 0, tk_scalar = 0, tk_decode = 0, tk_patch = 0, tk_ens = 0, tk_sym = 0, tk_iir = 0, tk_search = 0, tk_off = 0;
 
     // The first 148 FIR outputs of a gated run still see the tail of the previous run (Q2): recompute them from the
@@ -425,6 +514,14 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         window_reset(t0);
         tk_patch += now() - p0;
     };
+    // A channel that left K2's replay in the previous segment finds nothing of its own in hbuf (the replay that ran ahead started from
+    // a state that is not this channel's; K2 is re-deriving the replay's state from this wave's while we run): it serves itself from
+    // its first sample on.  The next segment's replay is good again.
+    if (hrow && P.dropped_in && P.dropped_in[c]) {
+        diverged = true;
+        h_until = 0;
+        if ((s.initializing || s.dcd_on) && wl == 0) { float* hw = const_cast<float*>(hrow); hw[-1] = s.h0; hw[-2] = s.h1; hw[-3] = s.h2; }
+    }
     if (s.run_pos < 148 && (s.initializing || s.dcd_on)) patch_run_start(0);
 
     // ---------------- main loop (wave-uniform control flow) ------------------------------------------------------------
@@ -432,6 +529,19 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     while (t < P.T) {
         bool decode_due = false, tail_dcd = false;
         uint32_t te = 0;
+#ifndef M17_V1
+        if (diverged && t >= h_until && (s.initializing || s.dcd_on)) {
+            // every sample up to the next update point (the end of the initialisation run) will be fed whatever happens: serve them
+            const unsigned long long q0 = now();
+            const uint32_t fed_end = min(P.T, t + (s.initializing ? (uint32_t)s.initializing : 960u - min((uint32_t)s.count, 959u)));
+            hpf_ready(); hpf_base = -0x40000000; hw_base = 0x40000000;   // the staging block is the decoder's array; windows of hbuf are stale now
+            ++n_serve; served += fed_end - t;
+            const Hist3 r = nf_serve_limit(yr, const_cast<float*>(hrow), as_lds(reinterpret_cast<float*>(DL.soft)), t, fed_end, s.h0, s.h1, s.h2);
+            s.h0 = r.h0; s.h1 = r.h1; s.h2 = r.h2;
+            h_until = fed_end;
+            tk_iir += now() - q0;
+        }
+#endif
         // ---- carrier off: nothing happens until the next DCD update point (:675-689) -> jump there ----------------------
         if (!s.initializing && !s.dcd_on) {
             const unsigned long long f0 = now();
@@ -454,6 +564,12 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     s.need_clock_reset = 1;
                     s.run_pos = 0;  // a new gated run starts with the next sample
                     if (t < P.T) patch_run_start(t);
+#ifndef M17_V2
+                    if (diverged) {   // the history the run inherits, where its first samples will look for it (K2's convention)
+                        if (wl == 0) { float* hw = const_cast<float*>(hrow); hw[(int64_t)te] = s.h0; hw[(int64_t)te - 1] = s.h1; hw[(int64_t)te - 2] = s.h2; }
+                        h_until = t;
+                    }
+#endif
                 }
                 dcd_update_at(te);
                 fire_diag(te, 0.f);
@@ -486,7 +602,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                         n = min((uint32_t)(77 - s.sync_count), lim); mode = BULK_QUIET;
                         if (s.spec_ok) {
                             const int32_t target = (int32_t)t + (77 - (int32_t)s.sync_count) - 3;
-                            if (hpf_base != target) hpf_issue(target);
+                            if (hpf_base != target && (!diverged || target + 64 <= (int32_t)h_until)) hpf_issue(target);
                         }
                     }
                     else if (s.sync_count < 86) {   // the window where the next sync word is looked for (:420-574), up to the sample
@@ -607,7 +723,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             const uint32_t f = mask ? (uint32_t)(__ffsll((long long)mask) - 1) : n;   // leading samples that are committed here
             if (f > 0u) {
                 const uint32_t rp0 = s.ring_pos;
-                s.h0 = hb[2u + f]; s.h1 = hb[1u + f]; s.h2 = hb[f];
+                if (!s.spec_ok) { s.h0 = hb[2u + f]; s.h1 = hb[1u + f]; s.h2 = hb[f]; }   // (with hbuf behind the run the history is read where it is needed; while diverged s.h0..h2 belong to the END of the served stretch)
                 const uint32_t first = f > 80u ? f - 80u : 0u;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                 for (uint32_t o = first + wl; o < f; o += 64) ring[(s.ring_pos + o) % 80u] = W[80u + o];
@@ -906,8 +1022,14 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     }
 
     // ---------------- save state ------------------------------------------------------------------------------
-    if (s.spec_ok) { const float* f = P.final_h + (size_t)c * 4; s.h0 = f[0]; s.h1 = f[1]; s.h2 = f[2]; }
-    if (P.dropped && wl == 0) P.dropped[c] = s.spec_ok ? 0u : 1u;
+    if (s.spec_ok) {
+        if (!diverged) { const float* f = P.final_h + (size_t)c * 4; s.h0 = f[0]; s.h1 = f[1]; s.h2 = f[2]; }
+        else if (s.initializing || s.dcd_on) pick_hist(P.T - 1u);   // (gate off: the history was picked where it froze)
+    }
+    if (P.dropped && wl == 0) P.dropped[c] = diverged ? 1u : 0u;
+#ifdef M17_DBGCNT
+    if (!PROF && !TIMED && P.dbg && wl == 0) { P.dbg[(size_t)c * 24 + 23] = n_serve | ((unsigned long long)diverged << 32) | ((unsigned long long)h_until << 33) | (n_despec << 56); P.dbg[(size_t)c * 24 + 22] = served | (tt_div << 24) | (cnt_div << 48); }
+#endif
     s.store(as_lds(hot_lds));
     wave_lds_sync();
     {
@@ -933,6 +1055,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     for (int k = wl; k < 8; k += 64) gs->lsf[k] = DL.lsf[k];
     P.rec_count[c] = cd->n_run;
     if (P.diag_log && wl == 0) P.diag_count[c] = cd->n_diag_run;
+    if constexpr (TIMED) if (wl == 0) {
+        unsigned long long* slot = P.dbg + (size_t)c * 24 + ((P.flags >> 8) & 31u);
+        *slot = (wall_clock64() - *slot) | (P.dropped && P.dropped[c] ? 1ull << 62 : 0ull);
+    }
     if constexpr (PROF) if (wl == 0) {
         unsigned long long* o = P.dbg + (size_t)c * 24;
         o[8] = tk_patch; o[12] = tk_ens; o[13] = tk_sym; o[14] = tk_iir; o[15] = tk_search; o[16] = tk_off; o[17] = n_despec;

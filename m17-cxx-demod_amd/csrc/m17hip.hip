@@ -65,6 +65,8 @@ struct m17hip_ctx {
     void* synth_scratch = nullptr;    // symbol staging of m17hip_synth_i16
     size_t synth_bytes = 0;
     uint32_t runT = 0;                // samples of the latest run
+    int redo_mode = 1;                // tuning knob 20
+    bool wave_times = false;          // tuning knob 19: K5 writes each wave's working time per segment (m17hip_debug_counters)
     uint32_t stagedC = 0, stagedT = 0;
     uint32_t slabC[2] = {0, 0}, slabT[2] = {0, 0};   // what the input slab of each pair holds (m17hip_input_alternate)
     bool front_pending = false;       // m17hip_demod_front has queued the front end of the run that must follow
@@ -618,7 +620,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->hbuf, C * c->ypitch * sizeof(float));
     ALLOC(c->final_h, 2 * C * 4 * sizeof(float));
     ALLOC(c->gate_exp, C * sizeof(GateExport));
-    ALLOC(c->dropped, C * sizeof(uint32_t));
+    ALLOC(c->dropped, 2 * C * sizeof(uint32_t));
     ALLOC(c->bert_state, C * sizeof(BertState));
     hipLaunchKernelGGL(bert_reset_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, 0, (BertState*)c->bert_state, (uint32_t)C);
     if (hipGetLastError() != hipSuccess) return fail(M17HIP_EHIP);
@@ -1216,9 +1218,15 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipMalloc((void**)&c->defer_llr, (size_t)c->maxC * c->rec_cap_alloc * 46 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void**)&c->defer_hist, (size_t)c->maxC * DEFER_HIST_WORDS * 64 * sizeof(uint32_t)));
     }
-    c->dbg_waves = c->profile ? C : 0;
+    c->dbg_waves = (c->profile || c->wave_times) ? C : 0;
     // K2 launch: the whole segment from K5's state (first segment), ahead of K5 from K2's own state (later segments, on side3),
     // or the redo of the channels whose K5 dropped the speculation in the previous segment (from K5's state again)
+    // Redo policy (tuning knob 20).  1 (default): the redo of segment k only re-derives the REPLAY'S STATE for the channels that left it in
+    // segment k - 1, beside K5 of segment k on the replay stream (it stores nothing: those channels serve themselves in segment k,
+    // m17_wave_kernel.hpp), so that the replay of segment k + 1 is good for them again; K5 never waits for it.  0: the redo runs on the
+    // main stream between K5 of segment k - 1 and K5 of segment k and stores the history K5 of segment k then reads (rounds 1-2).
+    const bool side_redo = c->redo_mode == 1;
+    uint32_t* const drop_of[2] = {c->dropped, c->dropped + c->maxC};   // by segment parity
     auto launch_gate = [&](uint32_t k, hipStream_t st, bool ahead, bool redo) -> int {
         const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
         Timed tm(c, KT_GATE, st);
@@ -1226,8 +1234,8 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         G.x = c->xbuf + t0; G.xpitch = c->xpitch; G.y = c->ybuf + t0; G.ypitch = c->ypitch; G.h = c->hbuf + t0;
         G.dcd_table = c->dcd_table; G.ticks_cap = c->ticks_cap; G.state = c->seq_state;
         G.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
-        G.chain_in = ahead ? c->gate_exp : nullptr; G.chain_out = c->gate_exp; G.only = redo ? c->dropped : nullptr;
-        G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags;
+        G.chain_in = ahead ? c->gate_exp : nullptr; G.chain_out = c->gate_exp; G.only = redo ? drop_of[(k - 1u) & 1u] : nullptr;
+        G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags | ((redo && side_redo) ? 2u : 0u);
         hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), 0, st, G);
         HIPCHK(c, hipGetLastError());
         return M17HIP_OK;
@@ -1240,7 +1248,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
             const uint32_t last = std::min(c->front_first, nseg) - 1u;
             HIPCHK(c, hipStreamWaitEvent(c->stream, ev_fir[last], 0));
         }
-        if (c->speculate) {
+        if (c->speculate && !side_redo) {
             if (k == 0) {
                 if ((r = launch_gate(0, c->stream, false, false))) return r;
             } else {
@@ -1256,15 +1264,37 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
                 HIPCHK(c, hipEventRecord(ev_gate[k + 1], c->side3));
             }
         }
+        if (c->speculate && side_redo) {
+            // replay stream: ahead(k) -> redo(k) [after K5(k - 1): its flags and its state] -> ahead(k + 1) -> ...; the main stream only
+            // ever waits for an `ahead`
+            if (k == 0) {
+                if ((r = launch_gate(0, c->stream, false, false))) return r;
+                HIPCHK(c, hipEventRecord(ev_redo[0], c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->side3, ev_redo[0], 0));
+            } else {
+                HIPCHK(c, hipStreamWaitEvent(c->stream, ev_gate[k], 0));
+                if (k + 1 < nseg) {
+                    HIPCHK(c, hipStreamWaitEvent(c->side3, ev_seq[k - 1], 0));
+                    if ((r = launch_gate(k, c->side3, false, true))) return r;
+                }
+            }
+            if (k + 1 < nseg) {
+                HIPCHK(c, hipStreamWaitEvent(c->side3, ev_fir[k + 1], 0));
+                HIPCHK(c, hipStreamWaitEvent(c->side3, ev_dcd[k + 1], 0));
+                if ((r = launch_gate(k + 1, c->side3, true, false))) return r;
+                HIPCHK(c, hipEventRecord(ev_gate[k + 1], c->side3));
+            }
+        }
         Timed tm(c, KT_SEQ);
         SeqParams P{};
         P.h = c->speculate ? c->hbuf + t0 : nullptr; P.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
-        P.dropped = c->speculate ? c->dropped : nullptr;
+        P.dropped = c->speculate ? drop_of[k & 1u] : nullptr;
+        P.dropped_in = (c->speculate && side_redo && k > 0) ? drop_of[(k - 1u) & 1u] : nullptr;
         P.x = c->xbuf + t0; P.xpitch = c->xpitch; P.y = c->ybuf + t0; P.ypitch = c->ypitch;
         P.dcd_table = c->dcd_table; P.ticks_cap = c->ticks_cap; P.state = c->seq_state;
         P.recs = c->recs; P.rec_cap = c->rec_cap; P.rec_count = c->rec_count; P.overflow = c->overflow;
         P.tables = c->tables; P.taps = c->taps; P.llr_edges = c->llr_edges;
-        P.C = C; P.T = len; P.pos0 = c->pos + t0; P.tick_row0 = c->pos / TICK; P.flags = (flags & 1u) | (t0 ? 2u : 0u);
+        P.C = C; P.T = len; P.pos0 = c->pos + t0; P.tick_row0 = c->pos / TICK; P.flags = (flags & 1u) | (t0 ? 2u : 0u) | (std::min(k, 23u) << 8);
         P.kalman_order = c->kalman_order; P.channel_base = c->channel_base;
         P.diag_log = c->diag_cap ? c->diag_log : nullptr; P.diag_cap = c->diag_cap; P.diag_count = c->diag_count;
         P.defer = c->defer_decode ? c->defer_llr : nullptr;
@@ -1274,8 +1304,12 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         // LDS: what the workgroup needs (31.8 KB for four waves), padded so that a CU holds FOUR of them and not five — the rest of
         // the CU (24 KB, 128 VGPRs per SIMD) is where a K2 wave or a K1 workgroup runs beside them without taking a K5 slot
         const size_t lds = std::max((size_t)wave_lds_words((int)wpb) * 4, c->seq_lds_bytes ? (size_t)c->seq_lds_bytes : (wpb == 4 ? (size_t)SEQ_LDS_BYTES_4 : (size_t)0));
-        P.dbg = c->profile ? c->dbg : nullptr;
+        P.dbg = (c->profile || (c->wave_times && wpb == 4)) ? c->dbg : nullptr;
+#ifdef M17_DBGCNT
+        P.dbg = c->dbg; c->dbg_waves = C;
+#endif
         if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P);
+        else if (c->wave_times && wpb == 4) hipLaunchKernelGGL((demod_wave_kernel<4, false, true>), grid, block, lds, c->stream, P);
         else switch (wpb) {
         case 1: hipLaunchKernelGGL(demod_wave_kernel<1>, grid, block, lds, c->stream, P); break;
         case 2: hipLaunchKernelGGL(demod_wave_kernel<2>, grid, block, lds, c->stream, P); break;
@@ -1764,6 +1798,13 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         if (value < 0 || value > (int64_t)c->rec_cap_alloc) return M17HIP_EINVAL;
         c->rec_cap = value ? (uint32_t)value : c->rec_cap_alloc;
         c->recs_valid = false;   // the slots of the last run were written with the old stride: nothing to fetch until the next run
+        return M17HIP_OK;
+    case 20:  // redo policy: 1 = beside K5, state only (default); 0 = on the main stream ahead of K5, with the history stored
+        if (value != 0 && value != 1) return M17HIP_EINVAL;
+        c->redo_mode = (int)value;
+        return M17HIP_OK;
+    case 19:  // per-wave working time of the sequential kernel, per segment (production build): m17hip_debug_counters slot = segment
+        c->wave_times = value != 0;
         return M17HIP_OK;
     case 16:  // the in-place producers (m17hip_upload_i16, m17hip_upload_i16_device, m17hip_synth_i16) write the STAGING slab instead
         c->stage_inputs = value != 0;

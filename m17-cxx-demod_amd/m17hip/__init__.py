@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libm17hip.so")
+LIB_PATH = os.environ.get("M17HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libm17hip.so")   # (M17HIP_LIB: an experiment build of the same library)
 
 FRAME_REC = np.dtype(
     [("channel", "<u4"), ("seq", "<u4"), ("sample_pos", "<u8"), ("cost", "<i4"), ("frame_type", "u1"), ("sync_type", "u1"),

@@ -197,13 +197,13 @@ def test_performance_knobs_do_not_change_results():
     exp = _oracle_flat(x)
     c = m17hip.Context(48, 96000)
     c.upload(x)
-    for settings in ({}, {13: 0}, {13: 2}, {10: 1}, {14: 1}, {14: 40000}, {0: 8}, {0: 1}, {3: 19200}, {2: 0}, {3: 0, 13: 0, 14: 65536}, {15: 0}, {15: 0, 3: 7001}):
+    for settings in ({}, {13: 0}, {13: 2}, {10: 1}, {14: 1}, {14: 40000}, {0: 8}, {0: 1}, {3: 19200}, {2: 0}, {3: 0, 13: 0, 14: 65536}, {15: 0}, {15: 0, 3: 7001}, {20: 0}, {20: 0, 3: 19200}, {3: 4800}):
         for k, v in settings.items():
             c.tune(k, v)
         c.reset(); c.run()
         assert c.frames().tobytes() == exp.tobytes(), settings
         for k in settings:
-            c.tune(k, {13: 1, 10: 0, 14: 0, 0: 0, 3: 48000, 2: 1, 15: 1}[k])   # back to the defaults
+            c.tune(k, {13: 1, 10: 0, 14: 0, 0: 0, 3: 48000, 2: 1, 15: 1, 20: 1}[k])   # back to the defaults
     import ctypes as C_
     assert c.lib.m17hip_tune(c.h, 14, C_.c_int64(70000)) == -1 and c.lib.m17hip_tune(c.h, 13, C_.c_int64(3)) == -1
     c.close()

@@ -23,7 +23,7 @@ def _oracle_records(x, invert=0):
     return flat, counts, diags
 
 
-@pytest.fixture(scope="module", params=[(1, 0, 1), (0, 0, 1), (1, 1, 0)], ids=["limit_ahead", "limit_inline", "k3_pipeline_decode_in_k5"])
+@pytest.fixture(scope="module", params=[(1, 0, 1, 1), (0, 0, 1, 1), (1, 1, 0, 1), (1, 0, 1, 0)], ids=["limit_ahead", "limit_inline", "k3_pipeline_decode_in_k5", "redo_on_main_stream"])
 def ctx(request):
     """Every test runs three times: with the correlator's limit filter run ahead of the sequential kernel (K2, the default), with
     the sequential kernel carrying it itself (tuning knob 2 = 0, also the fallback of a dropped speculation), and with the
@@ -32,6 +32,7 @@ def ctx(request):
     c.tune(2, request.param[0])
     c.tune(10, request.param[1])
     c.tune(15, request.param[2])   # payload frames decoded after the run (default) / where they complete
+    c.tune(20, request.param[3])   # the replay's redo beside K5, state only (default) / on the main stream ahead of K5
     c.limit_ahead = bool(request.param[0])
     yield c
     c.close()

@@ -32,7 +32,7 @@ def _sorted(parts):
     return got[np.lexsort((got["seq"], got["channel"]))]
 
 
-@pytest.fixture(scope="module", params=[{}, {2: 0}, {10: 1, 15: 0}, {3: 7001}], ids=["default", "limit_inline", "k3_pipeline_decode_in_k5", "seg7001"])
+@pytest.fixture(scope="module", params=[{}, {2: 0}, {10: 1, 15: 0}, {3: 7001}, {20: 0}], ids=["default", "limit_inline", "k3_pipeline_decode_in_k5", "seg7001", "redo_on_main_stream"])
 def ctx(request):
     c = m17hip.Context(64, 48000)
     for k, v in request.param.items():
