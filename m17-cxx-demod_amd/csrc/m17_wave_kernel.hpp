@@ -312,7 +312,9 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     auto pick_hist = [&](uint32_t tt) {   // the history after sample tt, from hbuf (tt < h_until)
         s.h0 = hrow[(int64_t)tt]; s.h1 = hrow[(int64_t)tt - 1]; s.h2 = hrow[(int64_t)tt - 2];
     };
+    bool left_replay = false;   // a forced unlock fell into THIS segment: the replay that is (or was) run for it ends in a state that is not this channel's
     auto despec = [&](uint32_t tt) {      // tt: the sample being processed; s.count already counts it
+        if (s.spec_ok) left_replay = true;
 #ifdef M17_V3
         if (s.spec_ok) { ++n_despec; pick_hist(tt); s.spec_ok = 0; }
         if (false) {
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         if (!diverged) { const float* f = P.final_h + (size_t)c * 4; s.h0 = f[0]; s.h1 = f[1]; s.h2 = f[2]; }
         else if (s.initializing || s.dcd_on) pick_hist(P.T - 1u);   // (gate off: the history was picked where it froze)
     }
-    if (P.dropped && wl == 0) P.dropped[c] = diverged ? 1u : 0u;
+    if (P.dropped && wl == 0) P.dropped[c] = left_replay ? 1u : 0u;
 #ifdef M17_DBGCNT
     if (!PROF && !TIMED && P.dbg && wl == 0) { P.dbg[(size_t)c * 24 + 23] = n_serve | ((unsigned long long)diverged << 32) | ((unsigned long long)h_until << 33) | (n_despec << 56); P.dbg[(size_t)c * 24 + 22] = served | (tt_div << 24) | (cnt_div << 48); }
 #endif
@@ -1057,7 +1059,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     if (P.diag_log && wl == 0) P.diag_count[c] = cd->n_diag_run;
     if constexpr (TIMED) if (wl == 0) {
         unsigned long long* slot = P.dbg + (size_t)c * 24 + ((P.flags >> 8) & 31u);
-        *slot = (wall_clock64() - *slot) | (P.dropped && P.dropped[c] ? 1ull << 62 : 0ull);
+        *slot = (wall_clock64() - *slot) | (diverged ? 1ull << 62 : 0ull);
     }
     if constexpr (PROF) if (wl == 0) {
         unsigned long long* o = P.dbg + (size_t)c * 24;
