@@ -6,8 +6,13 @@
 // delivered in exactly the reference's order: every frame callback and every diagnostic callback (one per 960 samples while
 // the carrier is on, one per 384 while it is off), ordered by the sample that fired them, frame callbacks of a sample first.
 // What a caller can observe beyond that: callbacks arrive up to one block late, and the end of the input needs flush() —
-// the destructor calls it, so a stock read loop loses nothing.  There is no CPU fallback: without libm17hip.so / a GPU the
+// the destructor calls it, so a stock read loop loses nothing.  There is no silent CPU fallback: without libm17hip.so / a GPU the
 // constructor throws.  For thousands of channels at once use BatchedDemodulator.h (this class is the 1-channel case of it).
+//
+// The same object can be told to stay on the HOST (BASELINE configs[0]: one stream, no GPU): construct it with the tag
+// `mobilinkd::scalar_cpu`, or — for an application that is not to be touched, like the stock apps/m17-demod.cpp — export
+// M17_DEMOD_DEVICE=cpu (M17_DEMOD_DEVICE=<n> picks GPU n; unset = GPU 0).  It then runs detail/scalar_demod.h: the operator classes
+// of this directory, i.e. the arithmetic cores the kernels are built from, one sample per call, callbacks delivered at once.
 //
 // Like the reference's header this one pulls in the whole operator surface (Correlator, FirFilter, DataCarrierDetect,
 // ClockRecovery, FreqDevEstimator, M17FrameDecoder with LinkSetupFrame / CRC16 / Viterbi / Trellis, M17Framer, SymbolEvm,
@@ -24,8 +29,11 @@
 #include "M17Framer.h"
 #include "SymbolEvm.h"
 #include "Util.h"
+#include "detail/scalar_demod.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <memory>
 #include <array>
 #include <cmath>
 #include <cstring>
@@ -56,6 +64,9 @@ struct Taps
 
 } // detail
 
+struct scalar_cpu_t { explicit scalar_cpu_t() = default; };
+inline constexpr scalar_cpu_t scalar_cpu{};   // M17Demodulator<float> demod(callback, scalar_cpu): the host form, no GPU involved
+
 template <typename FloatType>
 struct M17Demodulator
 {
@@ -83,13 +94,18 @@ struct M17Demodulator
 
     DemodState demodState = DemodState::UNLOCKED;   // state at the end of the last block
 
-    explicit M17Demodulator(callback_t callback, uint32_t block_samples = 1920, int device = 0)
-    : gpu_(1, block_samples, device), callback_(std::move(callback)), block_(block_samples)
+    // the reference's constructor (M17Demodulator.h:180-182): where it runs is the environment's choice (see the header comment)
+    explicit M17Demodulator(callback_t callback) : callback_(std::move(callback)), block_(1920)
     {
-        buffer_.reserve(block_);
-        gpu_.enable_diag_log(block_ / 384 + 2);
-        gpu_.reset();
+        const char* where = std::getenv("M17_DEMOD_DEVICE");
+        if (where && std::string(where) == "cpu") start_cpu();
+        else start_gpu(where && *where ? std::atoi(where) : 0);
     }
+    M17Demodulator(callback_t callback, uint32_t block_samples, int device = 0) : callback_(std::move(callback)), block_(block_samples)
+    {
+        start_gpu(device);
+    }
+    M17Demodulator(callback_t callback, scalar_cpu_t) : callback_(std::move(callback)), block_(1920) { start_cpu(); }
 
     virtual ~M17Demodulator()
     {
@@ -99,12 +115,18 @@ struct M17Demodulator
     // The reference takes sample / 41067.0 (apps/m17-demod.cpp:489); the int16 the GPU path scales itself is recovered exactly.
     void operator()(const FloatType input)
     {
+        if (cpu_) {   // the host form: this very sample, callbacks before the call returns
+            cpu_->step(input);
+            demodState = (DemodState)cpu_->state();
+            return;
+        }
         buffer_.push_back((int16_t)std::lrint((double)input * 41067.0));
         if (buffer_.size() == block_) run_block();
     }
 
     // demodulate what is buffered (end of input); safe to call at any time
-    void flush() { if (!buffer_.empty()) run_block(); }
+    void flush() { if (gpu_ && !buffer_.empty()) run_block(); }
+    bool on_gpu() const { return gpu_ != nullptr; }
 
     bool locked() const { return dcd_; }
     void passall(bool enabled) { passall_ = enabled; }
@@ -134,8 +156,25 @@ private:
             diagnostic_callback(d.dcd != 0, (FloatType)d.evm, (FloatType)d.deviation, (FloatType)d.offset, d.locked != 0, (FloatType)d.clock,
                                 d.sample_index, d.sync_index, d.clock_index, d.viterbi_cost);
     }
+    void start_gpu(int device)
+    {
+        gpu_ = std::make_unique<BatchedDemodulator>(1, block_, device);
+        buffer_.reserve(block_);
+        gpu_->enable_diag_log(block_ / 384 + 2);
+        gpu_->reset();
+    }
+    void start_cpu()
+    {
+        cpu_ = std::make_unique<detail::ScalarDemodulator<FloatType>>(detail::Taps<FloatType>::rrc_taps,
+            [this](const M17FrameDecoder::output_buffer_t& f, int cost) { return callback_ ? callback_(f, cost) : true; });
+        cpu_->on_diagnostics = [this](bool dcd, FloatType evm, FloatType dev, FloatType off, bool locked, FloatType clock, int si, int sy, int ci, int vc) {
+            dcd_ = dcd;
+            if (diagnostic_callback) diagnostic_callback(dcd, evm, dev, off, locked, clock, si, sy, ci, vc);
+        };
+    }
     void run_block()
     {
+        auto& gpu_ = *this->gpu_;
         gpu_.upload(buffer_.data(), 1, (uint32_t)buffer_.size(), buffer_.size());
         gpu_.run();
         const auto frames = gpu_.frames();
@@ -152,7 +191,8 @@ private:
         buffer_.clear();
     }
 
-    BatchedDemodulator gpu_;
+    std::unique_ptr<BatchedDemodulator> gpu_;                        // one of the two
+    std::unique_ptr<detail::ScalarDemodulator<FloatType>> cpu_;
     callback_t callback_;
     std::vector<int16_t> buffer_;
     uint32_t block_;

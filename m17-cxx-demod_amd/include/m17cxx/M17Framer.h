@@ -26,15 +26,13 @@ struct M17Framer
     /// hard decision: dibit -> +-1 per bit
     size_t operator()(int dibit, int8_t** result)
     {
-        (void)result;
-        return push((dibit & 2) ? 1 : -1, (dibit & 1) ? 1 : -1);
+        return hand_out(push((dibit & 2) ? 1 : -1, (dibit & 1) ? 1 : -1), result);
     }
 
     /// soft decision: the LLR pair of llr<>()
     size_t operator()(std::tuple<int8_t, int8_t> symbol, int8_t** result)
     {
-        (void)result;
-        return push(std::get<0>(symbol), std::get<1>(symbol));
+        return hand_out(push(std::get<0>(symbol), std::get<1>(symbol)), result);
     }
 
     void reset()
@@ -44,6 +42,12 @@ struct M17Framer
     }
 
 private:
+    // a full frame is handed out as a pointer into the framer's own buffer (valid until the next symbol), as the reference does
+    size_t hand_out(size_t n, int8_t** result)
+    {
+        if (n != 0 && result) *result = buffer_.data();
+        return n;
+    }
     size_t push(int8_t first, int8_t second)
     {
         buffer_[index_] = first;

@@ -356,11 +356,11 @@ int main(int argc, char** argv)
         save(argv[6], out);
         return 0;
     }
-    if (mode == "gpu_demod") {   // gpu_demod in.i16 block : M17Demodulator<float> fed one sample per call; prints every callback in order
+    if (mode == "gpu_demod" || mode == "cpu_demod") {   // gpu_demod in.i16 block | cpu_demod in.i16 : M17Demodulator<float> fed one sample per call; prints every callback in order
         auto in = load<int16_t>(argv[2]);
         size_t n_diag = 0;
         {
-            M17Demodulator<float> demod([](M17FrameDecoder::output_buffer_t const& f, int cost) {
+            auto on_frame = [](M17FrameDecoder::output_buffer_t const& f, int cost) {
                 const uint8_t* p = nullptr; size_t n = 0;
                 switch (f.type) {
                 case M17FrameDecoder::FrameType::LSF: p = f.lsf.data(); n = 30; break;
@@ -373,7 +373,11 @@ int main(int argc, char** argv)
                 for (size_t i = 0; i < n; ++i) std::printf("%02x", p[i]);
                 std::printf("\n");
                 return true;
-            }, (uint32_t)std::atoi(argv[3]));
+            };
+            std::unique_ptr<M17Demodulator<float>> dp;
+            if (mode == "cpu_demod") dp = std::make_unique<M17Demodulator<float>>(on_frame, scalar_cpu);   // detail/scalar_demod.h on the host
+            else dp = std::make_unique<M17Demodulator<float>>(on_frame, (uint32_t)std::atoi(argv[3]));
+            auto& demod = *dp;
             demod.diagnostics([&](bool dcd, float evm, float dev, float off, bool locked, float clock, int si, int sy, int ci, int vc) {
                 uint32_t w[4]; std::memcpy(&w[0], &evm, 4); std::memcpy(&w[1], &dev, 4); std::memcpy(&w[2], &off, 4); std::memcpy(&w[3], &clock, 4);
                 std::printf("D %d %08x %08x %08x %d %08x %d %d %d %d\n", (int)dcd, w[0], w[1], w[2], (int)locked, w[3], si, sy, ci, vc);

@@ -92,7 +92,7 @@ def _p(a, t=None):
 def oracle():
     global _oracle
     if _oracle is None:
-        path = os.path.join(ORACLE_DIR, "libm17oracle.so")
+        path = os.environ.get("M17_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libm17oracle.so")   # (M17_ORACLE_LIB: the sanitizer build, tools/sanitize_cpu.sh)
         if not os.path.exists(path):
             build_oracle()
         lib = C.CDLL(path)

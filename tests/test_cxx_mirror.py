@@ -13,8 +13,8 @@ import pytest
 import oracle_lib as ol
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "tests", "cxx", "mirror_check")
-SRC = EXE + ".cpp"
+SRC = os.path.join(ROOT, "tests", "cxx", "mirror_check.cpp")
+EXE = os.environ.get("M17_MIRROR_CHECK") or os.path.join(ROOT, "tests", "cxx", "mirror_check")   # (M17_MIRROR_CHECK: the sanitizer build)
 
 
 @pytest.fixture(scope="module")
@@ -224,6 +224,39 @@ def test_batched_fir_through_the_mirror_equals_reference(exe, golden, tmp_path):
 def test_batched_viterbi_through_the_mirror_equals_reference(exe, golden, tmp_path):
     """Viterbi<Trellis<4,2>,4>::decode<IN,OUT>(batched::Device&, ...) -> m17hip_viterbi, golden frames of all four shapes + the LSF KAT."""
     _viterbi(exe, golden, tmp_path, "gpu_viterbi")
+
+
+def _expected_callback_lines(x):
+    recs, _ = ol.demod(x)
+    log = ol.demod_diag_log(x)
+    events = [(int(r["sample_pos"]), 0, r) for r in recs] + [(int(d["pad"][0]) | (int(d["pad"][1]) << 32), 1, d) for d in log]
+    events.sort(key=lambda e: (e[0], e[1]))
+    exp = []
+    for _, k, e in events:
+        if k == 0:
+            exp.append(f"F {int(e['frame_type'])} {int(e['cost'])} {bytes(e['payload'][:int(e['len'])]).hex()}")
+        else:
+            w = [int(np.array(e[f], dtype=np.float32).view(np.uint32)) for f in ("evm", "deviation", "offset", "clock")]
+            exp.append(f"D {int(e['dcd'])} {w[0]:08x} {w[1]:08x} {w[2]:08x} {int(e['locked'])} {w[3]:08x} {int(e['sample_index'])} "
+                       f"{int(e['sync_index'])} {int(e['clock_index'])} {int(e['viterbi_cost'])}")
+    exp.append(f"END {log.size}")
+    return exp, len(recs), log.size
+
+
+@pytest.mark.parametrize("kind,sigma,dc", [(0, 500.0, 0.0), (1, 500.0, 0.0), (2, 300.0, 0.0), (4, 300.0, 0.0), (1, 2500.0, -1500.0), (3, 800.0, 0.0)])
+def test_scalar_cpu_demodulator_delivers_the_reference_callback_sequence(exe, tmp_path, kind, sigma, dc):
+    """mobilinkd::M17Demodulator<float>(callback, scalar_cpu): the orchestrator of detail/scalar_demod.h over the operator classes of the
+    mirror (no GPU, no oracle code), fed one sample per call like apps/m17-demod.cpp:484-490 — every frame callback and every diagnostic
+    callback, in order, arguments bit for bit, equals the oracle's (BERT, voice stream with LICH, packets, a noisy stream with a
+    frequency offset that loses sync, noise only)."""
+    p = ol.gen_params(seed=140 + kind, kind=kind, n_frames=9, lead_in=3072, noise_sigma=sigma, tail_sigma=sigma if kind != 1 or dc == 0 else 3000.0,
+                      lead_sigma=40000.0, dc_offset=dc, total=40000)
+    x = ol.generate(p)
+    x.tofile(tmp_path / "x.i16")
+    lines = run(exe, "cpu_demod", tmp_path / "x.i16").strip().split("\n")
+    exp, n_recs, n_diag = _expected_callback_lines(x)
+    assert n_diag > 30 and (n_recs >= 5 or kind == 3)
+    assert lines == exp
 
 
 @pytest.mark.gpu

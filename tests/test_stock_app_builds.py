@@ -31,6 +31,35 @@ def test_unmodified_stock_app_builds_against_the_mirror(tmp_path):
     assert v.returncode == 0 and "2.2" in v.stdout
 
 
+@pytest.mark.skipif(not os.path.exists(APP), reason="reference not present (build container only)")
+def test_unmodified_stock_app_demodulates_a_stream_on_the_host_form(tmp_path):
+    """BASELINE configs[0]: one 48 kSPS stream through the stock m17-demod with no GPU.  The unmodified application, built as a release
+    build (NDEBUG, as the reference's CMake does) against the mirror, is told to stay on the host (M17_DEMOD_DEVICE=cpu ->
+    detail/scalar_demod.h) and fed a BERT transmission on stdin: it locks, counts the PRBS9 bits of the frames the oracle
+    decodes too, and reports the bit error rate the application prints (apps/m17-demod.cpp:353-368)."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    out = tmp_path / "m17-demod-stock"
+    cmd = FLAGS + ["-DNDEBUG", "-I", INC, "-I", os.path.join(ROOT, "tests", "shims"), APP, "-L", os.path.join(ROOT, "m17-cxx-demod_amd"), "-lm17hip",
+                   "-Wl,-rpath," + os.path.join(ROOT, "m17-cxx-demod_amd"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    p = ol.gen_params(seed=5, kind=0, n_frames=12, lead_in=3072, noise_sigma=300.0, tail_sigma=300.0, lead_sigma=40000.0, total=48000)
+    x = ol.generate(p)
+    run = subprocess.run([str(out), "-d"], input=x.tobytes(), capture_output=True, env=dict(os.environ, M17_DEMOD_DEVICE="cpu"))
+    assert run.returncode == 0
+    err = run.stderr.replace(b"\r", b"\n").decode(errors="replace")
+    recs, _ = ol.demod(x)
+    bert = [r_ for r_ in recs if int(r_["frame_type"]) == 5]
+    assert len(bert) >= 12
+    bits = [int(m) for m in re.findall(r"BER: [0-9.]+ \((\d+) bits\)", err)]
+    assert bits and 197 * 11 <= max(bits) <= 197 * len(bert)     # the 12 transmitted frames (the receiver needs 18 good bits to lock) ... the garbage after them
+    assert re.search(r"BER: 0\.0", err)
+    assert "locked:  true" in err and "dcd: 1" in err
+
+
 def test_surface_signatures_compile(tmp_path):
     """Every class the north star names, instantiated and called with the reference's signatures."""
     src = tmp_path / "surface.cpp"
