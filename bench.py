@@ -499,11 +499,16 @@ def main():
         "value_with_h2d": h2d["value_with_h2d"] if h2d else None, "h2d": h2d,
         "roofline": roofline, "cpu_baseline": cpu,
     }
-    print(json.dumps(out))
     for m_ in comms:
         m_.close()
     if multi:
         dist.destroy_process_group()
+    try:   # RCCL writes a version banner through C stdio: flush it so that the JSON line is the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
+    print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(args, ol, x, C, T, ncpu, ncpu_affinity, cpu_quota, chain):

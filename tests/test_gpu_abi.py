@@ -223,7 +223,39 @@ def test_rccl_gather_single_rank():
     tot = C.c_uint64(0)
     code = c.lib.m17hip_gather_frames(c.h, comm.h, 0, small.ctypes.data_as(C.c_void_p), C.c_uint64(5), None, C.byref(tot))
     assert code == m17hip.ETRUNC and tot.value == recs.size and small.tobytes() == recs[:5].tobytes()
+    # a run that outran its record slots (tune 8) followed by a gather — the dense buffer is sized for what the run did
+    # produce whatever the first compaction pass returned; the call reports EOVERFLOW and delivers the records that exist
+    c2 = m17hip.Context(12, 48000)
+    c2.tune(8, 3)
+    c2.upload(x); c2.reset(); c2.run()
+    big = np.zeros(4096, dtype=m17hip.FRAME_REC)
+    cnt = np.zeros(1, dtype=np.uint64)
+    code = c2.lib.m17hip_gather_frames(c2.h, comm.h, 0, big.ctypes.data_as(C.c_void_p), C.c_uint64(big.size), cnt.ctypes.data_as(C.c_void_p), C.byref(tot))
+    assert code == -5 and tot.value == 12 * 3 and int(cnt[0]) == 36
+    full = _oracle_flat(x)
+    first3 = np.concatenate([full[full["channel"] == ch][:3] for ch in range(12)])
+    assert big[:36].tobytes() == first3.tobytes()
+    # ... and before any run the collective still completes on every rank, with the call-sequence error as its result
+    c3 = m17hip.Context(4, 4800)
+    assert c3.lib.m17hip_gather_frames(c3.h, comm.h, 0, big.ctypes.data_as(C.c_void_p), C.c_uint64(big.size), None, C.byref(tot)) == -4
+    c3.close(); c2.close()
     comm.close(); c.close()
+
+
+def test_bench_multi_gpu_code_path_with_one_rank(tmp_path):
+    """bench.py's N > 1 branch (process group, one C-ABI communicator per batch in flight agreed on collectively, gather per step to
+    rank 0, the ordered-and-unique check, both regimes) driven with a world of ONE rank: --force-gather --gather cabi."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-gather", "--gather", "cabi", "--channels", "64", "--samples", "48000",
+                        "--steps", "2", "--warmup", "1", "--prewarm", "2", "--cpu-seconds", "0", "--h2d-steps", "0", "--parity-channels", "8"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])   # (RCCL prints its version banner on stdout too)
+    assert line["n_gpus"] == 1 and line["config"]["gather"].startswith("m17hip_gather_frames_device")
+    assert line["config"]["gathered_set_ordered_and_unique"] is True and line["config"]["parity_vs_oracle_first_channels"] is True
+    assert line["value"] > 0 and line["value_single_stream"] > 0
 
 
 _WORKER = r"""

@@ -64,3 +64,42 @@ def test_two_rank_gather_equals_single_process(tmp_path):
         assert got.tobytes() == expect.tobytes(), rank                     # every rank holds the full, ordered set
         counts = np.load(os.path.join(tmp_path, f"counts{rank}.npy"))
         assert counts.sum() == expect.size and len(counts) == 2
+
+
+def _worker8(rank, world, port, outdir):
+    """world_size 8 over 5 channels: ranks 5..7 hold an EMPTY shard (zero records), rank 3's channel is noise only (zero records
+    from a non-empty shard), the others differ in length — the padded all-gather of m17hip/dist.py must still return the one ordered set."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = _signals8()
+    lo, hi = mdist.shard_range(x.shape[0], rank, world)
+    mine = _records(x[lo:hi], lo) if hi > lo else np.zeros(0, dtype=ol.FRAME_REC)
+    buf = torch.zeros(max(1, mine.size) * 64, dtype=torch.uint8)
+    if mine.size:
+        buf[: mine.size * 64] = torch.from_numpy(np.frombuffer(mine.tobytes(), dtype=np.uint8).copy())
+    allrecs, counts = mdist.gather_records(buf, mine.size)
+    np.save(os.path.join(outdir, f"rank{rank}.npy"), allrecs.numpy())
+    np.save(os.path.join(outdir, f"counts{rank}.npy"), np.array(counts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _signals8():
+    rows = []
+    for c, (kind, frames) in enumerate([(0, 9), (1, 3), (2, 6), (3, 1), (1, 8)]):   # BERT, short stream, packets, NOISE ONLY, stream
+        p = ol.gen_params(seed=300 + c, kind=kind, n_frames=frames, lead_in=3072, noise_sigma=400.0, tail_sigma=400.0, lead_sigma=40000.0, total=T)
+        rows.append(ol.generate(p)[:T])
+    return np.stack(rows)
+
+
+def test_eight_rank_gather_with_uneven_and_empty_shards(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    expect = _records(_signals8(), 0)
+    assert expect.size > 0 and not (expect["channel"] == 3).any()         # the noise-only channel produced nothing
+    for rank in range(8):
+        got = np.load(os.path.join(tmp_path, f"rank{rank}.npy"))
+        counts = np.load(os.path.join(tmp_path, f"counts{rank}.npy"))
+        assert got.tobytes() == expect.tobytes(), rank
+        assert len(counts) == 8 and counts.sum() == expect.size and counts[3] == 0 and (counts[5:] == 0).all()
