@@ -77,6 +77,13 @@ int m17hip_version(void);
  * M17Demodulator<float> per channel (apps/m17-demod.cpp:455, M17Demodulator.h:180-182). */
 int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out);
 void m17hip_ctx_destroy(m17hip_ctx* ctx);
+/* Deployment advice (bit set; 0 = nothing to say).  Bit 0 (M17HIP_ADVICE_HW_QUEUES): the process runs with fewer than 8 hardware
+ * queues (environment variable GPU_MAX_HW_QUEUES, read by the HIP runtime when it initialises; its default is 4).  A context uses
+ * five streams (main, matched filter, carrier detect, limit-filter replay, copy); with streams sharing a hardware queue a kernel
+ * queued behind another stream's event wait waits with it, and the overlap the streams exist for is lost (measured: two contexts
+ * 42 instead of 26 ms per step).  Export GPU_MAX_HW_QUEUES=16 before the first HIP call of the process. */
+#define M17HIP_ADVICE_HW_QUEUES 1
+int m17hip_advice(const m17hip_ctx* ctx);
 /* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = the default stream). */
 int m17hip_set_stream(m17hip_ctx* ctx, void* hip_stream);
 

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -592,6 +593,12 @@ const char* m17hip_strerror(int code)
     }
 }
 int m17hip_last_hip_error(const m17hip_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+int m17hip_advice(const m17hip_ctx* ctx)
+{
+    if (!ctx) return 0;
+    const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+    return (!q || std::atoi(q) < 8) ? M17HIP_ADVICE_HW_QUEUES : 0;
+}
 int m17hip_version(void) { return 300; }
 
 int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out)

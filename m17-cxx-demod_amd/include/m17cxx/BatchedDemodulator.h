@@ -6,6 +6,7 @@
 #include "../../../include/m17hip.h"
 
 #include <cstdint>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -28,6 +29,12 @@ public:
     BatchedDemodulator(uint32_t max_channels, uint32_t max_samples, int device = 0)
     {
         check(m17hip_ctx_create(device, max_channels, max_samples, &ctx_), "m17hip_ctx_create");
+        static bool warned = false;
+        if ((m17hip_advice(ctx_) & M17HIP_ADVICE_HW_QUEUES) && !warned) {
+            warned = true;
+            std::fprintf(stderr, "m17hip: GPU_MAX_HW_QUEUES is unset or below 8: the context's streams will share hardware queues and serialise; "
+                                 "export GPU_MAX_HW_QUEUES=16 before the process touches the GPU (include/m17hip.h)\n");
+        }
     }
     ~BatchedDemodulator() { m17hip_ctx_destroy(ctx_); }
     BatchedDemodulator(const BatchedDemodulator&) = delete;

@@ -39,7 +39,7 @@ EXPORTS = [
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_packets_fetch", "m17hip_packets_feed", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
     "m17hip_set_kalman_order", "m17hip_kalman_trace", "m17hip_set_channel_base", "m17hip_upload_wait", "m17hip_comm_get_id", "m17hip_comm_create",
     "m17hip_comm_destroy", "m17hip_comm_last_error", "m17hip_gather_frames", "m17hip_gather_frames_device", "m17hip_diag_log_fetch",
-    "m17hip_upload_i16_device_async", "m17hip_input_alternate", "m17hip_demod_front",
+    "m17hip_upload_i16_device_async", "m17hip_input_alternate", "m17hip_demod_front", "m17hip_advice",
 ]
 ETRUNC = -6
 COMM_ID_BYTES = 128
@@ -97,6 +97,8 @@ class Comm:
 class Context:
     """One demodulation context = `channels` independent 48 kSPS channels on one GPU (include/m17hip.h)."""
 
+    _warned = False
+
     def __init__(self, max_channels, max_samples, device=0, stream=None):
         self.lib = load_library()
         self.h = C.c_void_p()
@@ -104,6 +106,11 @@ class Context:
         self._chk(self.lib.m17hip_ctx_create(C.c_int(device), C.c_uint32(max_channels), C.c_uint32(max_samples), C.byref(self.h)))
         if stream is not None:
             self.set_stream(stream)
+        if self.lib.m17hip_advice(self.h) & 1 and not Context._warned:
+            Context._warned = True
+            import warnings
+            warnings.warn("m17hip: GPU_MAX_HW_QUEUES is unset or below 8 — the streams of a context (and of several contexts) will share "
+                          "hardware queues and serialise; export GPU_MAX_HW_QUEUES=16 before the process touches the GPU (include/m17hip.h)")
 
     def _chk(self, code):
         if code != 0:

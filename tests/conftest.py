@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before anything initialises the HIP runtime (include/m17hip.h, m17hip_advice)
+
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -8,12 +8,16 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --prewarm 0 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0"
+# ONE step strictly after the other (--in-flight 1, no single-stream leg, no extra one-at-a-time pass): every launch in the trace is in
+# the regime bench.py's `roofline` object is computed from, so the kernel_trace_stats average and the line's kernel_ms_per_launch agree
+ARGS="--in-flight 1 --single-stream 0 --one-at-a-time 0 --steps 4 --warmup 1 --prewarm 0 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -d $OUT/sq -o sq -- python3 $R/bench.py $ARGS > $OUT/sq.log 2>&1
-for p in trace fetch write sq; do
+# the default command (two batches in flight, then the single-stream regime), for the record
+rocprofv3 --kernel-trace --stats -d $OUT/trace_default -o trace_default -- python3 $R/bench.py --steps 4 --warmup 1 --prewarm 4 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0 > $OUT/trace_default.log 2>&1
+for p in trace fetch write sq trace_default; do
   python3 $R/tools/rocpd_summary.py $OUT/$p/${p}_results.db $OUT/${p}_summary.md > /dev/null 2>&1
   grep -h '"metric"' $OUT/$p.log | head -1 > $OUT/${p}_bench_line.json
 done
