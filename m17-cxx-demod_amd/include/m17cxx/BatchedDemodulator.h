@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -28,6 +29,10 @@ class BatchedDemodulator
 public:
     BatchedDemodulator(uint32_t max_channels, uint32_t max_samples, int device = 0)
     {
+        // The HIP runtime reads GPU_MAX_HW_QUEUES when it initialises (a context's five streams must not share hardware queues,
+        // include/m17hip.h m17hip_advice): ask for 16 unless the host has decided otherwise.  Effective when this is the process's
+        // first contact with the GPU — the case of a host like apps/m17-demod.cpp; a host that has already used HIP sets it itself.
+        ::setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite*/0);
         check(m17hip_ctx_create(device, max_channels, max_samples, &ctx_), "m17hip_ctx_create");
         static bool warned = false;
         if ((m17hip_advice(ctx_) & M17HIP_ADVICE_HW_QUEUES) && !warned) {
