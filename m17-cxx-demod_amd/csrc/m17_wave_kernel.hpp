@@ -73,22 +73,6 @@ typedef float m17_v4f __attribute__((ext_vector_type(4)));
 __device__ __noinline__ Hist3 nf_serve_limit(const float* yr, float* hr, M17_LDS float* B, uint32_t from, uint32_t to, float h0, float h1, float h2)
 {
     const uint32_t l = threadIdx.x & 63u;
-#ifdef M17_V5
-    {   // simplest form (debugging): every lane runs the chain from global memory, lane 0 stores
-        float m2s = IirCoef::a2 * h1;
-        for (uint32_t i = from; i < to; ++i) {
-            const float hn = iir_advance_pk(fabsf(yr[i]), h0, m2s);
-            h2 = h1; h1 = h0; h0 = hn;
-            if (l == 0) hr[i] = hn;
-        }
-#ifdef M17_V6
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-#else
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#endif
-        return Hist3{h0, h1, h2};
-    }
-#endif
     float nx[4];
     auto load = [&](uint32_t b) {
 #pragma unroll
@@ -307,7 +291,6 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // wave's state).  While diverged, s.h0..h2 = the filter's history after the last sample served / fed.
     unsigned long long n_despec = 0;
     bool diverged = false;
-    unsigned long long n_serve = 0, served = 0, tt_div = 0, cnt_div = 0;
     uint32_t h_until = P.T;   // hbuf holds this channel's true history for every fed sample below this (relative) index
     auto pick_hist = [&](uint32_t tt) {   // the history after sample tt, from hbuf (tt < h_until)
         s.h0 = hrow[(int64_t)tt]; s.h1 = hrow[(int64_t)tt - 1]; s.h2 = hrow[(int64_t)tt - 2];
@@ -315,19 +298,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     bool left_replay = false;   // a forced unlock fell into THIS segment: the replay that is (or was) run for it ends in a state that is not this channel's
     auto despec = [&](uint32_t tt) {      // tt: the sample being processed; s.count already counts it
         if (s.spec_ok) left_replay = true;
-#ifdef M17_V3
-        if (s.spec_ok) { ++n_despec; pick_hist(tt); s.spec_ok = 0; }
-        if (false) {
-#else
         if (s.spec_ok && !diverged) {
-#endif
             ++n_despec;
-            diverged = true; tt_div = tt; cnt_div = s.count;
-#ifdef M17_DBG_A
-            h_until = tt + 1u; pick_hist(tt);
-#else
+            diverged = true;
             h_until = min(P.T, tt + (960u - min((uint32_t)s.count, 960u)) + 1u);
-#endif
         }
     };
     auto sw_triggered = [&](int w) -> float {  // Correlator.h:150-157
@@ -531,19 +505,16 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     while (t < P.T) {
         bool decode_due = false, tail_dcd = false;
         uint32_t te = 0;
-#ifndef M17_V1
         if (diverged && t >= h_until && (s.initializing || s.dcd_on)) {
             // every sample up to the next update point (the end of the initialisation run) will be fed whatever happens: serve them
             const unsigned long long q0 = now();
             const uint32_t fed_end = min(P.T, t + (s.initializing ? (uint32_t)s.initializing : 960u - min((uint32_t)s.count, 959u)));
             hpf_ready(); hpf_base = -0x40000000; hw_base = 0x40000000;   // the staging block is the decoder's array; windows of hbuf are stale now
-            ++n_serve; served += fed_end - t;
             const Hist3 r = nf_serve_limit(yr, const_cast<float*>(hrow), as_lds(reinterpret_cast<float*>(DL.soft)), t, fed_end, s.h0, s.h1, s.h2);
             s.h0 = r.h0; s.h1 = r.h1; s.h2 = r.h2;
             h_until = fed_end;
             tk_iir += now() - q0;
         }
-#endif
         // ---- carrier off: nothing happens until the next DCD update point (:675-689) -> jump there ----------------------
         if (!s.initializing && !s.dcd_on) {
             const unsigned long long f0 = now();
@@ -566,12 +537,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     s.need_clock_reset = 1;
                     s.run_pos = 0;  // a new gated run starts with the next sample
                     if (t < P.T) patch_run_start(t);
-#ifndef M17_V2
                     if (diverged) {   // the history the run inherits, where its first samples will look for it (K2's convention)
                         if (wl == 0) { float* hw = const_cast<float*>(hrow); hw[(int64_t)te] = s.h0; hw[(int64_t)te - 1] = s.h1; hw[(int64_t)te - 2] = s.h2; }
                         h_until = t;
                     }
-#endif
                 }
                 dcd_update_at(te);
                 fire_diag(te, 0.f);
@@ -1029,9 +998,6 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         else if (s.initializing || s.dcd_on) pick_hist(P.T - 1u);   // (gate off: the history was picked where it froze)
     }
     if (P.dropped && wl == 0) P.dropped[c] = left_replay ? 1u : 0u;
-#ifdef M17_DBGCNT
-    if (!PROF && !TIMED && P.dbg && wl == 0) { P.dbg[(size_t)c * 24 + 23] = n_serve | ((unsigned long long)diverged << 32) | ((unsigned long long)h_until << 33) | (n_despec << 56); P.dbg[(size_t)c * 24 + 22] = served | (tt_div << 24) | (cnt_div << 48); }
-#endif
     s.store(as_lds(hot_lds));
     wave_lds_sync();
     {

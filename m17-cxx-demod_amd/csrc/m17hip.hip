@@ -1312,9 +1312,6 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         // the CU (24 KB, 128 VGPRs per SIMD) is where a K2 wave or a K1 workgroup runs beside them without taking a K5 slot
         const size_t lds = std::max((size_t)wave_lds_words((int)wpb) * 4, c->seq_lds_bytes ? (size_t)c->seq_lds_bytes : (wpb == 4 ? (size_t)SEQ_LDS_BYTES_4 : (size_t)0));
         P.dbg = (c->profile || (c->wave_times && wpb == 4)) ? c->dbg : nullptr;
-#ifdef M17_DBGCNT
-        P.dbg = c->dbg; c->dbg_waves = C;
-#endif
         if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P);
         else if (c->wave_times && wpb == 4) hipLaunchKernelGGL((demod_wave_kernel<4, false, true>), grid, block, lds, c->stream, P);
         else switch (wpb) {
