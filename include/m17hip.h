@@ -307,6 +307,12 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * waves on a SIMD, which is worth 9 % of the step with two batches in flight), 0 = straight-line tap loop (167 VGPRs), 2 = rolled with
  * 11 outputs per lane (62 VGPRs; measured slower than 1).  key 14: LDS bytes a workgroup of the sequential kernel asks for (0 = default:
  * 34 816, which makes a CU hold four of them and leaves 24 KB and 128 VGPRs per SIMD to the kernels running beside them).
+ * key 19 (diagnostics): 1 = the sequential kernel (four-wave form) records every wave's working time per segment in 10 ns ticks, bit 62
+ * = the wave served itself: m17hip_debug_counters slot k = segment k.  key 20: what happens after a forced dcd.unlock() took a channel
+ * off the limit-filter replay: 1 (default) = the channel serves itself for the rest of that segment and the next one while the replay's
+ * state is re-derived beside the sequential kernel; 0 = the replay is redone between two launches of the sequential kernel (rounds 1-2).
+ * key 21: the matched filter of a STAGED run (m17hip_demod_front) starts after the sequential kernel of this segment (1-based) of the run
+ * before it (0 = at once, the default: every delay measured slower).
  * key 16 (not a performance knob): 1 = m17hip_upload_i16, m17hip_upload_i16_device and m17hip_synth_i16 write the context's STAGING slab
  * (as m17hip_upload_i16_async does, but complete when they return) and stage it for the next run; 0 (default) = the current slab.
  * key 15: 1 (default) = the sequential kernel leaves the payload frames of running stream / BERT transmissions undecoded (LLRs to a

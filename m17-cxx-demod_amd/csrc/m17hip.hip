@@ -67,6 +67,8 @@ struct m17hip_ctx {
     size_t synth_bytes = 0;
     uint32_t runT = 0;                // samples of the latest run
     int redo_mode = 1;                // tuning knob 20
+    uint32_t front_k1_after = 0;      // tuning knob 21: the matched filter of a staged run starts after K5 of this segment (1-based) of the run before it; 0 = at once
+    uint32_t last_nseg = 0;           // segments of the latest run
     bool wave_times = false;          // tuning knob 19: K5 writes each wave's working time per segment (m17hip_debug_counters)
     uint32_t stagedC = 0, stagedT = 0;
     uint32_t slabC[2] = {0, 0}, slabT[2] = {0, 0};   // what the input slab of each pair holds (m17hip_input_alternate)
@@ -1149,6 +1151,10 @@ int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_in_ready, 0));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_mark, 0));
     }
+    if (c->front_k1_after && c->have_run && c->last_nseg) {   // K1 out of the way of the previous run's first (heaviest) K5 launches
+        const uint32_t j = std::min(c->front_k1_after, c->last_nseg) - 1u;
+        HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_seq_[c->slot ^ 1][j], 0));
+    }
     const SegPlan sp(c, T);
     int r = ensure_seg_events(c, c->slot, sp.nseg);
     if (r) return r;
@@ -1348,7 +1354,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     HIPCHK(c, hipEventRecord(c->ev_end[q], c->stream));
     c->slot_used[q] = true;
     c->pos += T;
-    c->lastC = C; c->lastT = T; c->runT = T;
+    c->lastC = C; c->lastT = T; c->runT = T; c->last_nseg = nseg;
     c->have_run = true;
     c->recs_valid = true;
     return M17HIP_OK;
@@ -1802,6 +1808,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         if (value < 0 || value > (int64_t)c->rec_cap_alloc) return M17HIP_EINVAL;
         c->rec_cap = value ? (uint32_t)value : c->rec_cap_alloc;
         c->recs_valid = false;   // the slots of the last run were written with the old stride: nothing to fetch until the next run
+        return M17HIP_OK;
+    case 21:  // the matched filter of a staged run waits for K5 of this segment (1-based) of the run before it (0 = starts at once)
+        if (value < 0 || value > 1000) return M17HIP_EINVAL;
+        c->front_k1_after = (uint32_t)value;
         return M17HIP_OK;
     case 20:  // redo policy: 1 = beside K5, state only (default); 0 = on the main stream ahead of K5, with the history stored
         if (value != 0 && value != 1) return M17HIP_EINVAL;

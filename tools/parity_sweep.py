@@ -2,12 +2,14 @@
 many seeds, both limit-filter modes, several segment lengths; prints the channels whose records or diagnostics differ from the oracle.
 Usage: parity_sweep.py <first seed> <n seeds>"""
 import sys, os, numpy as np
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import oracle_lib as ol
 C, T = 64, 96000
 DUMP = len(sys.argv) > 3 and sys.argv[3] == 'dump'   # write the input of the first seed to tools/x_dbg.npy (no GPU needed) and stop
 if not DUMP:
+    import torch   # before libm17hip.so initialises the system HIP runtime (torch carries its own; tests/conftest.py)
     import m17hip
     ctx = m17hip.Context(C, T)
 total_bad = 0
@@ -29,19 +31,37 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
         np.save(os.path.join(ROOT, 'tools', 'x_dbg.npy'), x); print('wrote tools/x_dbg.npy, invert =', inv); sys.exit(0)
     recs, counts, diags = ol.demod_batch(x, invert=inv, cap=2 * (T // 1920 + 2) + 4, threads=os.cpu_count())
     cuts = sorted(int(v) for v in rng.integers(1, T, size=2))
-    for spec, seg, pieces in ((1, 19200, None), (1, int(rng.integers(3000, 30000)), None), (0, 0, None), (1, 19200, [0] + cuts + [T]), (0, 0, [0] + cuts + [T])):
-        ctx.tune(2, spec); ctx.tune(3, seg); ctx.reset()
+    rseg = int(rng.integers(3000, 30000))
+    # (limit filter ahead, segment length, run boundaries, redo policy [m17hip_tune 20], staged + m17hip_demod_front)
+    for spec, seg, pieces, redo, piped in ((1, 19200, None, 1, 0), (1, rseg, None, 1, 0), (1, rseg, None, 0, 0), (0, 0, None, 1, 0), (1, 19200, [0] + cuts + [T], 1, 0),
+                                           (1, 19200, [0] + cuts + [T], 1, 1), (1, rseg, [0] + cuts + [T], 0, 1), (0, 0, [0] + cuts + [T], 1, 0)):
+        ctx.tune(2, spec); ctx.tune(3, seg); ctx.tune(20, redo); ctx.reset()
         if pieces is None:
             ctx.upload(x); ctx.run(flags=inv); got = ctx.frames()
-        else:   # the same stream as three runs (state, filter history and DCD sums carried between them)
+        elif not piped:   # the same stream as three runs (state, filter history and DCD sums carried between them)
             parts = []
             for a, b in zip(pieces[:-1], pieces[1:]):
                 if b > a:
                     ctx.upload(x[:, a:b]); ctx.run(flags=inv); parts.append(ctx.frames().copy())
             got = np.concatenate(parts); got = got[np.lexsort((got['seq'], got['channel']))]
+        else:             # ... staged in the second slab pair, the front end of each run queued before the previous run's records are fetched
+            import torch
+            spans = [(a, b) for a, b in zip(pieces[:-1], pieces[1:]) if b > a]
+            pins = [torch.from_numpy(np.ascontiguousarray(x[:, a:b])).pin_memory() for a, b in spans]
+            parts = []
+            ctx.upload_async(pins[0].data_ptr(), C, spans[0][1] - spans[0][0]); ctx.run(flags=inv, channels=C, samples=spans[0][1] - spans[0][0])
+            for i in range(len(spans)):
+                if i + 1 < len(spans):
+                    n1 = spans[i + 1][1] - spans[i + 1][0]
+                    ctx.upload_async(pins[i + 1].data_ptr(), C, n1); ctx.front(flags=inv, channels=C, samples=n1)
+                parts.append(ctx.frames().copy())
+                if i + 1 < len(spans):
+                    ctx.run(flags=inv, channels=C, samples=n1)
+            ctx.upload_wait()
+            got = np.concatenate(parts); got = got[np.lexsort((got['seq'], got['channel']))]
         d = ctx.diag()
         bad = [c for c in range(C) if got[got['channel'] == c].tobytes() != recs[c, :counts[c]].tobytes()
                or any(not np.array_equal(d[f][c:c + 1], diags[f][c:c + 1], equal_nan=True) for f in d.dtype.names if f in diags.dtype.names)]
         total_bad += len(bad)
-        print(f'seed {seed} invert={inv} limit_ahead={spec} seg={seg} runs={"1" if pieces is None else pieces}: frames {int(counts.sum())}, bad channels {bad}', flush=True)
+        print(f'seed {seed} invert={inv} limit_ahead={spec} seg={seg} redo={redo} piped={piped} runs={"1" if pieces is None else pieces}: frames {int(counts.sum())}, bad channels {bad}', flush=True)
 print('TOTAL bad channel-runs:', total_bad)
