@@ -23,7 +23,7 @@ def row(c):
     t = d[c]
     return (f"ch {c:5d}: total {t[0]/1e5:6.2f} ms | bulk {t[1]/1e5:5.2f} (ens {t[12]/1e5:4.2f} sym {t[13]/1e5:4.2f} iir/serve {t[14]/1e5:4.2f}) search {t[15]/1e5:5.2f} single {t[2]/1e5:5.2f} "
             f"decode {t[3]/1e5:5.2f} patch {t[8]/1e5:4.2f} off {t[16]/1e5:4.2f} | #bulk {int(t[4]):5d} #single {int(t[5]):5d} bulk_samples {int(t[6]):6d} #dec {int(t[7]) >> 32:3d} drops {int(t[17])}"
-            f" | singles by state U/L/S/P/B/W/F {[int(x) for x in t[18:24]]}")
+            f" | singles by state L/S/P/B/W/F {[int(x) for x in t[19:24]]} | (experiment build) single-step parts: pre {t[18]/1e5:4.2f} lim {t[9]/1e5:4.2f} upd {t[10]/1e5:4.2f} clk {t[11]/1e5:4.2f}")
 print(f"first {T} samples of a run in the stream regime, one launch, PROF build; median {np.median(tot):.2f} ms, p99 {np.percentile(tot, 99):.2f}, max {tot.max():.2f}")
 for c in order[:6]:
     print(row(int(c)))
