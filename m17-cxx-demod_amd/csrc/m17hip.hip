@@ -729,13 +729,13 @@ static int stage_prepare(m17hip_ctx* c)
             if (e != hipSuccess) { c->last_hip = (int)e; return e == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP; }
             return M17HIP_OK;
         };
-        int r;
-        if ((r = alloc((void**)&c->yalt, (size_t)c->maxC * c->ypitch * sizeof(float)))) return r;
-        if ((r = alloc((void**)&c->halt, (size_t)c->maxC * c->ypitch * sizeof(float)))) return r;
-        if ((r = alloc((void**)&c->dcd_alt, (size_t)c->maxC * c->ticks_cap * 12 * sizeof(float)))) return r;
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_in_ready, hipEventDisableTiming));
+        int r;   // (a call that failed half way is picked up where it stopped: nothing is allocated twice)
+        if (!c->yalt && (r = alloc((void**)&c->yalt, (size_t)c->maxC * c->ypitch * sizeof(float)))) return r;
+        if (!c->halt && (r = alloc((void**)&c->halt, (size_t)c->maxC * c->ypitch * sizeof(float)))) return r;
+        if (!c->dcd_alt && (r = alloc((void**)&c->dcd_alt, (size_t)c->maxC * c->ticks_cap * 12 * sizeof(float)))) return r;
+        if (!c->copy) HIPCHK(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+        if (!c->ev_copy) HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+        if (!c->ev_in_ready) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in_ready, hipEventDisableTiming));
         if ((r = alloc((void**)&c->xstage, (size_t)c->maxC * c->xpitch * sizeof(int16_t)))) return r;   // last: its presence says "all of it is there"
     }
     return M17HIP_OK;
