@@ -29,6 +29,7 @@ extern "C" {
 #define M17HIP_EOVERFLOW (-5) /* a per-channel frame-record buffer overflowed */
 #define M17HIP_ETRUNC (-6)   /* more results than the caller's capacity: *count says how many exist, `capacity` were written */
 #define M17HIP_ECOMM (-7)    /* an RCCL call failed (m17hip_gather_*) */
+#define M17HIP_ETIMEOUT (-8) /* the persistent kernels' hand-over timed out: the run's results are void (m17hip_tune key 22 = 0 runs without them) */
 
 /* Frame-type / sync-type codes = the reference enums M17FrameDecoder.h:52-55. */
 enum { M17_FRAME_LSF = 0, M17_FRAME_LICH = 1, M17_FRAME_STREAM = 2, M17_FRAME_BASIC_PACKET = 3, M17_FRAME_FULL_PACKET = 4, M17_FRAME_BERT = 5 };
@@ -84,6 +85,11 @@ void m17hip_ctx_destroy(m17hip_ctx* ctx);
  * 42 instead of 26 ms per step).  Export GPU_MAX_HW_QUEUES=16 before the first HIP call of the process. */
 #define M17HIP_ADVICE_HW_QUEUES 1
 int m17hip_advice(const m17hip_ctx* ctx);
+/* The persistent form of the replay / sequential kernels (m17hip_tune key 22): out[0] = waves of the sequential kernel that gave up
+ * waiting for their replay wave since the last reset (any: the run is void, the fetch calls return M17HIP_ETIMEOUT), out[1] = segment
+ * boundaries at which the replay went on without waiting any longer for a channel's sequential wave (harmless: that channel computes
+ * its own limit-filter history until the replay has caught up with it).  Waits for the work queued so far. */
+int m17hip_persist_stats(m17hip_ctx* ctx, uint32_t out[2]);
 /* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = the default stream). */
 int m17hip_set_stream(m17hip_ctx* ctx, void* hip_stream);
 
@@ -306,13 +312,21 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * key 13: form of the matched filter K1: 1 = rolled tap loop, 95 VGPRs (default: a workgroup of it fits beside the sequential kernel's
  * waves on a SIMD, which is worth 9 % of the step with two batches in flight), 0 = straight-line tap loop (167 VGPRs), 2 = rolled with
  * 11 outputs per lane (62 VGPRs; measured slower than 1).  key 14: LDS bytes a workgroup of the sequential kernel asks for (0 = default:
- * 34 816, which makes a CU hold four of them and leaves 24 KB and 128 VGPRs per SIMD to the kernels running beside them).
+ * 34 816, which makes a CU hold four of them and leaves 128 VGPRs per SIMD and — LDS goes in 1280-byte granules — 20 KB to the kernels
+ * running beside them; the persistent form asks for 33 280 so that its replay, 22.4 KB, is among those).
  * key 19 (diagnostics): 1 = the sequential kernel (four-wave form) records every wave's working time per segment in 10 ns ticks, bit 62
  * = the wave served itself: m17hip_debug_counters slot k = segment k.  key 20: what happens after a forced dcd.unlock() took a channel
  * off the limit-filter replay: 1 (default) = the channel serves itself for the rest of that segment and the next one while the replay's
  * state is re-derived beside the sequential kernel; 0 = the replay is redone between two launches of the sequential kernel (rounds 1-2).
  * key 21: the matched filter of a STAGED run (m17hip_demod_front) starts after the sequential kernel of this segment (1-based) of the run
  * before it (0 = at once, the default: every delay measured slower).
+ * key 22: 1 = the persistent form of the replay and the sequential kernel: ONE launch of each per run, a segment boundary is a hand-over
+ * in device memory between a channel's sequential wave and the replay wave of its sixteen channels instead of a kernel boundary (same
+ * results, tests/test_gpu_parity.py, tests/test_gpu_streaming.py; needs the redo policy 1 and four waves per workgroup, otherwise the
+ * segmented form runs).  Default 0: measured slower (NOTES.md 3.4) — the replay's recurrence runs at 1.7 ms per segment beside four
+ * sequential waves on its SIMD and every channel waits for it.  key 23 / key 24: microseconds the persistent replay waits for a channel's
+ * sequential wave at a boundary before it goes on without it (default 20 000), and the sequential wave for its replay before it declares
+ * the run void (default 2 000 000; M17HIP_ETIMEOUT, m17hip_persist_stats).
  * key 16 (not a performance knob): 1 = m17hip_upload_i16, m17hip_upload_i16_device and m17hip_synth_i16 write the context's STAGING slab
  * (as m17hip_upload_i16_async does, but complete when they return) and stage it for the next run; 0 (default) = the current slab.
  * key 15: 1 (default) = the sequential kernel leaves the payload frames of running stream / BERT transmissions undecoded (LLRs to a

@@ -66,33 +66,38 @@ struct GateParams {
 constexpr int GT_LPC = 4;             // lanes per channel (cooperative loads / stores; the recurrence runs on lane 0 of them)
 constexpr int GT_CPW = 64 / GT_LPC;   // channels per wave
 constexpr int GT_F4 = TICK / 4 / GT_LPC;  // float4 per lane per tick
+constexpr int GT_LDS_FLOATS = GT_CPW * TICK + GT_CPW * 148 + 298;   // 22.9 KB
 
-__global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
+// One pass over one segment for the sixteen channels of a wave.  Per lane: `valid` = the channel takes part (stores, exports its end
+// state), `from_chain` (wave-uniform) = it starts from the replay's own state (else from K5's: P.state, or `bnd_base[c]` where the persistent form hands a
+// boundary record over).
+// `t0`, `segT`, `state_only`, `fh_off`: the segment [t0, t0 + segT) of the slabs P names (P itself stays the kernel's argument: what is derived
+// from it is re-read where it is used instead of being kept in registers), whether history values are stored, which final_h slot.
+__device__ __forceinline__ void limit_track_pass(const GateParams& P, uint32_t t0, uint32_t segT, bool state_only, size_t fh_off, uint32_t c, bool valid,
+                                                 bool from_chain, const Boundary* bnd_base, float* lds_base)
 {
+    // (the channel index opaque to the optimiser: the per-lane row addresses derived from it are computed here, per pass, instead of being
+    // hoisted out of the persistent kernel's loops and kept — spilled — across them)
+    asm volatile("" : "+v"(c));
+    from_chain = __builtin_amdgcn_readfirstlane((int)from_chain) != 0;   // (the same for every channel of a pass)
+    const Boundary* bnd = bnd_base ? bnd_base + c : nullptr;   // (bnd_base: wave-uniform)
+    const uint64_t pos0 = P.pos0 + t0;
     // matched-filter samples of the current piece, replaced IN PLACE by h0 after each of them (the recurrence reads a sample, or the
     // block of samples ahead of it, before it stores the history value over it): one 12 KB array instead of two
-    __shared__ __attribute__((aligned(16))) float yl[GT_CPW][TICK];
+    float (&yl)[GT_CPW][TICK] = *reinterpret_cast<float (*)[GT_CPW][TICK]>(lds_base);
     float (&hl)[GT_CPW][TICK] = yl;
-    __shared__ float pl[GT_CPW][148];                                   // patched first outputs of the current run
-    __shared__ float pw[298];                                           // patch window: 149 snapshot + 148 run samples
-    __builtin_amdgcn_s_setprio(3);  // K5 of the next segment waits for this kernel: issue ahead of whatever shares the SIMD
+    float (&pl)[GT_CPW][148] = *reinterpret_cast<float (*)[GT_CPW][148]>(lds_base + GT_CPW * TICK);   // patched first outputs of the current run
+    float (&pw)[298] = *reinterpret_cast<float (*)[298]>(lds_base + GT_CPW * TICK + GT_CPW * 148);      // patch window: 149 snapshot + 148 run samples
     const int lane = threadIdx.x;
     const int g = lane / GT_LPC, r = lane % GT_LPC;
-    uint32_t c = blockIdx.x * GT_CPW + g;
-    bool valid = c < P.C;
-    if (!valid) c = P.C - 1;  // shadow the last channel, never store
-    if (P.only) {
-        valid = valid && P.only[c] != 0;
-        if (!__ballot(valid)) return;   // nothing to redo for these four channels
-    }
     const bool invert = P.flags & 1u;
     // flags bit 1: a replay whose history values nobody will read (the channels K5 serves itself, m17_wave_kernel.hpp): only the
     // replay's end state is wanted, hbuf is left alone (K5 is writing those very rows)
-    const bool store = !(P.flags & 2u);
+    const bool store = !state_only;
     const SeqState* gs = P.state + c;
-    const int16_t* xr = P.x + (size_t)c * P.xpitch + XPRE;
-    const float* yr = P.y + (size_t)c * P.ypitch + YPRE;
-    float* hr = P.h + (size_t)c * P.ypitch + YPRE;
+    const int16_t* xr = P.x + (size_t)c * P.xpitch + XPRE + t0;
+    const float* yr = P.y + (size_t)c * P.ypitch + YPRE + t0;
+    float* hr = P.h + (size_t)c * P.ypitch + YPRE + t0;
     const float* tab = P.dcd_table + (size_t)c * P.ticks_cap * 12;
 
     // the gate's state (M17Demodulator members dcd_, count_, initializing; DataCarrierDetect level/trigger) and the filter
@@ -101,11 +106,14 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
     uint32_t on, trig, count, seg;
     float h0, h1, h2, level;
     bool end_in_run = false;   // the previous gated run ended inside this slab, at relative sample end_t
-    if (P.chain_in) {
+    if (from_chain) {
         const GateExport e = P.chain_in[c];
         init = e.init; on = e.on; trig = e.trig; count = e.count; run_pos = e.run_pos;
         h0 = e.h0; h1 = e.h1; h2 = e.h2; level = e.level; seg = e.seg;
         end_in_run = e.end_in_run != 0; end_t = e.end_t;
+    } else if (bnd) {
+        init = bnd->init; on = bnd->on; trig = bnd->trig; count = bnd->count; run_pos = bnd->run_pos;
+        h0 = bnd->h0; h1 = bnd->h1; h2 = bnd->h2; level = bnd->level; seg = bnd->seg;
     } else {
         init = gs->hot.initializing;
         on = gs->hot.dcd_on; trig = gs->hot.dcd_trig; count = gs->hot.count;
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
     // Started from K5's state: the three slots in front of the segment get the history it starts with.  (What is there is the
     // previous segment's or run's tail, which is void if K5 had dropped the speculation there; a replay that continues from its own
     // state finds its own output there.)
-    if (!P.chain_in && r == 0 && valid && store) { hr[-1] = h0; hr[-2] = h1; hr[-3] = h2; }
+    if (!from_chain && r == 0 && valid && store) { hr[-1] = h0; hr[-2] = h1; hr[-3] = h2; }
     bool pl_valid = false;     // pl[g] holds the patched outputs of the current run
     int32_t pl_rs = 0;         // relative index of that run's first sample
 
@@ -135,8 +143,8 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
     };
 
     uint32_t t = 0;
-    uint32_t phase = (uint32_t)(P.pos0 % TICK);
-    uint64_t k_cur = P.pos0 / TICK;   // absolute index of the tick the current piece lies in
+    uint32_t phase = (uint32_t)(pos0 % TICK);
+    uint64_t k_cur = pos0 / TICK;   // absolute index of the tick the current piece lies in
     float4 pre[GT_F4];         // this lane's share of a tick of matched-filter samples, loaded one tick ahead
 #pragma unroll
     for (int b = 0; b < GT_F4; ++b) pre[b] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         float4* dst = reinterpret_cast<float4*>(&yl[g][0]) + r;
 #pragma unroll
         for (int b = 0; b < GT_F4; ++b) dst[GT_LPC * b] = pre[b];
-        if (t + 2 * TICK <= P.T) {
+        if (t + 2 * TICK <= segT) {
 #pragma unroll
             for (int b = 0; b < GT_F4; ++b) pre[b] = src[TICK / 4 + GT_LPC * b];
             pre_t = t + TICK;
@@ -188,12 +196,12 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
             if (b % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // three 16-byte rows in flight at a time (not all twelve: registers)
         }
     };
-    while (t < P.T) {
+    while (t < segT) {
         // ---- steady state: every channel of the wave is inside a gated run, past its first 148 samples, and this tick holds
         //      no update point — nothing but the filter -------------------------------------------------------------------------
         {
             const bool steady = init <= 0 && on != 0 && run_pos >= 148 && count + TICK < 960u;
-            if (phase == 0 && t + TICK <= P.T && ((P.pos0 + t) & 3u) == 0 && __ballot(!steady) == 0ull) {
+            if (phase == 0 && t + TICK <= segT && ((pos0 + t) & 3u) == 0 && __ballot(!steady) == 0ull) {
                 stage_tick();
                 lds_sync();
                 if (r == 0) iir_tick();
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
                 continue;
             }
         }
-        const uint32_t n = min(TICK - phase, P.T - t);   // a piece never crosses a tick boundary
+        const uint32_t n = min(TICK - phase, segT - t);   // a piece never crosses a tick boundary
         const bool feed = init > 0 || on;
         // ---- first 148 outputs of a gated run: FIR over (snapshot of the previous run's tail | this run's samples) ------------
         const bool need_patch = feed && run_pos < 148 && !pl_valid;
@@ -220,17 +228,18 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
                 const int32_t rs = (int32_t)t - rp;           // relative index of the run's first sample (>= -148)
                 const bool eir = __shfl((int)end_in_run, src);
                 const int32_t et = __shfl(end_t, src);
-                const int16_t* xrc = P.x + (size_t)cc * P.xpitch + XPRE;
-                const int16_t* hist = P.state[cc].hist;
+                const int16_t* xrc = P.x + (size_t)cc * P.xpitch + XPRE + t0;
+                const Boundary* bsrc = (!from_chain && bnd_base) ? bnd_base + cc : nullptr;   // (both wave-uniform)
+                const int16_t* hist = bsrc ? bsrc->hist : P.state[cc].hist;
                 for (int k = lane; k < 149; k += 64) {
                     const int sv = eir ? (int)xrc[(int64_t)et - 148 + k] : (int)hist[k];
                     pw[k] = scale_sample(sv, invert);
                 }
                 for (int k = lane; k < 148; k += 64)
-                    if ((int64_t)rs + k < (int64_t)P.T) pw[149 + k] = scale_sample((int)xrc[(int64_t)rs + k], invert);
+                    if ((int64_t)rs + k < (int64_t)segT) pw[149 + k] = scale_sample((int)xrc[(int64_t)rs + k], invert);
                 lds_sync();
                 for (int j = rp + lane; j < 148; j += 64) {
-                    if ((int64_t)rs + j >= (int64_t)P.T) break;
+                    if ((int64_t)rs + j >= (int64_t)segT) break;
                     float acc = 0.f;
                     for (int i = 0; i < NTAPS; ++i) {          // FirFilter.h:36-40: newest sample first
                         const float p = pw[149 + j - i] * P.taps[i];
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         if (__ballot(feed)) {
             // whole aligned ticks without patched outputs: 16-byte loads, issued one tick ahead
             const bool overlay = feed && pl_valid && (int32_t)t - pl_rs < 148;
-            const bool fast = n == TICK && ((P.pos0 + t) & 3u) == 0 && !__ballot(overlay);
+            const bool fast = n == TICK && ((pos0 + t) & 3u) == 0 && !__ballot(overlay);
             if (fast) {
                 stage_tick();
             } else {
@@ -330,13 +339,84 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         if (phase + n == TICK) { phase = 0; ++k_cur; } else phase += n;
     }
     if (r == 0 && valid) {
-        float* f = P.final_h + (size_t)c * 4;
+        float* f = P.final_h + fh_off + (size_t)c * 4;
         f[0] = h0; f[1] = h1; f[2] = h2;
         GateExport e;
         e.init = init; e.on = on; e.trig = trig; e.count = count; e.run_pos = run_pos;
         e.h0 = h0; e.h1 = h1; e.h2 = h2; e.level = level; e.seg = seg;
-        e.end_in_run = end_in_run ? 1 : 0; e.end_t = end_t - (int32_t)P.T;
+        e.end_in_run = end_in_run ? 1 : 0; e.end_t = end_t - (int32_t)segT;
         P.chain_out[c] = e;
+    }
+}
+
+__global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
+{
+    __builtin_amdgcn_s_setprio(3);  // K5 of the next segment waits for this kernel: issue ahead of whatever shares the SIMD
+    const int lane = threadIdx.x;
+    uint32_t c = blockIdx.x * GT_CPW + lane / GT_LPC;
+    bool valid = c < P.C;
+    if (!valid) c = P.C - 1;  // shadow the last channel, never store
+    if (P.only) {
+        valid = valid && P.only[c] != 0;
+        if (!__ballot(valid)) return;   // nothing to redo for these sixteen channels
+    }
+    __shared__ __attribute__((aligned(16))) float lds_static[GT_LDS_FLOATS];
+    limit_track_pass(P, 0u, P.T, (P.flags & 2u) != 0, 0, c, valid, P.chain_in != nullptr, nullptr, lds_static);
+}
+
+// The persistent form (PersistParams, m17_state.hpp): one launch replays segments 1 .. nseg - 1 of a run (segment 0 is replayed from
+// K5's state before anything of the run starts).  Step k stores the history of segment k + 1; before it, the channels that left the
+// replay in segment k - 1 are redone over segment k from the state K5 published at that boundary (end state only).
+// (its LDS is dynamic — GT_LDS_FLOATS floats — so that the register budget follows the waves-per-SIMD attribute and not what the compiler
+// makes of a static allocation: inlined into the loop the pass was given 205 VGPRs, and the kernel has to fit into the 128 that four K5
+// waves leave of a SIMD)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void limit_track_persist_kernel(GateParams P0, PersistParams R)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x;
+    const int r = lane % GT_LPC;
+    uint32_t c = blockIdx.x * GT_CPW + lane / GT_LPC;
+    const bool valid = c < P0.C;
+    if (!valid) c = P0.C - 1;
+    uint32_t basis = 0;   // the replay is this channel's own unless the channel left it in a segment >= basis
+    for (uint32_t k = 0; k + 1 < R.nseg; ++k) {
+        bool redo = false;
+        if (k >= 1) {
+            const unsigned long long t_wait = wall_clock64();
+            unsigned long long w;
+            uint32_t cw = c;
+            asm volatile("" : "+v"(cw));   // (as below)
+            for (;;) {
+                w = persist_load(R.k5_word + cw);
+                const bool here = !valid || ((uint32_t)(w >> 32) == R.serial && ((uint32_t)w >> 16) >= k);
+                if (!__ballot(!here)) break;
+                if (wall_clock64() - t_wait > R.k2_wait) {
+                    if (lane == 0) atomicAdd(R.stats, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const bool seen = valid && (uint32_t)(w >> 32) == R.serial && ((uint32_t)w >> 16) >= k;
+            redo = seen && ((uint32_t)w & 0xFFFFu) == k;   // left the replay in segment k - 1 (a later boundary's word hides that: the channel then waits for its turn)
+        }
+        for (int pass = __ballot(redo) ? 0 : 1; pass < 2; ++pass) {
+            const uint32_t sgm = k + (uint32_t)pass;
+            const uint32_t t0 = R.t0(sgm);
+            limit_track_pass(P0, t0, R.t0(sgm + 1u) - t0, pass == 0, (size_t)(sgm & 1u) * R.maxC * 4, c, pass == 0 ? redo : valid, pass == 1,
+                             pass == 0 ? R.bnd + (size_t)(k & 1u) * R.maxC : nullptr, lds_dyn);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the end state goes through memory (chain_out -> chain_in), other lanes read it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (redo) basis = k;
+        {   // (indices opaque: the two addresses are computed here, not hoisted out of the loop and spilled)
+            uint32_t ci = c, bi = blockIdx.x;
+            asm volatile("" : "+v"(ci), "+s"(bi));
+            if (r == 0 && valid) R.basis[(size_t)((k + 1u) & 1u) * R.maxC + ci] = basis;
+            persist_publish(R.gate_word + bi, ((unsigned long long)R.serial << 32) | (k + 1u), true, lane == 0);
+        }
     }
 }
 

@@ -131,6 +131,53 @@ struct SeqParams {
     uint32_t* defer;          // optional [C][rec_cap][46]: LLR frames (nibbles) whose decoding is deferred to decode_deferred_kernel (nullptr: none is)
 };
 
+// ---- The persistent forms of K2 and K5 (m17hip_tune key 22): ONE launch of each per run, every segment boundary a hand-over in memory
+// instead of a kernel boundary, so that a channel is held up by the sixteen channels of its own replay wave only and not by the slowest
+// of all of them.  (Agent-scope release / acquire around 8-byte words; the words carry the run's serial number, nothing is ever cleared.)
+//   K5 -> K2  k5_word[c]   = serial << 32 | segments finished << 16 | (last segment in which the channel left the replay) + 1
+//             bnd[b & 1][c] = what a replay needs of the channel's state at boundary b (after segment b - 1), written only where the
+//                             channel left the replay in that segment
+//   K2 -> K5  gate_word[w] = serial << 32 | number of segments whose history is stored (wave w = channels 16 w .. 16 w + 15)
+//             basis[s & 1][c] = the history of segment s is this channel's own unless it left the replay in a segment >= basis
+// K2 never waits for K5 longer than `k2_wait` (it then goes on with what it has: the channels concerned serve themselves), K5 waits for K2
+// only, and K2 is launched first: whatever the order in which the hardware runs the two, both end.
+struct Boundary {
+    int32_t init;
+    uint32_t on, trig, count;
+    int32_t run_pos;
+    float h0, h1, h2, level;
+    uint32_t seg;
+    int16_t hist[150];
+};
+struct PersistParams {
+    unsigned long long* k5_word;     // [C]
+    unsigned long long* gate_word;   // [(C + 15) / 16]
+    uint32_t* basis;                 // [2][maxC]
+    Boundary* bnd;                   // [2][maxC]
+    uint32_t* stats;                 // [0] K2 went on without a channel's boundary, [1] K5 gave up waiting (the run is void)
+    uint32_t maxC, serial;
+    uint32_t nseg, seg0, seg_len, T; // segment k = samples [t0(k), t0(k + 1)) of the run
+    uint32_t k2_wait, k5_wait;       // 10 ns ticks
+    __device__ __forceinline__ uint32_t t0(uint32_t k) const { return k == 0 ? 0u : min(T, seg0 + (k - 1u) * seg_len); }
+};
+__device__ __forceinline__ unsigned long long persist_load(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every lane's stores first, then ONE lane: release, and the word (the asm waits are not redundant: the compiler may drop the fence's own)
+__device__ __forceinline__ void persist_publish(unsigned long long* p, unsigned long long v, bool with_data, bool writer)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (writer) {
+        if (with_data) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // LDS words for a wave of `ls` channels: ring, sync samples, llr, hist, outb, lsf columns; edges, src maps, lich map
 
 __device__ __constant__ const float SW_MAG1[4] = {29.f, 31.f, 31.f, 31.f};

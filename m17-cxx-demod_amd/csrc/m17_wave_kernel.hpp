@@ -112,13 +112,16 @@ __device__ __noinline__ Hist3 nf_serve_limit(const float* yr, float* hr, M17_LDS
 
 // PROF: compile the 100 MHz section timers and counters in (diagnostics, tools/seq_ablate.py); the production
 // instantiation carries none of them.
-template <int WPB, bool PROF = false, bool TIMED = false>
-__global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(SeqParams P)
+// PERSIST: the whole run in ONE launch (m17hip_tune key 22, PersistParams in m17_state.hpp): the wave goes through the segments one after the
+// other exactly as the launches of the segmented form do (state saved and reloaded at every boundary), but what it waits for at a boundary
+// is the replay wave of its own sixteen channels, not the end of a launch.
+template <int WPB, bool PROF = false, bool TIMED = false, bool PERSIST = false>
+__global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(SeqParams P0, PersistParams R)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     float* edges = reinterpret_cast<float*>(lds);                        // [64] llr table edges (43 used)
-    for (int k = threadIdx.x; k < 43; k += 64 * WPB) edges[k] = P.llr_edges[k];
-    const float* taps = P.taps;                                          // [149] RRC taps (slow-FIR patch: rare, read where they are)
+    for (int k = threadIdx.x; k < 43; k += 64 * WPB) edges[k] = P0.llr_edges[k];
+    const float* taps = P0.taps;                                         // [149] RRC taps (slow-FIR patch: rare, read where they are)
     __syncthreads();  // the only block-level barrier: the waves of a block are independent from here on
 
     // the wave index is wave-uniform: tell the compiler, so that the channel's state, pointers and every branch of the state
@@ -130,7 +133,37 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // kept — spilled — for the whole kernel
     auto cold_lane = [&]() -> int { int l = wl; asm volatile("" : "+v"(l)); return l; };
     const uint32_t c = blockIdx.x * WPB + wave;
-    if (c >= P.C) return;
+    if (c >= P0.C) return;
+    int32_t last_drop = -1;   // PERSIST: the last segment of this run in which the channel left the replay
+    for (uint32_t sgi = 0; sgi < (PERSIST ? R.nseg : 1u); ++sgi) {
+    SeqParams P = P0;
+    bool inherit_void = false;   // PERSIST: the replay behind this segment's history did not know of the channel's last forced unlock
+    if constexpr (PERSIST) {
+        const uint32_t t0s = R.t0(sgi);
+        P.x = P0.x + t0s; P.y = P0.y + t0s; P.h = P0.h + t0s;
+        P.T = R.t0(sgi + 1u) - t0s;
+        P.pos0 = P0.pos0 + t0s;
+        P.final_h = P0.final_h + (size_t)(sgi & 1u) * R.maxC * 4;
+        P.dropped = P0.dropped + (size_t)(sgi & 1u) * R.maxC;
+        P.dropped_in = nullptr;
+        P.flags = (P0.flags & 1u) | (t0s ? 2u : 0u) | (min(sgi, 23u) << 8);
+        if (sgi) {
+            const unsigned long long* gw = R.gate_word + (c >> 4);
+            const unsigned long long t_wait = wall_clock64();
+            for (;;) {
+                const unsigned long long w = persist_load(gw);
+                const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)), lo = __builtin_amdgcn_readfirstlane((uint32_t)w);
+                if (hi == R.serial && lo >= sgi) break;
+                if (wall_clock64() - t_wait > R.k5_wait) {   // cannot happen while K2 runs at all: the run is void, say so and leave
+                    if (wl == 0) atomicAdd(R.stats + 1, 1u);
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(64);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            inherit_void = last_drop >= (int32_t)__builtin_amdgcn_readfirstlane(R.basis[(size_t)(sgi & 1u) * R.maxC + c]);
+        }
+    }
     uint32_t* wb = lds + WV_TAB_WORDS + wave * WV_WAVE_WORDS;
     float* ring = reinterpret_cast<float*>(wb);              // [80]  Correlator::buffer_
     float* swsm = ring + 80;                                 // [4][10] SyncWord::samples_
@@ -493,7 +526,9 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // A channel that left K2's replay in the previous segment finds nothing of its own in hbuf (the replay that ran ahead started from
     // a state that is not this channel's; K2 is re-deriving the replay's state from this wave's while we run): it serves itself from
     // its first sample on.  The next segment's replay is good again.
-    if (hrow && P.dropped_in && P.dropped_in[c]) {
+    bool void_in;
+    if constexpr (PERSIST) void_in = inherit_void; else void_in = hrow && P.dropped_in && P.dropped_in[c];
+    if (void_in) {
         diverged = true;
         h_until = 0;
         if ((s.initializing || s.dcd_on) && wl == 0) { float* hw = const_cast<float*>(hrow); hw[-1] = s.h0; hw[-2] = s.h1; hw[-3] = s.h2; }
@@ -1033,6 +1068,23 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         o[0] = now() - tk0; o[1] = tk_bulk; o[2] = tk_scalar; o[3] = tk_decode;
         o[4] = n_bulk; o[5] = n_scalar; o[6] = n_bulk_samples; o[7] = n_flip | (n_decode << 32);
     }
+    if constexpr (PERSIST) {
+        if (left_replay) {   // what the replay needs to take this channel up again: its state at this boundary
+            last_drop = (int32_t)sgi;
+            Boundary* b = R.bnd + (size_t)((sgi + 1u) & 1u) * R.maxC + c;
+            if (wl == 0) {
+                b->init = s.initializing; b->on = s.dcd_on; b->trig = s.dcd_trig; b->count = s.count; b->run_pos = s.run_pos;
+                b->h0 = s.h0; b->h1 = s.h1; b->h2 = s.h2; b->level = cd->dcd_level; b->seg = cd->seg_start_tick;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            const uint32_t* hs = reinterpret_cast<const uint32_t*>(gs->hist);
+            uint32_t* hd = reinterpret_cast<uint32_t*>(b->hist);
+            for (int k = wl; k < 75; k += 64) hd[k] = hs[k];
+        }
+        persist_publish(R.k5_word + c, ((unsigned long long)R.serial << 32) | ((unsigned long long)(sgi + 1u) << 16) | (unsigned long long)(uint32_t)(last_drop + 1),
+                        left_replay, wl == 0);
+    }
+    }   // segments
 }
 
 }  // namespace m17

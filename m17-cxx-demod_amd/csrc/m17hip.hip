@@ -67,6 +67,14 @@ struct m17hip_ctx {
     size_t synth_bytes = 0;
     uint32_t runT = 0;                // samples of the latest run
     int redo_mode = 1;                // tuning knob 20
+    int persist = 0;                  // tuning knob 22: K2 and K5 of a run as ONE launch each, hand-overs in memory (PersistParams, m17_state.hpp)
+    unsigned long long* k5_word = nullptr;
+    unsigned long long* gate_word = nullptr;
+    uint32_t* basis = nullptr;
+    Boundary* bnd = nullptr;
+    uint32_t persist_serial = 0;
+    uint32_t persist_skips = 0;        // boundaries the persistent K2 did not wait for (as of the last fetch)
+    uint32_t k2_wait_us = 20000, k5_wait_us = 2000000;   // tuning knobs 23 / 24
     uint32_t front_k1_after = 0;      // tuning knob 21: the matched filter of a staged run starts after K5 of this segment (1-based) of the run before it; 0 = at once
     uint32_t last_nseg = 0;           // segments of the latest run
     bool wave_times = false;          // tuning knob 19: K5 writes each wave's working time per segment (m17hip_debug_counters)
@@ -545,6 +553,7 @@ __global__ void compact_kernel(const FrameRec* recs, uint32_t rec_cap, const uin
 
 // t0: first sample of the slab to process (segment of a run); the kernels see the slab from there on
 constexpr size_t SEQ_LDS_BYTES_4 = 34816;   // see the K5 launch
+constexpr size_t SEQ_LDS_BYTES_4_PERSIST = 33280;
 int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0)
 {
     Timed tm(c, KT_FIR, st);
@@ -589,6 +598,7 @@ const char* m17hip_strerror(int code)
     case M17HIP_ENOMEM: return "out of memory";
     case M17HIP_ESTATE: return "call sequence error";
     case M17HIP_EOVERFLOW: return "frame record buffer overflow";
+    case M17HIP_ETIMEOUT: return "the persistent kernels' hand-over timed out (m17hip_tune key 22 = 0 runs without them)";
     case M17HIP_ETRUNC: return "output truncated to the caller's capacity";
     case M17HIP_ECOMM: return "RCCL communication error";
     default: return "unknown error";
@@ -639,7 +649,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->recs, C * c->rec_cap * sizeof(FrameRec));
     ALLOC(c->rec_count, C * sizeof(uint32_t));
     ALLOC(c->rec_offsets, (C + 1) * sizeof(uint64_t));
-    ALLOC(c->overflow, sizeof(uint32_t));
+    ALLOC(c->overflow, 4 * sizeof(uint32_t));   // [0] record overflow, [1] persistent K5 gave up waiting, [2] persistent K2 went on without a boundary
     ALLOC(c->tables, sizeof(DecodeTables));
     ALLOC(c->taps, 160 * sizeof(float));
     ALLOC(c->llr_edges, 64 * sizeof(float));
@@ -679,7 +689,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
         return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)decode_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (92 + 122 + 16) * 64 * 4) != hipSuccess)
         return fail(M17HIP_EHIP);
-    if (hipMemset(c->overflow, 0, 4) != hipSuccess) return fail(M17HIP_EHIP);
+    if (hipMemset(c->overflow, 0, 16) != hipSuccess) return fail(M17HIP_EHIP);
     *out = c;
     const int r = m17hip_demod_reset(c);
     if (r != M17HIP_OK) { *out = nullptr; return fail(r); }
@@ -705,7 +715,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
             for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
                     c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist,
-                    c->yalt, c->halt, c->dcd_alt, c->synth_scratch};
+                    c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->k5_word, c->gate_word, c->basis, c->bnd};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -1062,7 +1072,7 @@ int m17hip_demod_reset(m17hip_ctx* c)
         HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
     }
     HIPCHK(c, hipMemsetAsync(c->rec_count, 0, (size_t)c->maxC * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->overflow, 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->overflow, 0, 16, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));   // the front end of a staged run starts on its own streams: not before this
     c->pos = 0;
     c->have_run = false;
@@ -1253,7 +1263,77 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipGetLastError());
         return M17HIP_OK;
     };
-    for (uint32_t k = 0; k < nseg; ++k) {
+    // one wave per channel; `seq_lanes` (tuning knob 0) = waves per workgroup
+    const uint32_t wpb = (c->seq_lanes && !c->profile) ? c->seq_lanes : 4;  // the profiling build exists for 4 waves per workgroup
+    const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
+    // LDS: what the workgroup needs (31.8 KB for four waves), padded so that a CU holds FOUR of them and not five — the rest of
+    // the CU (24 KB, 128 VGPRs per SIMD) is where a K2 wave or a K1 workgroup runs beside them without taking a K5 slot
+    size_t lds = std::max((size_t)wave_lds_words((int)wpb) * 4, c->seq_lds_bytes ? (size_t)c->seq_lds_bytes : (wpb == 4 ? (size_t)SEQ_LDS_BYTES_4 : (size_t)0));
+    auto seq_params = [&](uint32_t k, uint32_t t0, uint32_t len) {
+        SeqParams P{};
+        P.h = c->speculate ? c->hbuf + t0 : nullptr; P.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
+        P.dropped = c->speculate ? drop_of[k & 1u] : nullptr;
+        P.x = c->xbuf + t0; P.xpitch = c->xpitch; P.y = c->ybuf + t0; P.ypitch = c->ypitch;
+        P.dcd_table = c->dcd_table; P.ticks_cap = c->ticks_cap; P.state = c->seq_state;
+        P.recs = c->recs; P.rec_cap = c->rec_cap; P.rec_count = c->rec_count; P.overflow = c->overflow;
+        P.tables = c->tables; P.taps = c->taps; P.llr_edges = c->llr_edges;
+        P.C = C; P.T = len; P.pos0 = c->pos + t0; P.tick_row0 = c->pos / TICK; P.flags = (flags & 1u) | (t0 ? 2u : 0u) | (std::min(k, 23u) << 8);
+        P.kalman_order = c->kalman_order; P.channel_base = c->channel_base;
+        P.diag_log = c->diag_cap ? c->diag_log : nullptr; P.diag_cap = c->diag_cap; P.diag_count = c->diag_count;
+        P.defer = c->defer_decode ? c->defer_llr : nullptr;
+        P.dbg = (c->profile || (c->wave_times && wpb == 4)) ? c->dbg : nullptr;
+        return P;
+    };
+    // The persistent form (tuning knob 22): the front end of the whole run first, the replay of segment 0 from K5's state, then ONE launch
+    // of the replay (segments 1 .. nseg - 1, on the replay stream, queued FIRST: it never waits for K5 without a bound) and ONE of K5.
+    const bool persist = c->persist && c->speculate && side_redo && wpb == 4 && !c->profile && !c->wave_times && nseg >= 2 && nseg < 60000 && ahead >= nseg;
+    if (persist) {
+        // (the persistent replay MUST find its place beside four K5 workgroups on every CU — K5's waves wait for it: LDS is handed out in
+        // 1280-byte granules, of which 34 816-byte workgroups leave 16 = 20 480 bytes, less than the replay's 22 952)
+        if (!c->seq_lds_bytes) lds = SEQ_LDS_BYTES_4_PERSIST;
+        if (!c->k5_word) {
+            const size_t mc = c->maxC;
+            HIPCHK(c, hipMalloc((void**)&c->k5_word, mc * 8));
+            HIPCHK(c, hipMalloc((void**)&c->gate_word, (mc / GT_CPW + 1) * 8));
+            HIPCHK(c, hipMalloc((void**)&c->basis, 2 * mc * 4));
+            HIPCHK(c, hipMalloc((void**)&c->bnd, 2 * mc * sizeof(Boundary)));
+            HIPCHK(c, hipMemsetAsync(c->k5_word, 0, mc * 8, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->gate_word, 0, (mc / GT_CPW + 1) * 8, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->basis, 0, 2 * mc * 4, c->stream));
+        }
+        HIPCHK(c, hipStreamWaitEvent(c->stream, ev_fir[nseg - 1], 0));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, ev_dcd[nseg - 1], 0));
+        if ((r = launch_gate(0, c->stream, false, false))) return r;
+        hipStream_t gst = c->side3, sst = c->stream;
+        HIPCHK(c, hipEventRecord(ev_redo[0], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(gst, ev_redo[0], 0));
+        PersistParams R{};
+        R.k5_word = c->k5_word; R.gate_word = c->gate_word; R.basis = c->basis; R.bnd = c->bnd; R.stats = c->overflow + 2;
+        R.maxC = c->maxC; R.serial = ++c->persist_serial;
+        R.nseg = nseg; R.seg0 = sp.seg0; R.seg_len = sp.seg_len; R.T = T;
+        R.k2_wait = c->k2_wait_us * 100u; R.k5_wait = c->k5_wait_us * 100u;
+        {
+            Timed tm(c, KT_GATE, gst);
+            GateParams G{};
+            G.x = c->xbuf; G.xpitch = c->xpitch; G.y = c->ybuf; G.ypitch = c->ypitch; G.h = c->hbuf;
+            G.dcd_table = c->dcd_table; G.ticks_cap = c->ticks_cap; G.state = c->seq_state;
+            G.final_h = c->final_h; G.chain_in = c->gate_exp; G.chain_out = c->gate_exp;
+            G.taps = c->taps; G.C = C; G.T = T; G.pos0 = c->pos; G.tick_row0 = c->pos / TICK; G.flags = flags;
+            hipLaunchKernelGGL(limit_track_persist_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), GT_LDS_FLOATS * sizeof(float), gst, G, R);
+            HIPCHK(c, hipGetLastError());
+        }
+        HIPCHK(c, hipEventRecord(ev_gate[nseg - 1], gst));
+        {
+            Timed tm(c, KT_SEQ, sst);
+            SeqParams P = seq_params(0, 0, T);
+            R.stats = c->overflow;   // K5 counts in word 1
+            hipLaunchKernelGGL((demod_wave_kernel<4, false, false, true>), grid, block, lds, sst, P, R);
+            HIPCHK(c, hipGetLastError());
+        }
+        for (uint32_t k = 0; k < nseg; ++k) HIPCHK(c, hipEventRecord(ev_seq[k], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, ev_gate[nseg - 1], 0));   // (the replay's last stores: the tails below are carried from hbuf)
+    }
+    for (uint32_t k = 0; k < nseg && !persist; ++k) {
         const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
         HIPCHK(c, hipStreamWaitEvent(c->stream, ev_fir[k], 0));
         HIPCHK(c, hipStreamWaitEvent(c->stream, ev_dcd[k], 0));
@@ -1299,32 +1379,15 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
             }
         }
         Timed tm(c, KT_SEQ);
-        SeqParams P{};
-        P.h = c->speculate ? c->hbuf + t0 : nullptr; P.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
-        P.dropped = c->speculate ? drop_of[k & 1u] : nullptr;
+        SeqParams P = seq_params(k, t0, len);
         P.dropped_in = (c->speculate && side_redo && k > 0) ? drop_of[(k - 1u) & 1u] : nullptr;
-        P.x = c->xbuf + t0; P.xpitch = c->xpitch; P.y = c->ybuf + t0; P.ypitch = c->ypitch;
-        P.dcd_table = c->dcd_table; P.ticks_cap = c->ticks_cap; P.state = c->seq_state;
-        P.recs = c->recs; P.rec_cap = c->rec_cap; P.rec_count = c->rec_count; P.overflow = c->overflow;
-        P.tables = c->tables; P.taps = c->taps; P.llr_edges = c->llr_edges;
-        P.C = C; P.T = len; P.pos0 = c->pos + t0; P.tick_row0 = c->pos / TICK; P.flags = (flags & 1u) | (t0 ? 2u : 0u) | (std::min(k, 23u) << 8);
-        P.kalman_order = c->kalman_order; P.channel_base = c->channel_base;
-        P.diag_log = c->diag_cap ? c->diag_log : nullptr; P.diag_cap = c->diag_cap; P.diag_count = c->diag_count;
-        P.defer = c->defer_decode ? c->defer_llr : nullptr;
-        // one wave per channel; `seq_lanes` (tuning knob 0) = waves per workgroup
-        const uint32_t wpb = (c->seq_lanes && !c->profile) ? c->seq_lanes : 4;  // the profiling build exists for 4 waves per workgroup
-        const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
-        // LDS: what the workgroup needs (31.8 KB for four waves), padded so that a CU holds FOUR of them and not five — the rest of
-        // the CU (24 KB, 128 VGPRs per SIMD) is where a K2 wave or a K1 workgroup runs beside them without taking a K5 slot
-        const size_t lds = std::max((size_t)wave_lds_words((int)wpb) * 4, c->seq_lds_bytes ? (size_t)c->seq_lds_bytes : (wpb == 4 ? (size_t)SEQ_LDS_BYTES_4 : (size_t)0));
-        P.dbg = (c->profile || (c->wave_times && wpb == 4)) ? c->dbg : nullptr;
-        if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P);
-        else if (c->wave_times && wpb == 4) hipLaunchKernelGGL((demod_wave_kernel<4, false, true>), grid, block, lds, c->stream, P);
+        if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P, PersistParams{});
+        else if (c->wave_times && wpb == 4) hipLaunchKernelGGL((demod_wave_kernel<4, false, true>), grid, block, lds, c->stream, P, PersistParams{});
         else switch (wpb) {
-        case 1: hipLaunchKernelGGL(demod_wave_kernel<1>, grid, block, lds, c->stream, P); break;
-        case 2: hipLaunchKernelGGL(demod_wave_kernel<2>, grid, block, lds, c->stream, P); break;
-        case 8: hipLaunchKernelGGL(demod_wave_kernel<8>, grid, block, lds, c->stream, P); break;
-        default: hipLaunchKernelGGL(demod_wave_kernel<4>, grid, block, lds, c->stream, P); break;
+        case 1: hipLaunchKernelGGL(demod_wave_kernel<1>, grid, block, lds, c->stream, P, PersistParams{}); break;
+        case 2: hipLaunchKernelGGL(demod_wave_kernel<2>, grid, block, lds, c->stream, P, PersistParams{}); break;
+        case 8: hipLaunchKernelGGL(demod_wave_kernel<8>, grid, block, lds, c->stream, P, PersistParams{}); break;
+        default: hipLaunchKernelGGL(demod_wave_kernel<4>, grid, block, lds, c->stream, P, PersistParams{}); break;
         }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(ev_seq[k], c->stream));
@@ -1376,12 +1439,14 @@ static int compact_into(m17hip_ctx* c, FrameRec* dev_out, uint64_t cap, uint64_t
         }
     }
     uint64_t total = 0;
-    uint32_t ovf = 0;
+    uint32_t ovf[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(&total, c->rec_offsets + C, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&ovf, c->overflow, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ovf, c->overflow, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (count) *count = total;
-    if (ovf) return M17HIP_EOVERFLOW;
+    c->persist_skips = ovf[2];
+    if (ovf[1]) return M17HIP_ETIMEOUT;
+    if (ovf[0]) return M17HIP_EOVERFLOW;
     if (dev_out && total > cap) return M17HIP_ETRUNC;
     return M17HIP_OK;
 }
@@ -1715,6 +1780,18 @@ int m17hip_gather_frames_device(m17hip_ctx* c, m17hip_comm* m, int root, m17_fra
 
 int m17hip_comm_last_error(const m17hip_comm* m) { return m ? m->last_rccl : 0; }
 
+int m17hip_persist_stats(m17hip_ctx* c, uint32_t out[2])
+{
+    if (!c || !out) return M17HIP_EINVAL;
+    GUARD(c);
+    uint32_t w[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(w, c->overflow, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out[0] = w[1];
+    out[1] = w[2];
+    return M17HIP_OK;
+}
+
 int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
 {
     if (!c) return M17HIP_EINVAL;
@@ -1812,6 +1889,18 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 21:  // the matched filter of a staged run waits for K5 of this segment (1-based) of the run before it (0 = starts at once)
         if (value < 0 || value > 1000) return M17HIP_EINVAL;
         c->front_k1_after = (uint32_t)value;
+        return M17HIP_OK;
+    case 22:  // persistent K2 / K5: one launch of each per run, segment boundaries handed over in memory (PersistParams, m17_state.hpp)
+        if (value != 0 && value != 1) return M17HIP_EINVAL;
+        c->persist = (int)value;
+        return M17HIP_OK;
+    case 23:  // microseconds the persistent K2 waits for a channel's K5 at a boundary before it goes on without it
+        if (value < 1 || value > 10000000) return M17HIP_EINVAL;
+        c->k2_wait_us = (uint32_t)value;
+        return M17HIP_OK;
+    case 24:  // microseconds the persistent K5 waits for its replay wave before it declares the run void (M17HIP_ETIMEOUT)
+        if (value < 1 || value > 10000000) return M17HIP_EINVAL;
+        c->k5_wait_us = (uint32_t)value;
         return M17HIP_OK;
     case 20:  // redo policy: 1 = beside K5, state only (default); 0 = on the main stream ahead of K5, with the history stored
         if (value != 0 && value != 1) return M17HIP_EINVAL;

@@ -39,7 +39,7 @@ EXPORTS = [
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_packets_fetch", "m17hip_packets_feed", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
     "m17hip_set_kalman_order", "m17hip_kalman_trace", "m17hip_set_channel_base", "m17hip_upload_wait", "m17hip_comm_get_id", "m17hip_comm_create",
     "m17hip_comm_destroy", "m17hip_comm_last_error", "m17hip_gather_frames", "m17hip_gather_frames_device", "m17hip_diag_log_fetch",
-    "m17hip_upload_i16_device_async", "m17hip_input_alternate", "m17hip_demod_front", "m17hip_advice",
+    "m17hip_upload_i16_device_async", "m17hip_input_alternate", "m17hip_demod_front", "m17hip_advice", "m17hip_persist_stats",
 ]
 ETRUNC = -6
 COMM_ID_BYTES = 128
@@ -349,6 +349,12 @@ class Context:
         r = np.ascontiguousarray(recs2d, dtype=FRAME_REC)
         n = np.ascontiguousarray(counts, dtype=np.uint32)
         self._chk(self.lib.m17hip_packets_feed(self.h, _ptr(r), _ptr(n), C.c_uint32(r.shape[0]), C.c_uint32(r.shape[1])))
+
+    def persist_stats(self):
+        """(sequential waves that gave up waiting, boundaries the replay did not wait for) — m17hip_persist_stats."""
+        out = (C.c_uint32 * 2)()
+        self._chk(self.lib.m17hip_persist_stats(self.h, out))
+        return int(out[0]), int(out[1])
 
     def tune(self, key, value):
         self._chk(self.lib.m17hip_tune(self.h, C.c_int(key), C.c_int64(value)))

@@ -23,7 +23,8 @@ def _oracle_records(x, invert=0):
     return flat, counts, diags
 
 
-@pytest.fixture(scope="module", params=[(1, 0, 1, 1), (0, 0, 1, 1), (1, 1, 0, 1), (1, 0, 1, 0)], ids=["limit_ahead", "limit_inline", "k3_pipeline_decode_in_k5", "redo_on_main_stream"])
+@pytest.fixture(scope="module", params=[(1, 0, 1, 1, 0), (0, 0, 1, 1, 0), (1, 1, 0, 1, 0), (1, 0, 1, 0, 0), (1, 0, 1, 1, 1)],
+                ids=["limit_ahead", "limit_inline", "k3_pipeline_decode_in_k5", "redo_on_main_stream", "persistent_k2_k5"])
 def ctx(request):
     """Every test runs three times: with the correlator's limit filter run ahead of the sequential kernel (K2, the default), with
     the sequential kernel carrying it itself (tuning knob 2 = 0, also the fallback of a dropped speculation), and with the
@@ -33,8 +34,10 @@ def ctx(request):
     c.tune(10, request.param[1])
     c.tune(15, request.param[2])   # payload frames decoded after the run (default) / where they complete
     c.tune(20, request.param[3])   # the replay's redo beside K5, state only (default) / on the main stream ahead of K5
+    c.tune(22, request.param[4])   # K2 and K5 of a run as one launch each, segment boundaries handed over in memory
     c.limit_ahead = bool(request.param[0])
     yield c
+    assert c.persist_stats()[0] == 0   # (persistent form: no sequential wave gave up waiting for its replay)
     c.close()
 
 

@@ -33,9 +33,11 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     cuts = sorted(int(v) for v in rng.integers(1, T, size=2))
     rseg = int(rng.integers(3000, 30000))
     # (limit filter ahead, segment length, run boundaries, redo policy [m17hip_tune 20], staged + m17hip_demod_front)
+    # redo policy 2 = the persistent form of K2 / K5 (m17hip_tune 22)
     for spec, seg, pieces, redo, piped in ((1, 19200, None, 1, 0), (1, rseg, None, 1, 0), (1, rseg, None, 0, 0), (0, 0, None, 1, 0), (1, 19200, [0] + cuts + [T], 1, 0),
-                                           (1, 19200, [0] + cuts + [T], 1, 1), (1, rseg, [0] + cuts + [T], 0, 1), (0, 0, [0] + cuts + [T], 1, 0)):
-        ctx.tune(2, spec); ctx.tune(3, seg); ctx.tune(20, redo); ctx.reset()
+                                           (1, 19200, [0] + cuts + [T], 1, 1), (1, rseg, [0] + cuts + [T], 0, 1), (0, 0, [0] + cuts + [T], 1, 0),
+                                           (1, rseg, None, 2, 0), (1, 4800, [0] + cuts + [T], 2, 1)):
+        ctx.tune(2, spec); ctx.tune(3, seg); ctx.tune(20, 1 if redo == 2 else redo); ctx.tune(22, 1 if redo == 2 else 0); ctx.reset()
         if pieces is None:
             ctx.upload(x); ctx.run(flags=inv); got = ctx.frames()
         elif not piped:   # the same stream as three runs (state, filter history and DCD sums carried between them)
@@ -64,4 +66,4 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
                or any(not np.array_equal(d[f][c:c + 1], diags[f][c:c + 1], equal_nan=True) for f in d.dtype.names if f in diags.dtype.names)]
         total_bad += len(bad)
         print(f'seed {seed} invert={inv} limit_ahead={spec} seg={seg} redo={redo} piped={piped} runs={"1" if pieces is None else pieces}: frames {int(counts.sum())}, bad channels {bad}', flush=True)
-print('TOTAL bad channel-runs:', total_bad)
+print('TOTAL bad channel-runs:', total_bad, ' persistent hand-over (gave up, went on):', ctx.persist_stats())
