@@ -55,6 +55,7 @@ struct GateParams {
     const GateExport* chain_in;   // non-null: start from the replay's own state instead (K5 has not finished the previous segment yet)
     GateExport* chain_out;        // the replay's state at the end of this segment
     const uint32_t* only;         // non-null: redo only the channels flagged here (K5 dropped the speculation in the previous segment)
+    const Boundary* bnd;          // with `only`: the flagged channels start from these records [C] instead of P.state (K5 is at work on the next segment and on that state)
     float* final_h;           // [C][4]: h0, h1, h2 after the last fed sample of this run
     const float* taps;        // 149 floats
     uint32_t C, T;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         if (!__ballot(valid)) return;   // nothing to redo for these sixteen channels
     }
     __shared__ __attribute__((aligned(16))) float lds_static[GT_LDS_FLOATS];
-    limit_track_pass(P, 0u, P.T, (P.flags & 2u) != 0, 0, c, valid, P.chain_in != nullptr, nullptr, lds_static);
+    limit_track_pass(P, 0u, P.T, (P.flags & 2u) != 0, 0, c, valid, P.chain_in != nullptr, P.only ? P.bnd : nullptr, lds_static);
 }
 
 // The persistent form (PersistParams, m17_state.hpp): one launch replays segments 1 .. nseg - 1 of a run (segment 0 is replayed from
@@ -380,6 +381,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const bool valid = c < P0.C;
     if (!valid) c = P0.C - 1;
     uint32_t basis = 0;   // the replay is this channel's own unless the channel left it in a segment >= basis
+    const unsigned long long t_start = R.k2_dbg ? wall_clock64() : 0ull;
+    unsigned long long tk_wait = 0, tk_pass[2] = {0, 0}, n_redo = 0;
     for (uint32_t k = 0; k + 1 < R.nseg; ++k) {
         bool redo = false;
         if (k >= 1) {
@@ -398,17 +401,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 __builtin_amdgcn_s_sleep(32);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (R.k2_dbg) tk_wait += wall_clock64() - t_wait;
             const bool seen = valid && (uint32_t)(w >> 32) == R.serial && ((uint32_t)w >> 16) >= k;
             redo = seen && ((uint32_t)w & 0xFFFFu) == k;   // left the replay in segment k - 1 (a later boundary's word hides that: the channel then waits for its turn)
         }
         for (int pass = __ballot(redo) ? 0 : 1; pass < 2; ++pass) {
             const uint32_t sgm = k + (uint32_t)pass;
             const uint32_t t0 = R.t0(sgm);
+            const unsigned long long t_pass = R.k2_dbg ? wall_clock64() : 0ull;
             limit_track_pass(P0, t0, R.t0(sgm + 1u) - t0, pass == 0, (size_t)(sgm & 1u) * R.maxC * 4, c, pass == 0 ? redo : valid, pass == 1,
                              pass == 0 ? R.bnd + (size_t)(k & 1u) * R.maxC : nullptr, lds_dyn);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the end state goes through memory (chain_out -> chain_in), other lanes read it
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            if (R.k2_dbg) { tk_pass[pass] += wall_clock64() - t_pass; n_redo += pass == 0; }
         }
         if (redo) basis = k;
         {   // (indices opaque: the two addresses are computed here, not hoisted out of the loop and spilled)
@@ -417,6 +423,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (r == 0 && valid) R.basis[(size_t)((k + 1u) & 1u) * R.maxC + ci] = basis;
             persist_publish(R.gate_word + bi, ((unsigned long long)R.serial << 32) | (k + 1u), true, lane == 0);
         }
+        if (R.k2_dbg && lane == 0 && k < 20u) R.k2_dbg[(size_t)blockIdx.x * 24 + 4 + k] = wall_clock64() - t_start;
+    }
+    if (R.k2_dbg && lane == 0) {
+        unsigned long long* o = R.k2_dbg + (size_t)blockIdx.x * 24;
+        o[0] = tk_wait; o[1] = tk_pass[0]; o[2] = tk_pass[1]; o[3] = n_redo;
     }
 }
 

@@ -99,6 +99,16 @@ struct SeqState {
     int16_t hist[150];          // last 149 gated FIR inputs (raw int16) at the end of the previous run
 };
 
+// What a replay needs of a channel's state at a segment boundary, written by K5 where the channel left the replay in the segment that ends
+// there (a copy: the replay that takes the channel up again runs beside K5 of the next segment, which goes on changing the state itself)
+struct Boundary {
+    int32_t init;
+    uint32_t on, trig, count;
+    int32_t run_pos;
+    float h0, h1, h2, level;
+    uint32_t seg;
+    int16_t hist[150];
+};
 struct SeqParams {
     const int16_t* x;
     size_t xpitch;
@@ -128,6 +138,7 @@ struct SeqParams {
     uint32_t* diag_count;     // [C] entries written this run
     uint32_t kalman_order;    // evaluation order of the Kalman update (kal_update)
     uint32_t channel_base;    // global id of channel 0 of this context (written into the frame records)
+    Boundary* bnd_out;        // optional [C]: boundary records for the end of this segment (m17_gate_kernel.hpp reads them)
     uint32_t* defer;          // optional [C][rec_cap][46]: LLR frames (nibbles) whose decoding is deferred to decode_deferred_kernel (nullptr: none is)
 };
 
@@ -135,20 +146,11 @@ struct SeqParams {
 // instead of a kernel boundary, so that a channel is held up by the sixteen channels of its own replay wave only and not by the slowest
 // of all of them.  (Agent-scope release / acquire around 8-byte words; the words carry the run's serial number, nothing is ever cleared.)
 //   K5 -> K2  k5_word[c]   = serial << 32 | segments finished << 16 | (last segment in which the channel left the replay) + 1
-//             bnd[b & 1][c] = what a replay needs of the channel's state at boundary b (after segment b - 1), written only where the
-//                             channel left the replay in that segment
+//             bnd[b & 1][c] = the channel's Boundary record at boundary b (after segment b - 1)
 //   K2 -> K5  gate_word[w] = serial << 32 | number of segments whose history is stored (wave w = channels 16 w .. 16 w + 15)
 //             basis[s & 1][c] = the history of segment s is this channel's own unless it left the replay in a segment >= basis
 // K2 never waits for K5 longer than `k2_wait` (it then goes on with what it has: the channels concerned serve themselves), K5 waits for K2
 // only, and K2 is launched first: whatever the order in which the hardware runs the two, both end.
-struct Boundary {
-    int32_t init;
-    uint32_t on, trig, count;
-    int32_t run_pos;
-    float h0, h1, h2, level;
-    uint32_t seg;
-    int16_t hist[150];
-};
 struct PersistParams {
     unsigned long long* k5_word;     // [C]
     unsigned long long* gate_word;   // [(C + 15) / 16]
@@ -158,6 +160,7 @@ struct PersistParams {
     uint32_t maxC, serial;
     uint32_t nseg, seg0, seg_len, T; // segment k = samples [t0(k), t0(k + 1)) of the run
     uint32_t k2_wait, k5_wait;       // 10 ns ticks
+    unsigned long long* k2_dbg;      // optional [(C + 15) / 16][24] (m17hip_tune key 19): per replay wave, 10 ns ticks: [0] waiting, [1] redo passes, [2] ahead passes, [3] redo passes made, [4 + k] end of step k since the wave's start
     __device__ __forceinline__ uint32_t t0(uint32_t k) const { return k == 0 ? 0u : min(T, seg0 + (k - 1u) * seg_len); }
 };
 __device__ __forceinline__ unsigned long long persist_load(const unsigned long long* p)

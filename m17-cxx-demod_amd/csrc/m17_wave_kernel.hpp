@@ -146,6 +146,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         P.final_h = P0.final_h + (size_t)(sgi & 1u) * R.maxC * 4;
         P.dropped = P0.dropped + (size_t)(sgi & 1u) * R.maxC;
         P.dropped_in = nullptr;
+        P.bnd_out = R.bnd + (size_t)((sgi + 1u) & 1u) * R.maxC;
         P.flags = (P0.flags & 1u) | (t0s ? 2u : 0u) | (min(sgi, 23u) << 8);
         if (sgi) {
             const unsigned long long* gw = R.gate_word + (c >> 4);
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 __builtin_amdgcn_s_sleep(64);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if constexpr (TIMED) if (wl == 0 && sgi < 12u) P.dbg[(size_t)c * 24 + 12 + sgi] = wall_clock64() - t_wait;   // slots 12 ..: the wait in front of segment sgi
             inherit_void = last_drop >= (int32_t)__builtin_amdgcn_readfirstlane(R.basis[(size_t)(sgi & 1u) * R.maxC + c]);
         }
     }
@@ -1068,19 +1070,19 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         o[0] = now() - tk0; o[1] = tk_bulk; o[2] = tk_scalar; o[3] = tk_decode;
         o[4] = n_bulk; o[5] = n_scalar; o[6] = n_bulk_samples; o[7] = n_flip | (n_decode << 32);
     }
-    if constexpr (PERSIST) {
-        if (left_replay) {   // what the replay needs to take this channel up again: its state at this boundary
-            last_drop = (int32_t)sgi;
-            Boundary* b = R.bnd + (size_t)((sgi + 1u) & 1u) * R.maxC + c;
-            if (wl == 0) {
-                b->init = s.initializing; b->on = s.dcd_on; b->trig = s.dcd_trig; b->count = s.count; b->run_pos = s.run_pos;
-                b->h0 = s.h0; b->h1 = s.h1; b->h2 = s.h2; b->level = cd->dcd_level; b->seg = cd->seg_start_tick;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            const uint32_t* hs = reinterpret_cast<const uint32_t*>(gs->hist);
-            uint32_t* hd = reinterpret_cast<uint32_t*>(b->hist);
-            for (int k = wl; k < 75; k += 64) hd[k] = hs[k];
+    if (P.bnd_out && left_replay) {   // what the replay needs to take this channel up again: its state at this boundary
+        Boundary* b = P.bnd_out + c;
+        if (cold_lane() == 0) {
+            b->init = s.initializing; b->on = s.dcd_on; b->trig = s.dcd_trig; b->count = s.count; b->run_pos = s.run_pos;
+            b->h0 = s.h0; b->h1 = s.h1; b->h2 = s.h2; b->level = cd->dcd_level; b->seg = cd->seg_start_tick;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        const uint32_t* hs = reinterpret_cast<const uint32_t*>(gs->hist);
+        uint32_t* hd = reinterpret_cast<uint32_t*>(b->hist);
+        for (int k = cold_lane(); k < 75; k += 64) hd[k] = hs[k];
+    }
+    if constexpr (PERSIST) {
+        if (left_replay) last_drop = (int32_t)sgi;
         persist_publish(R.k5_word + c, ((unsigned long long)R.serial << 32) | ((unsigned long long)(sgi + 1u) << 16) | (unsigned long long)(uint32_t)(last_drop + 1),
                         left_replay, wl == 0);
     }

@@ -653,7 +653,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->tables, sizeof(DecodeTables));
     ALLOC(c->taps, 160 * sizeof(float));
     ALLOC(c->llr_edges, 64 * sizeof(float));
-    ALLOC(c->dbg, C * 24 * sizeof(unsigned long long));
+    ALLOC(c->dbg, (C + C / GT_CPW + 1) * 24 * sizeof(unsigned long long));   // (K5's waves, then the persistent replay's)
 #undef ALLOC
     {
         DecodeTables* t = new DecodeTables;
@@ -1249,6 +1249,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     // m17_wave_kernel.hpp), so that the replay of segment k + 1 is good for them again; K5 never waits for it.  0: the redo runs on the
     // main stream between K5 of segment k - 1 and K5 of segment k and stores the history K5 of segment k then reads (rounds 1-2).
     const bool side_redo = c->redo_mode == 1;
+    if (c->speculate && side_redo && !c->bnd) HIPCHK(c, hipMalloc((void**)&c->bnd, 2 * (size_t)c->maxC * sizeof(Boundary)));
     uint32_t* const drop_of[2] = {c->dropped, c->dropped + c->maxC};   // by segment parity
     auto launch_gate = [&](uint32_t k, hipStream_t st, bool ahead, bool redo) -> int {
         const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
@@ -1258,6 +1259,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         G.dcd_table = c->dcd_table; G.ticks_cap = c->ticks_cap; G.state = c->seq_state;
         G.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
         G.chain_in = ahead ? c->gate_exp : nullptr; G.chain_out = c->gate_exp; G.only = redo ? drop_of[(k - 1u) & 1u] : nullptr;
+        G.bnd = (redo && side_redo) ? c->bnd + (size_t)(k & 1u) * c->maxC : nullptr;   // (written by K5 of segment k - 1)
         G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags | ((redo && side_redo) ? 2u : 0u);
         hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), 0, st, G);
         HIPCHK(c, hipGetLastError());
@@ -1281,12 +1283,13 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         P.kalman_order = c->kalman_order; P.channel_base = c->channel_base;
         P.diag_log = c->diag_cap ? c->diag_log : nullptr; P.diag_cap = c->diag_cap; P.diag_count = c->diag_count;
         P.defer = c->defer_decode ? c->defer_llr : nullptr;
+        P.bnd_out = (c->speculate && side_redo) ? c->bnd + (size_t)((k + 1u) & 1u) * c->maxC : nullptr;
         P.dbg = (c->profile || (c->wave_times && wpb == 4)) ? c->dbg : nullptr;
         return P;
     };
     // The persistent form (tuning knob 22): the front end of the whole run first, the replay of segment 0 from K5's state, then ONE launch
     // of the replay (segments 1 .. nseg - 1, on the replay stream, queued FIRST: it never waits for K5 without a bound) and ONE of K5.
-    const bool persist = c->persist && c->speculate && side_redo && wpb == 4 && !c->profile && !c->wave_times && nseg >= 2 && nseg < 60000 && ahead >= nseg;
+    const bool persist = c->persist && c->speculate && side_redo && wpb == 4 && !c->profile && nseg >= 2 && nseg < 60000 && ahead >= nseg;
     if (persist) {
         // (the persistent replay MUST find its place beside four K5 workgroups on every CU — K5's waves wait for it: LDS is handed out in
         // 1280-byte granules, of which 34 816-byte workgroups leave 16 = 20 480 bytes, less than the replay's 22 952)
@@ -1296,7 +1299,6 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
             HIPCHK(c, hipMalloc((void**)&c->k5_word, mc * 8));
             HIPCHK(c, hipMalloc((void**)&c->gate_word, (mc / GT_CPW + 1) * 8));
             HIPCHK(c, hipMalloc((void**)&c->basis, 2 * mc * 4));
-            HIPCHK(c, hipMalloc((void**)&c->bnd, 2 * mc * sizeof(Boundary)));
             HIPCHK(c, hipMemsetAsync(c->k5_word, 0, mc * 8, c->stream));
             HIPCHK(c, hipMemsetAsync(c->gate_word, 0, (mc / GT_CPW + 1) * 8, c->stream));
             HIPCHK(c, hipMemsetAsync(c->basis, 0, 2 * mc * 4, c->stream));
@@ -1312,6 +1314,11 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         R.maxC = c->maxC; R.serial = ++c->persist_serial;
         R.nseg = nseg; R.seg0 = sp.seg0; R.seg_len = sp.seg_len; R.T = T;
         R.k2_wait = c->k2_wait_us * 100u; R.k5_wait = c->k5_wait_us * 100u;
+        if (c->wave_times) {
+            R.k2_dbg = c->dbg + (size_t)C * 24;
+            c->dbg_waves = C + (C + GT_CPW - 1) / GT_CPW;
+            HIPCHK(c, hipMemsetAsync(c->dbg, 0, (size_t)c->dbg_waves * 24 * sizeof(unsigned long long), c->stream));
+        }
         {
             Timed tm(c, KT_GATE, gst);
             GateParams G{};
@@ -1327,7 +1334,8 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
             Timed tm(c, KT_SEQ, sst);
             SeqParams P = seq_params(0, 0, T);
             R.stats = c->overflow;   // K5 counts in word 1
-            hipLaunchKernelGGL((demod_wave_kernel<4, false, false, true>), grid, block, lds, sst, P, R);
+            if (c->wave_times) hipLaunchKernelGGL((demod_wave_kernel<4, false, true, true>), grid, block, lds, sst, P, R);
+            else hipLaunchKernelGGL((demod_wave_kernel<4, false, false, true>), grid, block, lds, sst, P, R);
             HIPCHK(c, hipGetLastError());
         }
         for (uint32_t k = 0; k < nseg; ++k) HIPCHK(c, hipEventRecord(ev_seq[k], c->stream));
