@@ -320,6 +320,10 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * state is re-derived beside the sequential kernel; 0 = the replay is redone between two launches of the sequential kernel (rounds 1-2).
  * key 21: the matched filter of a STAGED run (m17hip_demod_front) starts after the sequential kernel of this segment (1-based) of the run
  * before it (0 = at once, the default: every delay measured slower).
+ * key 25: 1 (default) = m17hip_demod_front also queues the limit-filter replay of the staged run's FIRST segment (and the prefix copies in
+ * front of it) on the replay stream: it needs the run in flight only up to its last sequential launch and its carried tails, so it runs
+ * beside that run's record fetch and the launch of the next run from the host (0.9 ms per step of a pipelined stream); 0 = m17hip_demod_run
+ * queues it.
  * key 22: 1 = the persistent form of the replay and the sequential kernel: ONE launch of each per run, a segment boundary is a hand-over
  * in device memory between a channel's sequential wave and the replay wave of its sixteen channels instead of a kernel boundary (same
  * results, tests/test_gpu_parity.py, tests/test_gpu_streaming.py; needs the redo policy 1 and four waves per workgroup, otherwise the

@@ -67,6 +67,9 @@ struct m17hip_ctx {
     size_t synth_bytes = 0;
     uint32_t runT = 0;                // samples of the latest run
     int redo_mode = 1;                // tuning knob 20
+    hipEvent_t ev_tail = nullptr;     // the latest run has carried its tails into its prefixes (K5 is done with its last segment)
+    bool gate0_queued = false;        // m17hip_demod_front has queued the replay of the staged run's first segment (and the prefix copies in front of it)
+    int gate0_early = 1;              // tuning knob 25: 1 = it does so
     int persist = 0;                  // tuning knob 22: K2 and K5 of a run as ONE launch each, hand-overs in memory (PersistParams, m17_state.hpp)
     unsigned long long* k5_word = nullptr;
     unsigned long long* gate_word = nullptr;
@@ -679,6 +682,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
+    if (hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     for (int q = 0; q < 2; ++q)
         if (hipEventCreateWithFlags(&c->ev_end[q], hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)demod_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, wave_lds_words(8) * 4) != hipSuccess)
@@ -708,7 +712,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     if (c->side2) hipStreamDestroy(c->side2);
     if (c->side3) hipStreamDestroy(c->side3);
     if (c->copy) hipStreamDestroy(c->copy);
-    for (hipEvent_t e : {c->ev_copy, c->ev_in_ready, c->ev_end[0], c->ev_end[1], c->ev_mark})
+    for (hipEvent_t e : {c->ev_copy, c->ev_in_ready, c->ev_end[0], c->ev_end[1], c->ev_mark, c->ev_tail})
         if (e) hipEventDestroy(e);
     for (int q = 0; q < 2; ++q)
         for (auto* v : {&c->ev_fir_[q], &c->ev_dcd_[q], &c->ev_gate_[q], &c->ev_redo_[q], &c->ev_seq_[q]})
@@ -1057,7 +1061,9 @@ int m17hip_demod_reset(m17hip_ctx* c)
     if (c->front_pending) {   // a front end queued by m17hip_demod_front is abandoned: let it drain, its results are not used
         HIPCHK(c, hipStreamSynchronize(c->side));
         HIPCHK(c, hipStreamSynchronize(c->side2));
+        HIPCHK(c, hipStreamSynchronize(c->side3));
         c->front_pending = false;
+        c->gate0_queued = false;
     }
     hipLaunchKernelGGL(seq_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->dcd_state, c->maxC);
     HIPCHK(c, hipGetLastError());
@@ -1130,6 +1136,26 @@ int launch_front_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, uint32_t C, u
     return M17HIP_OK;
 }
 
+// One launch of K2 over segment k of the run whose slabs the context names: the whole segment from K5's state (first segment), ahead of
+// K5 from K2's own state, or the redo of the channels K5 flagged in the previous segment.
+int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStream_t st, bool ahead, bool redo, uint32_t C, uint32_t flags)
+{
+    const bool side_redo = c->redo_mode == 1;
+    const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
+    Timed tm(c, KT_GATE, st);
+    GateParams G{};
+    G.x = c->xbuf + t0; G.xpitch = c->xpitch; G.y = c->ybuf + t0; G.ypitch = c->ypitch; G.h = c->hbuf + t0;
+    G.dcd_table = c->dcd_table; G.ticks_cap = c->ticks_cap; G.state = c->seq_state;
+    G.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
+    G.chain_in = ahead ? c->gate_exp : nullptr; G.chain_out = c->gate_exp;
+    G.only = redo ? c->dropped + (size_t)((k - 1u) & 1u) * c->maxC : nullptr;   // (flags by segment parity)
+    G.bnd = (redo && side_redo) ? c->bnd + (size_t)(k & 1u) * c->maxC : nullptr;   // (written by K5 of segment k - 1)
+    G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags | ((redo && side_redo) ? 2u : 0u);
+    hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), 0, st, G);
+    HIPCHK(c, hipGetLastError());
+    return M17HIP_OK;
+}
+
 // A staged run begins: the slab pairs swap, the 152-sample tail of the previous input is carried into the new slab's prefix, and the
 // front end (K1, K3: nothing in them depends on the outcome of the run before) is queued on the side streams — NOT ordered behind
 // the main stream, where K2 / K5 of the previous run may still have a long way to go.
@@ -1184,9 +1210,23 @@ int m17hip_demod_front(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT || (flags & ~M17HIP_FLAG_INVERT)) return M17HIP_EINVAL;
     GUARD(c);
     if (c->front_pending || !c->staged) return M17HIP_ESTATE;
-    const int r = begin_staged(c, C, T, flags);
+    int r = begin_staged(c, C, T, flags);
     if (r) return r;
     c->front_pending = true;
+    // The replay of the staged run's first segment (K2 from K5's state) needs the run in flight only up to its last K5 launch and its
+    // carried tails — not its deferred decode, its consumers, the caller's fetch of its records or the launch of the next run from the
+    // host: queued here, on the replay stream, it runs beside all of those.
+    if (c->gate0_early && c->speculate && c->have_run && c->carryT && !c->profile) {
+        const int q = c->slot;
+        const SegPlan sp(c, T);
+        for (hipEvent_t e : {c->ev_tail, c->ev_in_ready, c->ev_fir_[q][0], c->ev_dcd_[q][0]}) HIPCHK(c, hipStreamWaitEvent(c->side3, e, 0));
+        hipLaunchKernelGGL(copy_prefix_f32_kernel, dim3(C), dim3(64), 0, c->side3, c->yalt, c->ybuf, c->ypitch);
+        hipLaunchKernelGGL(copy_prefix_f32_kernel, dim3(C), dim3(64), 0, c->side3, c->halt, c->hbuf, c->ypitch);
+        HIPCHK(c, hipGetLastError());
+        if ((r = launch_gate_seg(c, sp, 0, c->side3, false, false, C, flags))) return r;
+        HIPCHK(c, hipEventRecord(c->ev_gate_[q][0], c->side3));
+        c->gate0_queued = true;
+    }
     return M17HIP_OK;
 }
 
@@ -1221,7 +1261,9 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         // K2 / K5 read the input slab too (snapshots, spliced-history FIR outputs); the y / h prefixes (the correlator ring and the limit
         // filter's history reach back into the previous run) come from the previous run's slabs, final now that its K5 is done
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in_ready, 0));
-        if (c->carryT) {   // (the previous run ended by carrying its tails into its own prefixes: copy those)
+        if (c->gate0_queued) {
+            // (m17hip_demod_front has queued these copies on the replay stream, in front of the first segment's replay)
+        } else if (c->carryT) {   // (the previous run ended by carrying its tails into its own prefixes: copy those)
             hipLaunchKernelGGL(copy_prefix_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->yalt, c->ybuf, c->ypitch);
             hipLaunchKernelGGL(copy_prefix_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->halt, c->hbuf, c->ypitch);
             HIPCHK(c, hipGetLastError());
@@ -1252,18 +1294,11 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     if (c->speculate && side_redo && !c->bnd) HIPCHK(c, hipMalloc((void**)&c->bnd, 2 * (size_t)c->maxC * sizeof(Boundary)));
     uint32_t* const drop_of[2] = {c->dropped, c->dropped + c->maxC};   // by segment parity
     auto launch_gate = [&](uint32_t k, hipStream_t st, bool ahead, bool redo) -> int {
-        const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
-        Timed tm(c, KT_GATE, st);
-        GateParams G{};
-        G.x = c->xbuf + t0; G.xpitch = c->xpitch; G.y = c->ybuf + t0; G.ypitch = c->ypitch; G.h = c->hbuf + t0;
-        G.dcd_table = c->dcd_table; G.ticks_cap = c->ticks_cap; G.state = c->seq_state;
-        G.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
-        G.chain_in = ahead ? c->gate_exp : nullptr; G.chain_out = c->gate_exp; G.only = redo ? drop_of[(k - 1u) & 1u] : nullptr;
-        G.bnd = (redo && side_redo) ? c->bnd + (size_t)(k & 1u) * c->maxC : nullptr;   // (written by K5 of segment k - 1)
-        G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags | ((redo && side_redo) ? 2u : 0u);
-        hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), 0, st, G);
-        HIPCHK(c, hipGetLastError());
-        return M17HIP_OK;
+        if (k == 0 && c->gate0_queued) {   // m17hip_demod_front has queued this one on the replay stream, behind the prefix copies
+            HIPCHK(c, hipStreamWaitEvent(st, ev_gate[0], 0));
+            return M17HIP_OK;
+        }
+        return launch_gate_seg(c, sp, k, st, ahead, redo, C, flags);
     };
     // one wave per channel; `seq_lanes` (tuning knob 0) = waves per workgroup
     const uint32_t wpb = (c->seq_lanes && !c->profile) ? c->seq_lanes : 4;  // the profiling build exists for 4 waves per workgroup
@@ -1418,10 +1453,12 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
                            (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count, c->channel_base);
     }
     // the tails a run that continues in THESE slabs (input uploaded in place) will find as its prefixes; a staged run takes them from
-    // here into the other slab pair itself
+    // here into the other slab pair itself.  (Before the deferred decode: the next staged run's first replay waits for these, not for that.)
     hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
     if (c->speculate) hipLaunchKernelGGL(carry_tail_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->hbuf, c->ypitch, T);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_tail, c->stream));
+    c->gate0_queued = false;
     HIPCHK(c, hipEventRecord(c->ev_end[q], c->stream));
     c->slot_used[q] = true;
     c->pos += T;
@@ -1897,6 +1934,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 21:  // the matched filter of a staged run waits for K5 of this segment (1-based) of the run before it (0 = starts at once)
         if (value < 0 || value > 1000) return M17HIP_EINVAL;
         c->front_k1_after = (uint32_t)value;
+        return M17HIP_OK;
+    case 25:  // 1 (default) = m17hip_demod_front also queues the replay of the staged run's first segment (beside the current run's deferred decode)
+        if (value != 0 && value != 1) return M17HIP_EINVAL;
+        c->gate0_early = (int)value;
         return M17HIP_OK;
     case 22:  // persistent K2 / K5: one launch of each per run, segment boundaries handed over in memory (PersistParams, m17_state.hpp)
         if (value != 0 && value != 1) return M17HIP_EINVAL;
