@@ -209,6 +209,29 @@ def test_performance_knobs_do_not_change_results():
     c.close()
 
 
+def test_persistent_hand_over_timeout_is_reported_and_recoverable():
+    """m17hip_tune key 22 (persistent replay / sequential kernels): a sequential wave that gives up waiting for its replay wave makes the
+    fetch calls return M17HIP_ETIMEOUT — nothing hangs — and a reset clears it.  Forced here with a 1 us patience (key 24); with the
+    defaults the same run delivers the oracle's records and no wave gives up."""
+    x = _signals(40, 96000, seed=73, sigma=900.0)
+    exp = _oracle_flat(x)
+    c = m17hip.Context(40, 96000)
+    c.tune(22, 1); c.tune(3, 9600)
+    c.upload(x); c.reset(); c.run()
+    assert c.frames().tobytes() == exp.tobytes()
+    assert c.persist_stats()[0] == 0
+    c.tune(24, 1); c.tune(23, 100)          # K5 waits 1 us for its replay, the replay 100 us for K5
+    c.reset(); c.run()
+    with pytest.raises(m17hip.M17HipError, match="error -8"):
+        c.frames()
+    assert c.persist_stats()[0] > 0
+    c.tune(24, 2000000); c.tune(23, 20000)
+    c.reset(); c.run()                        # (the reset clears the flag)
+    assert c.frames().tobytes() == exp.tobytes()
+    assert c.persist_stats()[0] == 0
+    c.close()
+
+
 def test_rccl_gather_single_rank():
     """m17hip_comm_* / m17hip_gather_frames with a 1-rank communicator: RCCL is bound, the counts all-gather and the
     compaction run, the root receives its own records."""
