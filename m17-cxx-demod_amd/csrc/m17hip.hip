@@ -1437,6 +1437,13 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         if (k + ahead < nseg && (r = launch_front_seg(c, sp, k + ahead, C, flags))) return r;
     }
     HIPCHK(c, hipGetLastError());
+    // the tails a run that continues in THESE slabs (input uploaded in place) will find as its prefixes; a staged run takes them from
+    // here into the other slab pair itself.  (Before the deferred decode: the next staged run's first replay waits for these, not for that.)
+    hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
+    if (c->speculate) hipLaunchKernelGGL(carry_tail_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->hbuf, c->ypitch, T);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_tail, c->stream));
+    c->gate0_queued = false;
     if (c->defer_decode) {   // the payload frames K5 did not decode itself, one lane per frame; then the cost tags K5 left are replaced
         DeferParams D{};
         D.recs = c->recs; D.rec_cap = c->rec_cap; D.rec_count = c->rec_count; D.defer = c->defer_llr; D.hist = c->defer_hist; D.tables = c->tables;
@@ -1452,13 +1459,6 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         hipLaunchKernelGGL(packet_asm_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->recs, c->rec_cap, c->rec_count, (PacketState*)c->pkt_state, C,
                            (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count, c->channel_base);
     }
-    // the tails a run that continues in THESE slabs (input uploaded in place) will find as its prefixes; a staged run takes them from
-    // here into the other slab pair itself.  (Before the deferred decode: the next staged run's first replay waits for these, not for that.)
-    hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
-    if (c->speculate) hipLaunchKernelGGL(carry_tail_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->hbuf, c->ypitch, T);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev_tail, c->stream));
-    c->gate0_queued = false;
     HIPCHK(c, hipEventRecord(c->ev_end[q], c->stream));
     c->slot_used[q] = true;
     c->pos += T;
