@@ -29,7 +29,7 @@ extern "C" {
 #define M17HIP_EOVERFLOW (-5) /* a per-channel frame-record buffer overflowed */
 #define M17HIP_ETRUNC (-6)   /* more results than the caller's capacity: *count says how many exist, `capacity` were written */
 #define M17HIP_ECOMM (-7)    /* an RCCL call failed (m17hip_gather_*) */
-#define M17HIP_ETIMEOUT (-8) /* the persistent kernels' hand-over timed out: the run's results are void (m17hip_tune key 22 = 0 runs without them) */
+/* (-8 was M17HIP_ETIMEOUT of ABI 301's persistent kernel form, removed in ABI 400) */
 
 /* Frame-type / sync-type codes = the reference enums M17FrameDecoder.h:52-55. */
 enum { M17_FRAME_LSF = 0, M17_FRAME_LICH = 1, M17_FRAME_STREAM = 2, M17_FRAME_BASIC_PACKET = 3, M17_FRAME_FULL_PACKET = 4, M17_FRAME_BERT = 5 };
@@ -85,11 +85,10 @@ void m17hip_ctx_destroy(m17hip_ctx* ctx);
  * 42 instead of 26 ms per step).  Export GPU_MAX_HW_QUEUES=16 before the first HIP call of the process. */
 #define M17HIP_ADVICE_HW_QUEUES 1
 int m17hip_advice(const m17hip_ctx* ctx);
-/* The persistent form of the replay / sequential kernels (m17hip_tune key 22): out[0] = waves of the sequential kernel that gave up
- * waiting for their replay wave since the last reset (any: the run is void, the fetch calls return M17HIP_ETIMEOUT), out[1] = segment
- * boundaries at which the replay went on without waiting any longer for a channel's sequential wave (harmless: that channel computes
- * its own limit-filter history until the replay has caught up with it).  Waits for the work queued so far. */
-int m17hip_persist_stats(m17hip_ctx* ctx, uint32_t out[2]);
+/* Operational statistic: how many times since the last m17hip_demod_reset a channel left the limit-filter replay (the demodulator
+ * forced dcd.unlock() after losing sync, M17Demodulator.h:396-404, 470-478: the one gate event the replay cannot foresee) and computed
+ * its own limit-filter history up to the end of the next segment — the slow path of the sequential kernel.  Waits for the queued work. */
+int m17hip_replay_drops(m17hip_ctx* ctx, uint64_t* count);
 /* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = the default stream). */
 int m17hip_set_stream(m17hip_ctx* ctx, void* hip_stream);
 
@@ -298,46 +297,24 @@ int m17hip_gather_frames(m17hip_ctx* ctx, m17hip_comm* comm, int root, m17_frame
 int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m17_frame_rec* recs_dev, uint64_t capacity, uint64_t* counts,
                                 uint64_t* total);
 
-/* Tuning knobs (performance only, never results).  key 0: waves (= channels) per workgroup of the sequential kernel
- * (0 = default 4; 1, 2, 4, 8).  key 1: per-channel tick counters of that kernel on/off (m17hip_debug_counters).
- * key 2: run the correlator's limit filter ahead of the sequential kernel (default 1) or inside it (0).
- * key 3: samples per segment a run is processed in (default 48000; 0 = one segment).  key 4: samples of the first segment
- * (default 0 = like the others).  key 6: BERT statistics on/off (m17hip_bert_stats; default off).  key 7: packet reassembly, value = packets of room per run (m17hip_packets_fetch; default 0 = off).  key 5: segments the front end (K1, K3) may run ahead of the sequential kernel
- * (default 0 = unlimited).  key 8 (not a performance knob): record slots per channel and run actually used, 0 = all that were
- * allocated (2 per 1920 samples + 8, which a run cannot outgrow) — a smaller value makes M17HIP_EOVERFLOW reachable for tests.
+/* Knobs of a context (never results).  M17HIP_EINVAL for a key the library does not have.
+ * key 3: samples per segment a run is processed in (default 48000; 0 = one segment): the granule of the K2 / K5 alternation — shorter
+ *        segments bound how long a channel that lost sync computes its own limit-filter history, longer ones mean fewer launches.
+ * key 6: BERT statistics on/off (m17hip_bert_stats; default off).
+ * key 7: packet reassembly, value = packets of room per run (m17hip_packets_fetch; default 0 = off).
+ * key 8: record slots per channel and run actually used, 0 = all that were allocated (2 per 1920 samples + 8, which a run cannot
+ *        outgrow) — a smaller value makes M17HIP_EOVERFLOW reachable for tests.
  * key 9: diagnostic log, value = diagnostic callbacks of room per channel and run (m17hip_diag_log_fetch; default 0 = off).
- * key 10: form of the carrier-detect kernel K3: 0 = one wave per 32 channels (default), 1 = four-wave pipeline (1.8x faster alone,
- * four times the wave slots).  key 11: stream priorities of the front end (bit 0: K1 lowest, bit 1: K3 lowest, bit 2: K3 highest).
- * key 12: segments of K1 that must be complete before the first K5 starts (0 = its own only).
- * key 13: form of the matched filter K1: 1 = rolled tap loop, 95 VGPRs (default: a workgroup of it fits beside the sequential kernel's
- * waves on a SIMD, which is worth 9 % of the step with two batches in flight), 0 = straight-line tap loop (167 VGPRs), 2 = rolled with
- * 11 outputs per lane (62 VGPRs; measured slower than 1).  key 14: LDS bytes a workgroup of the sequential kernel asks for (0 = default:
- * 34 816, which makes a CU hold four of them and leaves 128 VGPRs per SIMD and — LDS goes in 1280-byte granules — 20 KB to the kernels
- * running beside them; the persistent form asks for 33 280 so that its replay, 22.4 KB, is among those).
- * key 19 (diagnostics): 1 = the sequential kernel (four-wave form) records every wave's working time per segment in 10 ns ticks, bit 62
- * = the wave served itself: m17hip_debug_counters slot k = segment k.  key 20: what happens after a forced dcd.unlock() took a channel
- * off the limit-filter replay: 1 (default) = the channel serves itself for the rest of that segment and the next one while the replay's
- * state is re-derived beside the sequential kernel; 0 = the replay is redone between two launches of the sequential kernel (rounds 1-2).
- * key 21: the matched filter of a STAGED run (m17hip_demod_front) starts after the sequential kernel of this segment (1-based) of the run
- * before it (0 = at once, the default: every delay measured slower).
- * key 25: 1 (default) = m17hip_demod_front also queues the limit-filter replay of the staged run's FIRST segment (and the prefix copies in
- * front of it) on the replay stream: it needs the run in flight only up to its last sequential launch and its carried tails, so it runs
- * beside that run's record fetch and the launch of the next run from the host (0.9 ms per step of a pipelined stream); 0 = m17hip_demod_run
- * queues it.
- * key 22: 1 = the persistent form of the replay and the sequential kernel: ONE launch of each per run, a segment boundary is a hand-over
- * in device memory between a channel's sequential wave and the replay wave of its sixteen channels instead of a kernel boundary (same
- * results, tests/test_gpu_parity.py, tests/test_gpu_streaming.py; needs the redo policy 1 and four waves per workgroup, otherwise the
- * segmented form runs).  Default 0: measured slower (NOTES.md 3.4) — the replay's recurrence runs at 1.7 ms per segment beside four
- * sequential waves on its SIMD and every channel waits for it.  key 23 / key 24: microseconds the persistent replay waits for a channel's
- * sequential wave at a boundary before it goes on without it (default 20 000), and the sequential wave for its replay before it declares
- * the run void (default 2 000 000; M17HIP_ETIMEOUT, m17hip_persist_stats).
- * key 16 (not a performance knob): 1 = m17hip_upload_i16, m17hip_upload_i16_device and m17hip_synth_i16 write the context's STAGING slab
- * (as m17hip_upload_i16_async does, but complete when they return) and stage it for the next run; 0 (default) = the current slab.
  * key 15: 1 (default) = the sequential kernel leaves the payload frames of running stream / BERT transmissions undecoded (LLRs to a
- * store, the record reserved) and a lane-per-frame kernel decodes them after the run; 0 = every frame is decoded where it completes. */
+ *        store, the record reserved) and a lane-per-frame kernel decodes them after the run; 0 = every frame is decoded where it completes.
+ * key 16: 1 = m17hip_upload_i16, m17hip_upload_i16_device and m17hip_synth_i16 write the context's STAGING slab (as
+ *        m17hip_upload_i16_async does, but complete when they return) and stage it for the next run; 0 (default) = the current slab.
+ * The measurement build of the library (make -C m17-cxx-demod_amd/csrc tools -> libm17hip_tools.so, -DM17_TOOLS; tools/ only) adds
+ * key 1 / key 19 (section timers / per-wave working times of the sequential kernel -> m17hip_debug_counters) and the schedule
+ * experiments 4, 5, 12, 14, 21, 25 (csrc/m17hip.hip, m17hip_tune). */
 int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 
-/* Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][24] =
+/* Measurement build only (otherwise *waves = 0).  Diagnostic counters of the last sequential-kernel launch (after m17hip_tune(ctx, 1, 1)): host[channels][40] =
  * {total, bulk chunks, single-sample steps, frame decodes} in 10 ns ticks, {#chunks, #single steps, samples in chunks,
  * #chunks cut by a clock move | #decodes << 32}, then [8..14] ticks and [16..22] counts of single-sample steps per
  * DemodState. */

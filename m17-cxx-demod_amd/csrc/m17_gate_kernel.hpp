@@ -69,18 +69,15 @@ constexpr int GT_CPW = 64 / GT_LPC;   // channels per wave
 constexpr int GT_F4 = TICK / 4 / GT_LPC;  // float4 per lane per tick
 constexpr int GT_LDS_FLOATS = GT_CPW * TICK + GT_CPW * 148 + 298;   // 22.9 KB
 
-// One pass over one segment for the sixteen channels of a wave.  Per lane: `valid` = the channel takes part (stores, exports its end
-// state), `from_chain` (wave-uniform) = it starts from the replay's own state (else from K5's: P.state, or `bnd_base[c]` where the persistent form hands a
-// boundary record over).
-// `t0`, `segT`, `state_only`, `fh_off`: the segment [t0, t0 + segT) of the slabs P names (P itself stays the kernel's argument: what is derived
-// from it is re-read where it is used instead of being kept in registers), whether history values are stored, which final_h slot.
-__device__ __forceinline__ void limit_track_pass(const GateParams& P, uint32_t t0, uint32_t segT, bool state_only, size_t fh_off, uint32_t c, bool valid,
-                                                 bool from_chain, const Boundary* bnd_base, float* lds_base)
+// One pass over the segment P names for the sixteen channels of a wave.  Per lane: `valid` = the channel takes part (stores, exports its
+// end state); a lane that does not idles.  `from_chain` (wave-uniform) = the pass starts from the replay's own state, else from K5's:
+// P.state, or the boundary record `bnd_base[c]` (the redo).  `state_only`: no history value is stored (the redo).
+__device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state_only, uint32_t c, bool valid, bool from_chain, const Boundary* bnd_base,
+                                                 float* lds_base)
 {
-    // (the channel index opaque to the optimiser: the per-lane row addresses derived from it are computed here, per pass, instead of being
-    // hoisted out of the persistent kernel's loops and kept — spilled — across them)
-    asm volatile("" : "+v"(c));
-    from_chain = __builtin_amdgcn_readfirstlane((int)from_chain) != 0;   // (the same for every channel of a pass)
+    constexpr uint32_t t0 = 0;
+    const uint32_t segT = P.T;
+    const size_t fh_off = 0;
     const Boundary* bnd = bnd_base ? bnd_base + c : nullptr;   // (bnd_base: wave-uniform)
     const uint64_t pos0 = P.pos0 + t0;
     // matched-filter samples of the current piece, replaced IN PLACE by h0 after each of them (the recurrence reads a sample, or the
@@ -123,6 +120,10 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, uint32_t t
         level = gs->cold.dcd_level;
         seg = gs->cold.seg_start_tick;
     }
+    // A lane whose channel takes no part in this pass (a redo pass runs for the flagged channels only; lanes beyond the last channel)
+    // idles with the carrier off: it is never fed, never patched and does not keep the other channels of the wave off the steady-state
+    // path.  (Its record in `bnd` / its live state must not steer anything: the record may never have been written.)
+    if (!valid) { init = 0; on = 0; trig = 0; count = 0; run_pos = 148; h0 = h1 = h2 = 0.f; level = 0.f; seg = 0; end_in_run = false; end_t = 0; }
     // Started from K5's state: the three slots in front of the segment get the history it starts with.  (What is there is the
     // previous segment's or run's tail, which is void if K5 had dropped the speculation there; a replay that continues from its own
     // state finds its own output there.)
@@ -153,7 +154,7 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, uint32_t t
     // whole aligned tick, no patched outputs: lane r stages float4 r, r + GT_LPC, ... (16-byte loads issued one tick ahead)
     auto stage_tick = [&]() {
         const float4* src = reinterpret_cast<const float4*>(yr + t) + r;
-        if (pre_t != t) {
+        if (pre_t != t && valid) {   // (an idle lane loads nothing: a redo pass of one channel does not read its fifteen neighbours' rows)
 #pragma unroll
             for (int b = 0; b < GT_F4; ++b) pre[b] = src[GT_LPC * b];
         }
@@ -161,8 +162,10 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, uint32_t t
 #pragma unroll
         for (int b = 0; b < GT_F4; ++b) dst[GT_LPC * b] = pre[b];
         if (t + 2 * TICK <= segT) {
+            if (valid) {
 #pragma unroll
-            for (int b = 0; b < GT_F4; ++b) pre[b] = src[TICK / 4 + GT_LPC * b];
+                for (int b = 0; b < GT_F4; ++b) pre[b] = src[TICK / 4 + GT_LPC * b];
+            }
             pre_t = t + TICK;
         }
     };
@@ -201,7 +204,7 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, uint32_t t
         // ---- steady state: every channel of the wave is inside a gated run, past its first 148 samples, and this tick holds
         //      no update point — nothing but the filter -------------------------------------------------------------------------
         {
-            const bool steady = init <= 0 && on != 0 && run_pos >= 148 && count + TICK < 960u;
+            const bool steady = !valid || (init <= 0 && on != 0 && run_pos >= 148 && count + TICK < 960u);
             if (phase == 0 && t + TICK <= segT && ((pos0 + t) & 3u) == 0 && __ballot(!steady) == 0ull) {
                 stage_tick();
                 lds_sync();
@@ -356,79 +359,13 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
     const int lane = threadIdx.x;
     uint32_t c = blockIdx.x * GT_CPW + lane / GT_LPC;
     bool valid = c < P.C;
-    if (!valid) c = P.C - 1;  // shadow the last channel, never store
+    if (!valid) c = P.C - 1;  // (a real row for its addresses; the lane idles)
     if (P.only) {
         valid = valid && P.only[c] != 0;
         if (!__ballot(valid)) return;   // nothing to redo for these sixteen channels
     }
     __shared__ __attribute__((aligned(16))) float lds_static[GT_LDS_FLOATS];
-    limit_track_pass(P, 0u, P.T, (P.flags & 2u) != 0, 0, c, valid, P.chain_in != nullptr, P.only ? P.bnd : nullptr, lds_static);
-}
-
-// The persistent form (PersistParams, m17_state.hpp): one launch replays segments 1 .. nseg - 1 of a run (segment 0 is replayed from
-// K5's state before anything of the run starts).  Step k stores the history of segment k + 1; before it, the channels that left the
-// replay in segment k - 1 are redone over segment k from the state K5 published at that boundary (end state only).
-// (its LDS is dynamic — GT_LDS_FLOATS floats — so that the register budget follows the waves-per-SIMD attribute and not what the compiler
-// makes of a static allocation: inlined into the loop the pass was given 205 VGPRs, and the kernel has to fit into the 128 that four K5
-// waves leave of a SIMD)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void limit_track_persist_kernel(GateParams P0, PersistParams R)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x;
-    const int r = lane % GT_LPC;
-    uint32_t c = blockIdx.x * GT_CPW + lane / GT_LPC;
-    const bool valid = c < P0.C;
-    if (!valid) c = P0.C - 1;
-    uint32_t basis = 0;   // the replay is this channel's own unless the channel left it in a segment >= basis
-    const unsigned long long t_start = R.k2_dbg ? wall_clock64() : 0ull;
-    unsigned long long tk_wait = 0, tk_pass[2] = {0, 0}, n_redo = 0;
-    for (uint32_t k = 0; k + 1 < R.nseg; ++k) {
-        bool redo = false;
-        if (k >= 1) {
-            const unsigned long long t_wait = wall_clock64();
-            unsigned long long w;
-            uint32_t cw = c;
-            asm volatile("" : "+v"(cw));   // (as below)
-            for (;;) {
-                w = persist_load(R.k5_word + cw);
-                const bool here = !valid || ((uint32_t)(w >> 32) == R.serial && ((uint32_t)w >> 16) >= k);
-                if (!__ballot(!here)) break;
-                if (wall_clock64() - t_wait > R.k2_wait) {
-                    if (lane == 0) atomicAdd(R.stats, 1u);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(32);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (R.k2_dbg) tk_wait += wall_clock64() - t_wait;
-            const bool seen = valid && (uint32_t)(w >> 32) == R.serial && ((uint32_t)w >> 16) >= k;
-            redo = seen && ((uint32_t)w & 0xFFFFu) == k;   // left the replay in segment k - 1 (a later boundary's word hides that: the channel then waits for its turn)
-        }
-        for (int pass = __ballot(redo) ? 0 : 1; pass < 2; ++pass) {
-            const uint32_t sgm = k + (uint32_t)pass;
-            const uint32_t t0 = R.t0(sgm);
-            const unsigned long long t_pass = R.k2_dbg ? wall_clock64() : 0ull;
-            limit_track_pass(P0, t0, R.t0(sgm + 1u) - t0, pass == 0, (size_t)(sgm & 1u) * R.maxC * 4, c, pass == 0 ? redo : valid, pass == 1,
-                             pass == 0 ? R.bnd + (size_t)(k & 1u) * R.maxC : nullptr, lds_dyn);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the end state goes through memory (chain_out -> chain_in), other lanes read it
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if (R.k2_dbg) { tk_pass[pass] += wall_clock64() - t_pass; n_redo += pass == 0; }
-        }
-        if (redo) basis = k;
-        {   // (indices opaque: the two addresses are computed here, not hoisted out of the loop and spilled)
-            uint32_t ci = c, bi = blockIdx.x;
-            asm volatile("" : "+v"(ci), "+s"(bi));
-            if (r == 0 && valid) R.basis[(size_t)((k + 1u) & 1u) * R.maxC + ci] = basis;
-            persist_publish(R.gate_word + bi, ((unsigned long long)R.serial << 32) | (k + 1u), true, lane == 0);
-        }
-        if (R.k2_dbg && lane == 0 && k < 20u) R.k2_dbg[(size_t)blockIdx.x * 24 + 4 + k] = wall_clock64() - t_start;
-    }
-    if (R.k2_dbg && lane == 0) {
-        unsigned long long* o = R.k2_dbg + (size_t)blockIdx.x * 24;
-        o[0] = tk_wait; o[1] = tk_pass[0]; o[2] = tk_pass[1]; o[3] = n_redo;
-    }
+    limit_track_pass(P, (P.flags & 2u) != 0, c, valid, P.chain_in != nullptr, P.only ? P.bnd : nullptr, lds_static);
 }
 
 }  // namespace m17

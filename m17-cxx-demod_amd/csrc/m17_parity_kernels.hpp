@@ -36,12 +36,23 @@ __global__ __launch_bounds__(64) void slice_kernel(const float* __restrict__ sym
 // a9/a10 stand-alone (parity API): the 2-state Kalman update of KalmanFilter.h:41-65 / :91-107 (kal_update, the function the
 // full-chain kernel calls) on `rows` independent filters, n updates each: z[r][i] after dt[r][i] samples.
 // out[r][i][6] = x0, x1, P00, P01, P10, P11 after update i.  One lane per row, the filter state in LDS as in K5.
+// wrap == -1: a LEVEL filter in the form K5 runs it (core::level_update with the gain schedule `gain` of this order, dt = 192 whatever
+// dt[] says): out[..][0..1] = x0, x1, the covariance slots are zero (the schedule holds it).
 __global__ __launch_bounds__(64) void kalman_kernel(const float* __restrict__ z, const uint32_t* __restrict__ dt, uint32_t rows, uint32_t n, int wrap,
-                                                    float z0, uint32_t order, float* __restrict__ out)
+                                                    float z0, uint32_t order, float* __restrict__ out, const core::Kalman2Gain* __restrict__ gain)
 {
     __shared__ Kal2 st[64];
     const uint32_t r = blockIdx.x * 64 + threadIdx.x;
     if (r >= rows) return;
+    if (wrap == -1) {
+        float x0 = z0, x1 = 0.f;
+        for (uint32_t i = 0; i < n; ++i) {
+            core::level_update(x0, x1, z[(size_t)r * n + i], gain[min(i, (uint32_t)core::LEVEL_SCHED_LAST)], order);
+            float* o = out + ((size_t)r * n + i) * 6;
+            o[0] = x0; o[1] = x1; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; o[5] = 0.f;
+        }
+        return;
+    }
     M17_LDS Kal2* kp = as_lds(&st[threadIdx.x]);
     Kal2 k;
     kal_reset(k, z0);

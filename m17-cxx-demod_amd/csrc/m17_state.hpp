@@ -9,6 +9,7 @@
 
 namespace m17 {
 
+constexpr int DBG_SLOTS = 40;   // 64-bit counters per wave of the measurement build (m17hip_debug_counters)
 enum : uint32_t { ST_UNLOCKED = 0, ST_LSF_SYNC, ST_STREAM_SYNC, ST_PACKET_SYNC, ST_BERT_SYNC, ST_SYNC_WAIT, ST_FRAME };
 
 using Kal2 = core::Kalman2;  // 2-state Kalman filter (KalmanFilter.h:18-108); F, H, R, Q are constants
@@ -28,7 +29,6 @@ struct Hot {  // per-channel scalars kept in registers while the kernel runs
     uint32_t st, sync_word_type, sample_index, sync_sample_index;
     uint32_t need_clock_reset, need_clock_update, eot_flag, viterbi_cost;
     int32_t sync_count, missing_sync_count, initializing;
-    uint32_t spec_ok;           // this run still trusts K2's speculative limit-filter history (m17_gate_kernel.hpp)
 };
 // The hot scalars while K5 runs: the same names as Hot, each one a wave-uniform value that every write forces into a SCALAR
 // register (v_readfirstlane), so the state machine's tests and counters are SALU work on registers instead of LDS round
@@ -55,7 +55,7 @@ template <typename T> struct SReg {
     X(float, ck_sample_est) X(float, idev) X(float, offset) X(float, evm_S) X(uint32_t, framer_idx) X(uint32_t, framer_half)       \
     X(uint32_t, st) X(uint32_t, sync_word_type) X(uint32_t, sample_index) X(uint32_t, sync_sample_index)                           \
     X(uint32_t, need_clock_reset) X(uint32_t, need_clock_update) X(uint32_t, eot_flag) X(uint32_t, viterbi_cost)                   \
-    X(int32_t, sync_count) X(int32_t, missing_sync_count) X(int32_t, initializing) X(uint32_t, spec_ok)
+    X(int32_t, sync_count) X(int32_t, missing_sync_count) X(int32_t, initializing)
 struct HotRegs {
 #define X(T, n) SReg<T> n;
     M17_HOT_SCALARS(X)
@@ -78,7 +78,9 @@ struct HotRegs {
     }
 };
 struct Cold {  // per-channel state touched a few times per frame (out-of-line helpers); lives in LDS while K5 runs, like Hot
-    Kal2 ck, kmin, kmax;
+    Kal2 ck;                    // ClockRecovery's index filter (dt varies: the full update)
+    float min_x0, min_x1, max_x0, max_x1;   // FreqDevEstimator's two level filters: state only, the covariance is the gain schedule's
+    uint32_t lvl_n;             // their updates since the last reset, saturating at core::LEVEL_SCHED_LAST (core.h: level_schedule)
     uint32_t dev_reset;
     float dcd_level;
     uint32_t seg_start_tick;    // absolute tick index where the current DCD accumulation segment began
@@ -129,7 +131,7 @@ struct SeqParams {
     uint64_t tick_row0;       // absolute tick stored in row 0 of the DCD table
     uint32_t flags;           // bit 0 invert, bit 1 continuation segment of a run
     unsigned long long* dbg;  // optional [channels][24] counters (diagnostics)
-    const float* h;           // K2's limit-filter history, pitch ypitch (nullptr: no speculation, K5 runs the filter itself)
+    const float* h;           // K2's limit-filter history (hbuf), pitch ypitch
     const float* final_h;     // [C][4] K2's filter history after the last fed sample of the run
     uint32_t* dropped;        // [C] out: this segment left K2's replay (K2 redoes the replay's state from K5's; K5 serves itself meanwhile)
     const uint32_t* dropped_in;   // [C] the same flags of the PREVIOUS segment (nullptr: first segment of a run): set = hbuf holds nothing for this channel
@@ -138,48 +140,10 @@ struct SeqParams {
     uint32_t* diag_count;     // [C] entries written this run
     uint32_t kalman_order;    // evaluation order of the Kalman update (kal_update)
     uint32_t channel_base;    // global id of channel 0 of this context (written into the frame records)
+    const core::Kalman2Gain* level_gain;   // [core::LEVEL_SCHED_N] gain schedule of the level filters under `kalman_order`
     Boundary* bnd_out;        // optional [C]: boundary records for the end of this segment (m17_gate_kernel.hpp reads them)
     uint32_t* defer;          // optional [C][rec_cap][46]: LLR frames (nibbles) whose decoding is deferred to decode_deferred_kernel (nullptr: none is)
 };
-
-// ---- The persistent forms of K2 and K5 (m17hip_tune key 22): ONE launch of each per run, every segment boundary a hand-over in memory
-// instead of a kernel boundary, so that a channel is held up by the sixteen channels of its own replay wave only and not by the slowest
-// of all of them.  (Agent-scope release / acquire around 8-byte words; the words carry the run's serial number, nothing is ever cleared.)
-//   K5 -> K2  k5_word[c]   = serial << 32 | segments finished << 16 | (last segment in which the channel left the replay) + 1
-//             bnd[b & 1][c] = the channel's Boundary record at boundary b (after segment b - 1)
-//   K2 -> K5  gate_word[w] = serial << 32 | number of segments whose history is stored (wave w = channels 16 w .. 16 w + 15)
-//             basis[s & 1][c] = the history of segment s is this channel's own unless it left the replay in a segment >= basis
-// K2 never waits for K5 longer than `k2_wait` (it then goes on with what it has: the channels concerned serve themselves), K5 waits for K2
-// only, and K2 is launched first: whatever the order in which the hardware runs the two, both end.
-struct PersistParams {
-    unsigned long long* k5_word;     // [C]
-    unsigned long long* gate_word;   // [(C + 15) / 16]
-    uint32_t* basis;                 // [2][maxC]
-    Boundary* bnd;                   // [2][maxC]
-    uint32_t* stats;                 // [0] K2 went on without a channel's boundary, [1] K5 gave up waiting (the run is void)
-    uint32_t maxC, serial;
-    uint32_t nseg, seg0, seg_len, T; // segment k = samples [t0(k), t0(k + 1)) of the run
-    uint32_t k2_wait, k5_wait;       // 10 ns ticks
-    unsigned long long* k2_dbg;      // optional [(C + 15) / 16][24] (m17hip_tune key 19): per replay wave, 10 ns ticks: [0] waiting, [1] redo passes, [2] ahead passes, [3] redo passes made, [4 + k] end of step k since the wave's start
-    __device__ __forceinline__ uint32_t t0(uint32_t k) const { return k == 0 ? 0u : min(T, seg0 + (k - 1u) * seg_len); }
-};
-__device__ __forceinline__ unsigned long long persist_load(const unsigned long long* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// every lane's stores first, then ONE lane: release, and the word (the asm waits are not redundant: the compiler may drop the fence's own)
-__device__ __forceinline__ void persist_publish(unsigned long long* p, unsigned long long v, bool with_data, bool writer)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (writer) {
-        if (with_data) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
 
 // LDS words for a wave of `ls` channels: ring, sync samples, llr, hist, outb, lsf columns; edges, src maps, lich map
 
@@ -221,28 +185,27 @@ using core::clock_predict;
 // ---- out-of-line helpers on COLD state ------------------------------------------------------------------------------
 // M17Demodulator::update_values (:233-241) = Correlator::outer_symbol_levels (Correlator.h:81-114) +
 // FreqDevEstimator::update (FreqDevEstimator.h:31-48).  Returns (idev, offset).
-__device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float* ring, int stride, int lane, uint32_t si, uint32_t order)
+__device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float* ring, int stride, int lane, uint32_t si, uint32_t order, const core::Kalman2Gain* gain)
 {
+    // the gain of this update: a function of the update count alone (core.h, level_schedule) — in flight while the levels are formed
+    const uint32_t n = cd->lvl_n;
+    const core::Kalman2Gain g = gain[n];
     float mn, mx;
     core::outer_symbol_levels([&](uint32_t i) { return ring[i * stride + lane]; }, si, mn, mx);
-    // the two level filters are the same code on different data: even lanes carry the minimum's, odd lanes the maximum's, ONE
-    // update call for both (every lane runs the wave-uniform code anyway; lanes of one parity store identical values)
-    {
-        const bool odd = threadIdx.x & 1u;
-        kal_update(odd ? &cd->kmax : &cd->kmin, odd ? mx : mn, 192u, 0, order);
-    }
-    const Kal2 a = lds_get(&cd->kmin), b = lds_get(&cd->kmax);
-    float offset = core::freqdev_offset(b.x0, a.x0);
-    float idev = core::freqdev_idev(b.x0, a.x0);
+    float a0 = cd->min_x0, a1 = cd->min_x1, b0 = cd->max_x0, b1 = cd->max_x1;
+    core::level_update(a0, a1, mn, g, order);
+    core::level_update(b0, b1, mx, g, order);
+    float offset = core::freqdev_offset(b0, a0);
+    float idev = core::freqdev_idev(b0, a0);
     uint32_t rst = cd->dev_reset;
-    if (isnan(a.x0) || isnan(a.x1) || isnan(b.x0) || isnan(b.x1)) rst = 1;
+    if (isnan(a0) || isnan(a1) || isnan(b0) || isnan(b1)) rst = 1;
+    uint32_t nn = min(n + 1u, (uint32_t)core::LEVEL_SCHED_LAST);
     if (rst) {
-        Kal2 k;
-        kal_reset(k, mn); lds_put(&cd->kmin, k);
-        kal_reset(k, mx); lds_put(&cd->kmax, k);
+        a0 = mn; a1 = 0.f; b0 = mx; b1 = 0.f; nn = 0;
         offset = (mn + mx) / 2.f;
         idev = core::freqdev_idev(mx, mn);
     }
+    cd->min_x0 = a0; cd->min_x1 = a1; cd->max_x0 = b0; cd->max_x1 = b1; cd->lvl_n = nn;
     cd->dev_reset = 0;
     return make_float2(idev, offset);
 }

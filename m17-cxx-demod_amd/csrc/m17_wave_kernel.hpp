@@ -112,16 +112,14 @@ __device__ __noinline__ Hist3 nf_serve_limit(const float* yr, float* hr, M17_LDS
 
 // PROF: compile the 100 MHz section timers and counters in (diagnostics, tools/seq_ablate.py); the production
 // instantiation carries none of them.
-// PERSIST: the whole run in ONE launch (m17hip_tune key 22, PersistParams in m17_state.hpp): the wave goes through the segments one after the
-// other exactly as the launches of the segmented form do (state saved and reloaded at every boundary), but what it waits for at a boundary
-// is the replay wave of its own sixteen channels, not the end of a launch.
-template <int WPB, bool PROF = false, bool TIMED = false, bool PERSIST = false>
-__global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(SeqParams P0, PersistParams R)
+// TIMED: per-wave working time per segment (both only in the tools build, -DM17_TOOLS).
+template <int WPB, bool PROF = false, bool TIMED = false>
+__global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(SeqParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     float* edges = reinterpret_cast<float*>(lds);                        // [64] llr table edges (43 used)
-    for (int k = threadIdx.x; k < 43; k += 64 * WPB) edges[k] = P0.llr_edges[k];
-    const float* taps = P0.taps;                                         // [149] RRC taps (slow-FIR patch: rare, read where they are)
+    for (int k = threadIdx.x; k < 43; k += 64 * WPB) edges[k] = P.llr_edges[k];
+    const float* taps = P.taps;                                         // [149] RRC taps (slow-FIR patch: rare, read where they are)
     __syncthreads();  // the only block-level barrier: the waves of a block are independent from here on
 
     // the wave index is wave-uniform: tell the compiler, so that the channel's state, pointers and every branch of the state
@@ -133,39 +131,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // kept — spilled — for the whole kernel
     auto cold_lane = [&]() -> int { int l = wl; asm volatile("" : "+v"(l)); return l; };
     const uint32_t c = blockIdx.x * WPB + wave;
-    if (c >= P0.C) return;
-    int32_t last_drop = -1;   // PERSIST: the last segment of this run in which the channel left the replay
-    for (uint32_t sgi = 0; sgi < (PERSIST ? R.nseg : 1u); ++sgi) {
-    SeqParams P = P0;
-    bool inherit_void = false;   // PERSIST: the replay behind this segment's history did not know of the channel's last forced unlock
-    if constexpr (PERSIST) {
-        const uint32_t t0s = R.t0(sgi);
-        P.x = P0.x + t0s; P.y = P0.y + t0s; P.h = P0.h + t0s;
-        P.T = R.t0(sgi + 1u) - t0s;
-        P.pos0 = P0.pos0 + t0s;
-        P.final_h = P0.final_h + (size_t)(sgi & 1u) * R.maxC * 4;
-        P.dropped = P0.dropped + (size_t)(sgi & 1u) * R.maxC;
-        P.dropped_in = nullptr;
-        P.bnd_out = R.bnd + (size_t)((sgi + 1u) & 1u) * R.maxC;
-        P.flags = (P0.flags & 1u) | (t0s ? 2u : 0u) | (min(sgi, 23u) << 8);
-        if (sgi) {
-            const unsigned long long* gw = R.gate_word + (c >> 4);
-            const unsigned long long t_wait = wall_clock64();
-            for (;;) {
-                const unsigned long long w = persist_load(gw);
-                const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)), lo = __builtin_amdgcn_readfirstlane((uint32_t)w);
-                if (hi == R.serial && lo >= sgi) break;
-                if (wall_clock64() - t_wait > R.k5_wait) {   // cannot happen while K2 runs at all: the run is void, say so and leave
-                    if (wl == 0) atomicAdd(R.stats + 1, 1u);
-                    return;
-                }
-                __builtin_amdgcn_s_sleep(64);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if constexpr (TIMED) if (wl == 0 && sgi < 12u) P.dbg[(size_t)c * 24 + 12 + sgi] = wall_clock64() - t_wait;   // slots 12 ..: the wait in front of segment sgi
-            inherit_void = last_drop >= (int32_t)__builtin_amdgcn_readfirstlane(R.basis[(size_t)(sgi & 1u) * R.maxC + c]);
-        }
-    }
+    if (c >= P.C) return;
     uint32_t* wb = lds + WV_TAB_WORDS + wave * WV_WAVE_WORDS;
     float* ring = reinterpret_cast<float*>(wb);              // [80]  Correlator::buffer_
     float* swsm = ring + 80;                                 // [4][10] SyncWord::samples_
@@ -186,8 +152,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     DL.stride = 1;
     DL.prof = nullptr;
     if constexpr (PROF) {
-        DL.prof = P.dbg + (size_t)c * 24 + 9;
-        if (wl < 15) P.dbg[(size_t)c * 24 + 9 + wl] = 0;   // slots 9..23
+        DL.prof = P.dbg + (size_t)c * DBG_SLOTS + 9;
+        if (wl < 15) P.dbg[(size_t)c * DBG_SLOTS + 9 + wl] = 0;   // slots 9..23
     }
     uint16_t* llr16 = reinterpret_cast<uint16_t*>(DL.llr);
 
@@ -211,14 +177,13 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         for (int k = wl; k < (int)(sizeof(Cold) / 4); k += 64) dst[k] = src[k];
     }
     HotRegs s;
-    const float* hrow = P.h ? P.h + (size_t)c * P.ypitch + YPRE : nullptr;  // K2's filter history for this channel
+    const float* hrow = P.h + (size_t)c * P.ypitch + YPRE;  // K2's filter history for this channel (hbuf row)
     for (int k = wl; k < 80; k += 64) ring[k] = gs->ring[k];
     for (int k = wl; k < 40; k += 64) swsm[k] = gs->sw_samples[k / 10][k % 10];
     for (int k = wl; k < 92; k += 64) DL.llr[k] = gs->llr[k];
     for (int k = wl; k < 8; k += 64) DL.lsf[k] = gs->lsf[k];
     wave_lds_sync();
     s.load(as_lds(hot_lds));
-    s.spec_ok = hrow != nullptr;  // every run starts trusting K2 (which started from this very state)
     if (!(P.flags & 2u)) { cd->n_run = 0; cd->n_diag_run = 0; }  // (flag bit 1: a later segment of the same run keeps counting its records)
     // Sample window: ybuf samples [t, avail) are in LDS; the next WV_PF samples are in flight in registers (pf) so that the
     // HBM/L2 latency of this channel's row is paid ~WV_PF samples ahead of its use instead of at the head of every step.
@@ -303,7 +268,6 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         if (hpf_wait) { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); hpf_wait = false; }   // vmcnt(0)
     };
     auto cur_lim = [&]() -> float {
-        if (!s.spec_ok) return iir_output(s.h0, s.h1, s.h2);
         const int32_t tt = (int32_t)cur_tt;
         {
             const int32_t o2 = tt - hpf_base;
@@ -332,9 +296,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     };
     bool left_replay = false;   // a forced unlock fell into THIS segment: the replay that is (or was) run for it ends in a state that is not this channel's
     auto despec = [&](uint32_t tt) {      // tt: the sample being processed; s.count already counts it
-        if (s.spec_ok) left_replay = true;
-        if (s.spec_ok && !diverged) {
+        left_replay = true;
+        if (!diverged) {
             ++n_despec;
+            if (cold_lane() == 0) atomicAdd(P.overflow + 1, 1u);   // (statistics: m17hip_replay_drops)
             diverged = true;
             h_until = min(P.T, tt + (960u - min((uint32_t)s.count, 960u)) + 1u);
         }
@@ -368,7 +333,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     };
     auto sw_updated = [&](int w) -> int32_t { const int32_t r = s.sw_updated[w]; s.sw_updated[w] = 0; return r; };
     auto update_values = [&](uint32_t index) {  // M17Demodulator.h:233-241
-        const float2 r = nf_update_values(cd, ring, 1, 0, s.sample_index, P.kalman_order);
+        const float2 r = nf_update_values(cd, ring, 1, 0, s.sample_index, P.kalman_order, P.level_gain);
         s.idev = r.x; s.offset = r.y;
         s.sync_sample_index = index;
     };
@@ -391,10 +356,6 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         }
     };
     auto corr_sample = [&](float v) {  // Correlator::sample :43-49
-        if (!s.spec_ok) {
-            const float h0n = iir_advance(fabsf(v), s.h0, s.h1);  // history shifts: h2 <- h1, h1 <- h0
-            s.h2 = s.h1; s.h1 = s.h0; s.h0 = h0n;
-        }
         ring[s.ring_pos] = v;
         s.prev_pos = s.ring_pos;
         if (++s.ring_pos == 80u) s.ring_pos = 0;
@@ -488,12 +449,13 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     };
 
     unsigned long long n_bulk = 0, n_bulk_samples = 0, n_scalar = 0, n_flip = 0, n_decode = 0;
+    uint32_t n_mode[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_lim_clock = 0, n_lim_count = 0, n_lim_room = 0;   // (PROF: loop iterations per chunk kind, why frame chunks ended)
     auto now = [&]() -> unsigned long long { if constexpr (PROF) return wall_clock64(); else return 0ull; };
     const unsigned long long tk0 = now();
     // wave timing (tuning knob 19; the production code in an instantiation of its own): how long THIS wave works on its segment, in 10 ns ticks, with the launch's
     // duration = the slowest wave's.  Slot = segment index (flags bits 8..12).
     // (the start time waits in the slot itself: nothing of this stays in registers across the kernel)
-    if constexpr (TIMED) if (wl == 0) P.dbg[(size_t)c * 24 + ((P.flags >> 8) & 31u)] = wall_clock64();
+    if constexpr (TIMED) if (wl == 0) P.dbg[(size_t)c * DBG_SLOTS + ((P.flags >> 8) & 31u)] = wall_clock64();
     unsigned long long tk_bulk = 0, tk_scalar = 0, tk_decode = 0, tk_patch = 0, tk_ens = 0, tk_sym = 0, tk_iir = 0, tk_search = 0, tk_off = 0;
 
     // The first 148 FIR outputs of a gated run still see the tail of the previous run (Q2): recompute them from the
@@ -528,9 +490,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // A channel that left K2's replay in the previous segment finds nothing of its own in hbuf (the replay that ran ahead started from
     // a state that is not this channel's; K2 is re-deriving the replay's state from this wave's while we run): it serves itself from
     // its first sample on.  The next segment's replay is good again.
-    bool void_in;
-    if constexpr (PERSIST) void_in = inherit_void; else void_in = hrow && P.dropped_in && P.dropped_in[c];
-    if (void_in) {
+    if (P.dropped_in && P.dropped_in[c]) {
         diverged = true;
         h_until = 0;
         if ((s.initializing || s.dcd_on) && wl == 0) { float* hw = const_cast<float*>(hrow); hw[-1] = s.h0; hw[-2] = s.h1; hw[-3] = s.h2; }
@@ -608,10 +568,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 if (is_sync) {
                     if (s.sync_count < 77) {
                         n = min((uint32_t)(77 - s.sync_count), lim); mode = BULK_QUIET;
-                        if (s.spec_ok) {
-                            const int32_t target = (int32_t)t + (77 - (int32_t)s.sync_count) - 3;
-                            if (hpf_base != target && (!diverged || target + 64 <= (int32_t)h_until)) hpf_issue(target);
-                        }
+                        const int32_t target = (int32_t)t + (77 - (int32_t)s.sync_count) - 3;
+                        if (hpf_base != target && (!diverged || target + 64 <= (int32_t)h_until)) hpf_issue(target);
                     }
                     else if (s.sync_count < 86) {   // the window where the next sync word is looked for (:420-574), up to the sample
                         n = min(min(10u, (uint32_t)(86 - s.sync_count)), lim);   // before its trigger falls / EOT / the count runs out
@@ -643,6 +601,14 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 }
             }
             if (n < 1u) mode = BULK_NONE;
+        }
+        if constexpr (PROF) {
+            n_mode[mode & 7]++;
+            if (mode == BULK_FRAME && !completes) {
+                if ((s.need_clock_reset | s.need_clock_update) && n == 10u - s.ring_pos % 10u) n_lim_clock++;
+                else if (n == 960u - s.count) n_lim_count++;
+                else if (n == (uint32_t)WV_YCH) n_lim_room++;
+            }
         }
         if (mode == BULK_FRAME) {
             // every anti-phase clock_recovery.update() of the chunk (:601-606) must leave sample_index where it is
@@ -679,7 +645,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
             for (uint32_t k = wl; k < 80u; k += 64) W[k] = ring[(s.prev_pos + 1u + k) % 80u];   // oldest first
             if (wl < n) W[80u + wl] = ywin[(t + wl) & (WV_WIN - 1)];
-            if (s.spec_ok) {   // the trajectory is in hbuf: hb[k] = history after sample t - 3 + k
+            {   // the trajectory is in hbuf: hb[k] = history after sample t - 3 + k
                 const int32_t off = (int32_t)t - 3 - hpf_base;
                 if (off >= 0 && off + (int32_t)n + 3 <= 64) {   // ... and already in LDS
                     hpf_ready();
@@ -688,16 +654,6 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 } else {
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                     for (uint32_t k = wl; k < n + 3u; k += 64) hb[k] = hrow[(int64_t)t - 3 + k];
-                }
-            } else {
-                float h0 = s.h0, h1 = s.h1;
-                float m2 = IirCoef::a2 * h1;
-                hb[0] = s.h2; hb[1] = h1; hb[2] = h0;
-                wave_lds_sync();
-                for (uint32_t k = 0; k < n; ++k) {
-                    const float hn = iir_advance_pk(fabsf(W[80u + k]), h0, m2);
-                    h0 = hn;
-                    hb[3u + k] = hn;
                 }
             }
             wave_lds_sync();
@@ -731,7 +687,6 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             const uint32_t f = mask ? (uint32_t)(__ffsll((long long)mask) - 1) : n;   // leading samples that are committed here
             if (f > 0u) {
                 const uint32_t rp0 = s.ring_pos;
-                if (!s.spec_ok) { s.h0 = hb[2u + f]; s.h1 = hb[1u + f]; s.h2 = hb[f]; }   // (with hbuf behind the run the history is read where it is needed; while diverged s.h0..h2 belong to the END of the served stretch)
                 const uint32_t first = f > 80u ? f - 80u : 0u;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                 for (uint32_t o = first + wl; o < f; o += 64) ring[(s.ring_pos + o) % 80u] = W[80u + o];
@@ -804,35 +759,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             }
             const unsigned long long b2 = now();
             tk_sym += b2 - b1;
-            {   // Correlator::sample x n: the limit IIR is one dependent chain; the ring keeps the last 80 samples
-                if (!s.spec_ok) {   // (a run that trusts K2 finds the filter history in hbuf when it needs it)
-                float h0 = s.h0, h1 = s.h1, h2 = s.h2;
-                float m2 = IirCoef::a2 * h1;   // a2 * (second-newest history value), carried by iir_advance_pk
-                uint32_t k = 0;
-                for (; k < n && ((t + k) & 3u); ++k) {  // head: up to a 16-byte boundary of the window
-                    const float hn = iir_advance_pk(fabsf(ywin[(t + k) & (WV_WIN - 1)]), h0, m2);
-                    h2 = h1; h1 = h0; h0 = hn;
-                }
-                if (k + 4 <= n) {
-                    float4 v = *reinterpret_cast<const float4*>(ywin + ((t + k) & (WV_WIN - 1)));
-                    for (; k + 4 <= n; k += 4) {
-                        const uint32_t kn = (k + 8 <= n) ? k + 4 : k;  // next group in flight
-                        const float4 nx = *reinterpret_cast<const float4*>(ywin + ((t + kn) & (WV_WIN - 1)));
-                        float hn;
-                        hn = iir_advance_pk(fabsf(v.x), h0, m2); h2 = h1; h1 = h0; h0 = hn;
-                        hn = iir_advance_pk(fabsf(v.y), h0, m2); h2 = h1; h1 = h0; h0 = hn;
-                        hn = iir_advance_pk(fabsf(v.z), h0, m2); h2 = h1; h1 = h0; h0 = hn;
-                        hn = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = hn;
-                        v = nx;
-                    }
-                }
-                for (; k < n; ++k) {
-                    const float hn = iir_advance_pk(fabsf(ywin[(t + k) & (WV_WIN - 1)]), h0, m2);
-                    h2 = h1; h1 = h0; h0 = hn;
-                }
-                s.h0 = h0; s.h1 = h1; s.h2 = h2;
-                }
-                tk_iir += now() - b2;
+            {   // Correlator::sample x n: the ring keeps the last 80 samples (the limit filter's history is in hbuf: K2 / nf_serve_limit)
                 const uint32_t first = n > 80u ? n - 80u : 0u;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                 for (uint32_t o = first + wl; o < n; o += 64) ring[(s.ring_pos + o) % 80u] = ywin[(t + o) & (WV_WIN - 1)];
@@ -868,7 +795,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         // ---- one input sample: M17Demodulator::operator() :657-753 -----------------------------------------------------------
         const unsigned long long c0 = now();
         ++n_scalar;
-        if constexpr (PROF) { if (wl == 0) P.dbg[(size_t)c * 24 + 17 + 1 + min((uint32_t)s.st, 5u)] += 1; }
+        if constexpr (PROF) { if (wl == 0) P.dbg[(size_t)c * DBG_SLOTS + 17 + 1 + min((uint32_t)s.st, 5u)] += 1; }
         const uint32_t tt = t;
         cur_tt = tt;
         s.count++;
@@ -1030,10 +957,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     }
 
     // ---------------- save state ------------------------------------------------------------------------------
-    if (s.spec_ok) {
-        if (!diverged) { const float* f = P.final_h + (size_t)c * 4; s.h0 = f[0]; s.h1 = f[1]; s.h2 = f[2]; }
-        else if (s.initializing || s.dcd_on) pick_hist(P.T - 1u);   // (gate off: the history was picked where it froze)
-    }
+    if (!diverged) { const float* f = P.final_h + (size_t)c * 4; s.h0 = f[0]; s.h1 = f[1]; s.h2 = f[2]; }
+    else if (s.initializing || s.dcd_on) pick_hist(P.T - 1u);   // (gate off: the history was picked where it froze)
     if (P.dropped && wl == 0) P.dropped[c] = left_replay ? 1u : 0u;
     s.store(as_lds(hot_lds));
     wave_lds_sync();
@@ -1061,14 +986,16 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     P.rec_count[c] = cd->n_run;
     if (P.diag_log && wl == 0) P.diag_count[c] = cd->n_diag_run;
     if constexpr (TIMED) if (wl == 0) {
-        unsigned long long* slot = P.dbg + (size_t)c * 24 + ((P.flags >> 8) & 31u);
+        unsigned long long* slot = P.dbg + (size_t)c * DBG_SLOTS + ((P.flags >> 8) & 31u);
         *slot = (wall_clock64() - *slot) | (diverged ? 1ull << 62 : 0ull);
     }
     if constexpr (PROF) if (wl == 0) {
-        unsigned long long* o = P.dbg + (size_t)c * 24;
+        unsigned long long* o = P.dbg + (size_t)c * DBG_SLOTS;
         o[8] = tk_patch; o[12] = tk_ens; o[13] = tk_sym; o[14] = tk_iir; o[15] = tk_search; o[16] = tk_off; o[17] = n_despec;
         o[0] = now() - tk0; o[1] = tk_bulk; o[2] = tk_scalar; o[3] = tk_decode;
         o[4] = n_bulk; o[5] = n_scalar; o[6] = n_bulk_samples; o[7] = n_flip | (n_decode << 32);
+        for (int k = 0; k < 8; ++k) o[24 + k] = n_mode[k];
+        o[32] = n_flip; o[33] = n_lim_clock; o[34] = n_lim_count; o[35] = n_lim_room;
     }
     if (P.bnd_out && left_replay) {   // what the replay needs to take this channel up again: its state at this boundary
         Boundary* b = P.bnd_out + c;
@@ -1081,12 +1008,6 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         uint32_t* hd = reinterpret_cast<uint32_t*>(b->hist);
         for (int k = cold_lane(); k < 75; k += 64) hd[k] = hs[k];
     }
-    if constexpr (PERSIST) {
-        if (left_replay) last_drop = (int32_t)sgi;
-        persist_publish(R.k5_word + c, ((unsigned long long)R.serial << 32) | ((unsigned long long)(sgi + 1u) << 16) | (unsigned long long)(uint32_t)(last_drop + 1),
-                        left_replay, wl == 0);
-    }
-    }   // segments
 }
 
 }  // namespace m17

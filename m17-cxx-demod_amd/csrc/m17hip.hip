@@ -66,18 +66,10 @@ struct m17hip_ctx {
     void* synth_scratch = nullptr;    // symbol staging of m17hip_synth_i16
     size_t synth_bytes = 0;
     uint32_t runT = 0;                // samples of the latest run
-    int redo_mode = 1;                // tuning knob 20
     hipEvent_t ev_tail = nullptr;     // the latest run has carried its tails into its prefixes (K5 is done with its last segment)
     bool gate0_queued = false;        // m17hip_demod_front has queued the replay of the staged run's first segment (and the prefix copies in front of it)
     int gate0_early = 1;              // tuning knob 25: 1 = it does so
-    int persist = 0;                  // tuning knob 22: K2 and K5 of a run as ONE launch each, hand-overs in memory (PersistParams, m17_state.hpp)
-    unsigned long long* k5_word = nullptr;
-    unsigned long long* gate_word = nullptr;
-    uint32_t* basis = nullptr;
-    Boundary* bnd = nullptr;
-    uint32_t persist_serial = 0;
-    uint32_t persist_skips = 0;        // boundaries the persistent K2 did not wait for (as of the last fetch)
-    uint32_t k2_wait_us = 20000, k5_wait_us = 2000000;   // tuning knobs 23 / 24
+    Boundary* bnd = nullptr;          // [2][maxC] boundary records (by segment parity): K5 -> the redo of K2 (m17_state.hpp)
     uint32_t front_k1_after = 0;      // tuning knob 21: the matched filter of a staged run starts after K5 of this segment (1-based) of the run before it; 0 = at once
     uint32_t last_nseg = 0;           // segments of the latest run
     bool wave_times = false;          // tuning knob 19: K5 writes each wave's working time per segment (m17hip_debug_counters)
@@ -105,8 +97,6 @@ struct m17hip_ctx {
     uint32_t kalman_order = 3;        // evaluation order of the Kalman updates (m17hip_set_kalman_order)
     uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
     uint32_t front_first = 0;         // tuning knob 12: segments of K1 that must be complete before the first K5 starts (0 = its own only)
-    bool dcd_pipeline = false;        // tuning knob 10: K3 as the four-wave pipeline (dcd_pipe_kernel) instead of one wave per 32 channels
-    bool speculate = true;            // tuning knob 2: K2 runs the limit filter ahead of K5
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     uint32_t seg0_len = 0;            // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others; measured neutral)
     float* dcd_table = nullptr;
@@ -124,8 +114,8 @@ struct m17hip_ctx {
     uint32_t* defer_hist = nullptr;  // [maxC][101][64]: that kernel's decision words
     bool defer_decode = true;
     uint32_t seq_lds_bytes = 0; // tune 14: LDS bytes a workgroup of the sequential kernel asks for (0 = SEQ_LDS_BYTES_4 for four waves)
-    int fir_form = 1;           // tune 13: 1 = rolled tap loop, 95 VGPRs (default: shares a SIMD with the sequential kernel), 0 = straight-line K1 (167 VGPRs), 2 = rolled, 11 outputs per lane, 62 VGPRs
     float* llr_edges = nullptr;
+    core::Kalman2Gain* level_gain = nullptr;   // [8 orders][LEVEL_SCHED_N] gain schedules of the level filters (core.h)
     void* scratch = nullptr;          // per-operator staging (correlator outputs, viterbi io)
     size_t scratch_bytes = 0;
     DcdCoef coef{};
@@ -135,7 +125,6 @@ struct m17hip_ctx {
     bool recs_valid = false;   // the record slots hold a finished run's records in the layout (rec_cap) they were written with
     bool uploaded = false;
     bool timing = false;
-    uint32_t seq_lanes = 0;    // waves per workgroup in K5 (0 = default)
     bool profile = false;      // K5 writes per-channel tick counters (tuning knob 1)
     unsigned long long* dbg = nullptr;  // [maxC][8] diagnostic cycle counters of K5
     uint32_t dbg_waves = 0;
@@ -308,8 +297,7 @@ __global__ void seq_reset_kernel(SeqState* st, DcdState* ds, uint32_t C)
     Cold& k = st[c].cold;
     s.run_pos = 148;              // the stream start is exact in ybuf (zero history)
     kal_reset(k.ck, 0.f);         // KalmanFilter() : reset(0.)
-    kal_reset(k.kmin, 0.f);
-    kal_reset(k.kmax, 0.f);
+    // (the level filters: SymbolKalmanFilter() : reset(0.) = zero state, update count 0 — the zeroes above)
     k.dev_reset = 1;              // FreqDevEstimator::reset_ = true
     s.evm_S = 1.0f;               // RunningStandardDeviation::S{1.0}
     s.initializing = 1920;        // M17Demodulator.h:659 (per channel)
@@ -556,17 +544,11 @@ __global__ void compact_kernel(const FrameRec* recs, uint32_t rec_cap, const uin
 
 // t0: first sample of the slab to process (segment of a run); the kernels see the slab from there on
 constexpr size_t SEQ_LDS_BYTES_4 = 34816;   // see the K5 launch
-constexpr size_t SEQ_LDS_BYTES_4_PERSIST = 33280;
 int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0)
 {
     Timed tm(c, KT_FIR, st);
     dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C);
-    if (c->fir_form == 1)
-        hipLaunchKernelGGL((fir_rrc150_rolled_kernel<FIR_R, 4>), grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
-    else if (c->fir_form == 2)
-        hipLaunchKernelGGL((fir_rrc150_rolled_kernel<11, 8>), dim3((T + 11 * FIR_THREADS - 1) / (11 * FIR_THREADS), C), dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
-    else
-        hipLaunchKernelGGL(fir_rrc150_kernel, grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags);
+    hipLaunchKernelGGL((fir_rrc150_rolled_kernel<FIR_R, 4>), grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
@@ -575,15 +557,8 @@ int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_
     Timed tm(c, KT_DCD, st);
     // table rows are numbered from the first tick of the RUN: a later segment continues where the previous one stopped
     const uint64_t row0 = (c->pos + t0) / TICK - c->pos / TICK;
-    if (!c->dcd_pipeline || T % DP_BLK != 0 || (c->pos + t0) % DP_BLK != 0 || t0 % 8 != 0 || T < 4 * DP_BLK)
-        hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW * DCD_WPB - 1) / (DCD_CPW * DCD_WPB)), dim3(64 * DCD_WPB), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
-                           c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
-    else if (flags & 1u)
-        hipLaunchKernelGGL(dcd_pipe_kernel<true>, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
-                           c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
-    else
-        hipLaunchKernelGGL(dcd_pipe_kernel<false>, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
-                           c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
+    hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW * DCD_WPB - 1) / (DCD_CPW * DCD_WPB)), dim3(64 * DCD_WPB), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+                       c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
@@ -601,7 +576,6 @@ const char* m17hip_strerror(int code)
     case M17HIP_ENOMEM: return "out of memory";
     case M17HIP_ESTATE: return "call sequence error";
     case M17HIP_EOVERFLOW: return "frame record buffer overflow";
-    case M17HIP_ETIMEOUT: return "the persistent kernels' hand-over timed out (m17hip_tune key 22 = 0 runs without them)";
     case M17HIP_ETRUNC: return "output truncated to the caller's capacity";
     case M17HIP_ECOMM: return "RCCL communication error";
     default: return "unknown error";
@@ -614,7 +588,7 @@ int m17hip_advice(const m17hip_ctx* ctx)
     const char* q = std::getenv("GPU_MAX_HW_QUEUES");
     return (!q || std::atoi(q) < 8) ? M17HIP_ADVICE_HW_QUEUES : 0;
 }
-int m17hip_version(void) { return 301; }
+int m17hip_version(void) { return 400; }
 
 int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out)
 {
@@ -652,11 +626,12 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->recs, C * c->rec_cap * sizeof(FrameRec));
     ALLOC(c->rec_count, C * sizeof(uint32_t));
     ALLOC(c->rec_offsets, (C + 1) * sizeof(uint64_t));
-    ALLOC(c->overflow, 4 * sizeof(uint32_t));   // [0] record overflow, [1] persistent K5 gave up waiting, [2] persistent K2 went on without a boundary
+    ALLOC(c->overflow, 4 * sizeof(uint32_t));   // [0] record overflow, [1] channels that left the limit-filter replay (m17hip_replay_drops)
     ALLOC(c->tables, sizeof(DecodeTables));
     ALLOC(c->taps, 160 * sizeof(float));
     ALLOC(c->llr_edges, 64 * sizeof(float));
-    ALLOC(c->dbg, (C + C / GT_CPW + 1) * 24 * sizeof(unsigned long long));   // (K5's waves, then the persistent replay's)
+    ALLOC(c->level_gain, 8 * (size_t)core::LEVEL_SCHED_N * sizeof(core::Kalman2Gain));
+    ALLOC(c->dbg, (C + 1) * DBG_SLOTS * sizeof(unsigned long long));   // (tools build: per-wave counters of K5)
 #undef ALLOC
     {
         DecodeTables* t = new DecodeTables;
@@ -670,6 +645,10 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
         build_llr_edges(edges);
         if (hipMemcpy(c->taps, taps, sizeof(taps), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
         if (hipMemcpy(c->llr_edges, edges, sizeof(edges), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
+        std::vector<core::Kalman2Gain> sched(8 * (size_t)core::LEVEL_SCHED_N);
+        for (uint32_t o = 0; o < 8; ++o)   // (false = the covariance has not reached its fixed point inside the table: the scheduled update would be wrong)
+            if (!core::level_schedule(sched.data() + (size_t)o * core::LEVEL_SCHED_N, o)) return fail(M17HIP_ESTATE);
+        if (hipMemcpy(c->level_gain, sched.data(), sched.size() * sizeof(core::Kalman2Gain), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
     }
     c->coef = build_coef();
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
@@ -685,8 +664,6 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     if (hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     for (int q = 0; q < 2; ++q)
         if (hipEventCreateWithFlags(&c->ev_end[q], hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
-    if (hipFuncSetAttribute((const void*)demod_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, wave_lds_words(8) * 4) != hipSuccess)
-        return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (122 + 122 + 16) * 64 * 4) != hipSuccess)
         return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)decode_deferred_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DEFER_LDS_BYTES) != hipSuccess)
@@ -718,8 +695,8 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
         for (auto* v : {&c->ev_fir_[q], &c->ev_dcd_[q], &c->ev_gate_[q], &c->ev_redo_[q], &c->ev_seq_[q]})
             for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->llr_edges, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist,
-                    c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->k5_word, c->gate_word, c->basis, c->bnd};
+                    c->overflow, c->tables, c->taps, c->llr_edges, c->level_gain, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist,
+                    c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->bnd};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -950,9 +927,7 @@ int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, 
 int m17hip_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* sums_host, uint32_t* ticks_out)
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT) return M17HIP_EINVAL;
-    // bits 4..7 switch roles of the K3 pipeline off (timing experiments, tools/k3_roles.py: the sums are wrong then): only with
-    // the diagnostics knob (m17hip_tune key 1) on
-    if ((flags & ~M17HIP_FLAG_INVERT) && !(c->profile && !(flags & ~(M17HIP_FLAG_INVERT | 0xF0u)))) return M17HIP_EINVAL;
+    if (flags & ~M17HIP_FLAG_INVERT) return M17HIP_EINVAL;
     GUARD(c);
     if (c->front_pending) return M17HIP_ESTATE;
     if (!c->uploaded) return M17HIP_ESTATE;
@@ -1101,7 +1076,7 @@ struct SegPlan {
     uint32_t t0(uint32_t k) const { return k == 0 ? 0u : std::min(T, seg0 + (k - 1u) * seg_len); }
 };
 
-int ensure_seg_events(m17hip_ctx* c, int q, uint32_t nseg)
+static int ensure_seg_events(m17hip_ctx* c, int q, uint32_t nseg)
 {
     while (c->ev_fir_[q].size() < nseg) {
         for (auto* v : {&c->ev_fir_[q], &c->ev_dcd_[q], &c->ev_gate_[q], &c->ev_redo_[q], &c->ev_seq_[q]}) {
@@ -1117,7 +1092,7 @@ int ensure_seg_events(m17hip_ctx* c, int q, uint32_t nseg)
 // The front end of segment k may be held back until K5 of segment k - front_ahead is done (tuning knob 5), to spread it over
 // the step; measured, letting it run ahead freely is faster (K3 is a latency chain of 1.7 ms per segment: held back, it is
 // what K5 ends up waiting for).
-int launch_front_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, uint32_t C, uint32_t flags)
+static int launch_front_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, uint32_t C, uint32_t flags)
 {
     if (k >= sp.nseg) return M17HIP_OK;
     const int q = c->slot;
@@ -1138,9 +1113,8 @@ int launch_front_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, uint32_t C, u
 
 // One launch of K2 over segment k of the run whose slabs the context names: the whole segment from K5's state (first segment), ahead of
 // K5 from K2's own state, or the redo of the channels K5 flagged in the previous segment.
-int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStream_t st, bool ahead, bool redo, uint32_t C, uint32_t flags)
+static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStream_t st, bool ahead, bool redo, uint32_t C, uint32_t flags)
 {
-    const bool side_redo = c->redo_mode == 1;
     const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
     Timed tm(c, KT_GATE, st);
     GateParams G{};
@@ -1149,8 +1123,8 @@ int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStream_t st
     G.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
     G.chain_in = ahead ? c->gate_exp : nullptr; G.chain_out = c->gate_exp;
     G.only = redo ? c->dropped + (size_t)((k - 1u) & 1u) * c->maxC : nullptr;   // (flags by segment parity)
-    G.bnd = (redo && side_redo) ? c->bnd + (size_t)(k & 1u) * c->maxC : nullptr;   // (written by K5 of segment k - 1)
-    G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags | ((redo && side_redo) ? 2u : 0u);
+    G.bnd = redo ? c->bnd + (size_t)(k & 1u) * c->maxC : nullptr;   // (written by K5 of segment k - 1)
+    G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags | (redo ? 2u : 0u);
     hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), 0, st, G);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
@@ -1159,7 +1133,7 @@ int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStream_t st
 // A staged run begins: the slab pairs swap, the 152-sample tail of the previous input is carried into the new slab's prefix, and the
 // front end (K1, K3: nothing in them depends on the outcome of the run before) is queued on the side streams — NOT ordered behind
 // the main stream, where K2 / K5 of the previous run may still have a long way to go.
-int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
+static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
 {
     if (C != c->stagedC || T != c->stagedT) return M17HIP_EINVAL;
     if (c->have_run && C != c->lastC) return M17HIP_EINVAL;  // a continued stream keeps its channel count
@@ -1216,7 +1190,7 @@ int m17hip_demod_front(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     // The replay of the staged run's first segment (K2 from K5's state) needs the run in flight only up to its last K5 launch and its
     // carried tails — not its deferred decode, its consumers, the caller's fetch of its records or the launch of the next run from the
     // host: queued here, on the replay stream, it runs beside all of those.
-    if (c->gate0_early && c->speculate && c->have_run && c->carryT && !c->profile) {
+    if (c->gate0_early && c->have_run && c->carryT && !c->profile) {
         const int q = c->slot;
         const SegPlan sp(c, T);
         for (hipEvent_t e : {c->ev_tail, c->ev_in_ready, c->ev_fir_[q][0], c->ev_dcd_[q][0]}) HIPCHK(c, hipStreamWaitEvent(c->side3, e, 0));
@@ -1284,14 +1258,15 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipMalloc((void**)&c->defer_hist, (size_t)c->maxC * DEFER_HIST_WORDS * 64 * sizeof(uint32_t)));
     }
     c->dbg_waves = (c->profile || c->wave_times) ? C : 0;
-    // K2 launch: the whole segment from K5's state (first segment), ahead of K5 from K2's own state (later segments, on side3),
-    // or the redo of the channels whose K5 dropped the speculation in the previous segment (from K5's state again)
-    // Redo policy (tuning knob 20).  1 (default): the redo of segment k only re-derives the REPLAY'S STATE for the channels that left it in
-    // segment k - 1, beside K5 of segment k on the replay stream (it stores nothing: those channels serve themselves in segment k,
-    // m17_wave_kernel.hpp), so that the replay of segment k + 1 is good for them again; K5 never waits for it.  0: the redo runs on the
-    // main stream between K5 of segment k - 1 and K5 of segment k and stores the history K5 of segment k then reads (rounds 1-2).
-    const bool side_redo = c->redo_mode == 1;
-    if (c->speculate && side_redo && !c->bnd) HIPCHK(c, hipMalloc((void**)&c->bnd, 2 * (size_t)c->maxC * sizeof(Boundary)));
+    // K2 launches: the whole first segment from K5's state; every later segment AHEAD of K5 from the replay's own end state (replay
+    // stream); and the REDO: for the channels that left the replay in segment k - 1 (a forced dcd.unlock()), the replay's state at the
+    // end of segment k is re-derived from K5's boundary record, beside K5 of segment k on the replay stream.  It stores nothing — those
+    // channels serve themselves in segment k (m17_wave_kernel.hpp) — and makes the replay of segment k + 1 good for them again; K5 never
+    // waits for it.
+    if (!c->bnd) {
+        HIPCHK(c, hipMalloc((void**)&c->bnd, 2 * (size_t)c->maxC * sizeof(Boundary)));
+        HIPCHK(c, hipMemsetAsync(c->bnd, 0, 2 * (size_t)c->maxC * sizeof(Boundary), c->stream));
+    }
     uint32_t* const drop_of[2] = {c->dropped, c->dropped + c->maxC};   // by segment parity
     auto launch_gate = [&](uint32_t k, hipStream_t st, bool ahead, bool redo) -> int {
         if (k == 0 && c->gate0_queued) {   // m17hip_demod_front has queued this one on the replay stream, behind the prefix copies
@@ -1300,83 +1275,30 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         }
         return launch_gate_seg(c, sp, k, st, ahead, redo, C, flags);
     };
-    // one wave per channel; `seq_lanes` (tuning knob 0) = waves per workgroup
-    const uint32_t wpb = (c->seq_lanes && !c->profile) ? c->seq_lanes : 4;  // the profiling build exists for 4 waves per workgroup
+    // one wave per channel, four waves per workgroup
+    constexpr uint32_t wpb = 4;
     const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
     // LDS: what the workgroup needs (31.8 KB for four waves), padded so that a CU holds FOUR of them and not five — the rest of
     // the CU (24 KB, 128 VGPRs per SIMD) is where a K2 wave or a K1 workgroup runs beside them without taking a K5 slot
-    size_t lds = std::max((size_t)wave_lds_words((int)wpb) * 4, c->seq_lds_bytes ? (size_t)c->seq_lds_bytes : (wpb == 4 ? (size_t)SEQ_LDS_BYTES_4 : (size_t)0));
+    const size_t lds = std::max((size_t)wave_lds_words((int)wpb) * 4, c->seq_lds_bytes ? (size_t)c->seq_lds_bytes : (size_t)SEQ_LDS_BYTES_4);
     auto seq_params = [&](uint32_t k, uint32_t t0, uint32_t len) {
         SeqParams P{};
-        P.h = c->speculate ? c->hbuf + t0 : nullptr; P.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
-        P.dropped = c->speculate ? drop_of[k & 1u] : nullptr;
+        P.h = c->hbuf + t0; P.final_h = c->final_h + (size_t)(k & 1u) * c->maxC * 4;
+        P.dropped = drop_of[k & 1u];
         P.x = c->xbuf + t0; P.xpitch = c->xpitch; P.y = c->ybuf + t0; P.ypitch = c->ypitch;
         P.dcd_table = c->dcd_table; P.ticks_cap = c->ticks_cap; P.state = c->seq_state;
         P.recs = c->recs; P.rec_cap = c->rec_cap; P.rec_count = c->rec_count; P.overflow = c->overflow;
         P.tables = c->tables; P.taps = c->taps; P.llr_edges = c->llr_edges;
         P.C = C; P.T = len; P.pos0 = c->pos + t0; P.tick_row0 = c->pos / TICK; P.flags = (flags & 1u) | (t0 ? 2u : 0u) | (std::min(k, 23u) << 8);
         P.kalman_order = c->kalman_order; P.channel_base = c->channel_base;
+        P.level_gain = c->level_gain + (size_t)(c->kalman_order & 7u) * core::LEVEL_SCHED_N;
         P.diag_log = c->diag_cap ? c->diag_log : nullptr; P.diag_cap = c->diag_cap; P.diag_count = c->diag_count;
         P.defer = c->defer_decode ? c->defer_llr : nullptr;
-        P.bnd_out = (c->speculate && side_redo) ? c->bnd + (size_t)((k + 1u) & 1u) * c->maxC : nullptr;
-        P.dbg = (c->profile || (c->wave_times && wpb == 4)) ? c->dbg : nullptr;
+        P.bnd_out = c->bnd + (size_t)((k + 1u) & 1u) * c->maxC;
+        P.dbg = (c->profile || c->wave_times) ? c->dbg : nullptr;
         return P;
     };
-    // The persistent form (tuning knob 22): the front end of the whole run first, the replay of segment 0 from K5's state, then ONE launch
-    // of the replay (segments 1 .. nseg - 1, on the replay stream, queued FIRST: it never waits for K5 without a bound) and ONE of K5.
-    const bool persist = c->persist && c->speculate && side_redo && wpb == 4 && !c->profile && nseg >= 2 && nseg < 60000 && ahead >= nseg;
-    if (persist) {
-        // (the persistent replay MUST find its place beside four K5 workgroups on every CU — K5's waves wait for it: LDS is handed out in
-        // 1280-byte granules, of which 34 816-byte workgroups leave 16 = 20 480 bytes, less than the replay's 22 952)
-        if (!c->seq_lds_bytes) lds = SEQ_LDS_BYTES_4_PERSIST;
-        if (!c->k5_word) {
-            const size_t mc = c->maxC;
-            HIPCHK(c, hipMalloc((void**)&c->k5_word, mc * 8));
-            HIPCHK(c, hipMalloc((void**)&c->gate_word, (mc / GT_CPW + 1) * 8));
-            HIPCHK(c, hipMalloc((void**)&c->basis, 2 * mc * 4));
-            HIPCHK(c, hipMemsetAsync(c->k5_word, 0, mc * 8, c->stream));
-            HIPCHK(c, hipMemsetAsync(c->gate_word, 0, (mc / GT_CPW + 1) * 8, c->stream));
-            HIPCHK(c, hipMemsetAsync(c->basis, 0, 2 * mc * 4, c->stream));
-        }
-        HIPCHK(c, hipStreamWaitEvent(c->stream, ev_fir[nseg - 1], 0));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, ev_dcd[nseg - 1], 0));
-        if ((r = launch_gate(0, c->stream, false, false))) return r;
-        hipStream_t gst = c->side3, sst = c->stream;
-        HIPCHK(c, hipEventRecord(ev_redo[0], c->stream));
-        HIPCHK(c, hipStreamWaitEvent(gst, ev_redo[0], 0));
-        PersistParams R{};
-        R.k5_word = c->k5_word; R.gate_word = c->gate_word; R.basis = c->basis; R.bnd = c->bnd; R.stats = c->overflow + 2;
-        R.maxC = c->maxC; R.serial = ++c->persist_serial;
-        R.nseg = nseg; R.seg0 = sp.seg0; R.seg_len = sp.seg_len; R.T = T;
-        R.k2_wait = c->k2_wait_us * 100u; R.k5_wait = c->k5_wait_us * 100u;
-        if (c->wave_times) {
-            R.k2_dbg = c->dbg + (size_t)C * 24;
-            c->dbg_waves = C + (C + GT_CPW - 1) / GT_CPW;
-            HIPCHK(c, hipMemsetAsync(c->dbg, 0, (size_t)c->dbg_waves * 24 * sizeof(unsigned long long), c->stream));
-        }
-        {
-            Timed tm(c, KT_GATE, gst);
-            GateParams G{};
-            G.x = c->xbuf; G.xpitch = c->xpitch; G.y = c->ybuf; G.ypitch = c->ypitch; G.h = c->hbuf;
-            G.dcd_table = c->dcd_table; G.ticks_cap = c->ticks_cap; G.state = c->seq_state;
-            G.final_h = c->final_h; G.chain_in = c->gate_exp; G.chain_out = c->gate_exp;
-            G.taps = c->taps; G.C = C; G.T = T; G.pos0 = c->pos; G.tick_row0 = c->pos / TICK; G.flags = flags;
-            hipLaunchKernelGGL(limit_track_persist_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), GT_LDS_FLOATS * sizeof(float), gst, G, R);
-            HIPCHK(c, hipGetLastError());
-        }
-        HIPCHK(c, hipEventRecord(ev_gate[nseg - 1], gst));
-        {
-            Timed tm(c, KT_SEQ, sst);
-            SeqParams P = seq_params(0, 0, T);
-            R.stats = c->overflow;   // K5 counts in word 1
-            if (c->wave_times) hipLaunchKernelGGL((demod_wave_kernel<4, false, true, true>), grid, block, lds, sst, P, R);
-            else hipLaunchKernelGGL((demod_wave_kernel<4, false, false, true>), grid, block, lds, sst, P, R);
-            HIPCHK(c, hipGetLastError());
-        }
-        for (uint32_t k = 0; k < nseg; ++k) HIPCHK(c, hipEventRecord(ev_seq[k], c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, ev_gate[nseg - 1], 0));   // (the replay's last stores: the tails below are carried from hbuf)
-    }
-    for (uint32_t k = 0; k < nseg && !persist; ++k) {
+    for (uint32_t k = 0; k < nseg; ++k) {
         const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
         HIPCHK(c, hipStreamWaitEvent(c->stream, ev_fir[k], 0));
         HIPCHK(c, hipStreamWaitEvent(c->stream, ev_dcd[k], 0));
@@ -1384,23 +1306,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
             const uint32_t last = std::min(c->front_first, nseg) - 1u;
             HIPCHK(c, hipStreamWaitEvent(c->stream, ev_fir[last], 0));
         }
-        if (c->speculate && !side_redo) {
-            if (k == 0) {
-                if ((r = launch_gate(0, c->stream, false, false))) return r;
-            } else {
-                HIPCHK(c, hipStreamWaitEvent(c->stream, ev_gate[k], 0));
-                if ((r = launch_gate(k, c->stream, false, true))) return r;
-            }
-            if (k + 1 < nseg) {   // the next segment's replay starts from this one's (now final) end state, beside K5
-                HIPCHK(c, hipEventRecord(ev_redo[k], c->stream));
-                HIPCHK(c, hipStreamWaitEvent(c->side3, ev_redo[k], 0));
-                HIPCHK(c, hipStreamWaitEvent(c->side3, ev_fir[k + 1], 0));
-                HIPCHK(c, hipStreamWaitEvent(c->side3, ev_dcd[k + 1], 0));
-                if ((r = launch_gate(k + 1, c->side3, true, false))) return r;
-                HIPCHK(c, hipEventRecord(ev_gate[k + 1], c->side3));
-            }
-        }
-        if (c->speculate && side_redo) {
+        {
             // replay stream: ahead(k) -> redo(k) [after K5(k - 1): its flags and its state] -> ahead(k + 1) -> ...; the main stream only
             // ever waits for an `ahead`
             if (k == 0) {
@@ -1423,15 +1329,13 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         }
         Timed tm(c, KT_SEQ);
         SeqParams P = seq_params(k, t0, len);
-        P.dropped_in = (c->speculate && side_redo && k > 0) ? drop_of[(k - 1u) & 1u] : nullptr;
-        if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P, PersistParams{});
-        else if (c->wave_times && wpb == 4) hipLaunchKernelGGL((demod_wave_kernel<4, false, true>), grid, block, lds, c->stream, P, PersistParams{});
-        else switch (wpb) {
-        case 1: hipLaunchKernelGGL(demod_wave_kernel<1>, grid, block, lds, c->stream, P, PersistParams{}); break;
-        case 2: hipLaunchKernelGGL(demod_wave_kernel<2>, grid, block, lds, c->stream, P, PersistParams{}); break;
-        case 8: hipLaunchKernelGGL(demod_wave_kernel<8>, grid, block, lds, c->stream, P, PersistParams{}); break;
-        default: hipLaunchKernelGGL(demod_wave_kernel<4>, grid, block, lds, c->stream, P, PersistParams{}); break;
-        }
+        P.dropped_in = k > 0 ? drop_of[(k - 1u) & 1u] : nullptr;
+#ifdef M17_TOOLS
+        if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P);
+        else if (c->wave_times) hipLaunchKernelGGL((demod_wave_kernel<4, false, true>), grid, block, lds, c->stream, P);
+        else
+#endif
+        hipLaunchKernelGGL(demod_wave_kernel<4>, grid, block, lds, c->stream, P);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(ev_seq[k], c->stream));
         if (k + ahead < nseg && (r = launch_front_seg(c, sp, k + ahead, C, flags))) return r;
@@ -1440,7 +1344,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     // the tails a run that continues in THESE slabs (input uploaded in place) will find as its prefixes; a staged run takes them from
     // here into the other slab pair itself.  (Before the deferred decode: the next staged run's first replay waits for these, not for that.)
     hipLaunchKernelGGL(carry_tail_kernel, dim3(C), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, C, T);
-    if (c->speculate) hipLaunchKernelGGL(carry_tail_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->hbuf, c->ypitch, T);
+    hipLaunchKernelGGL(carry_tail_f32_kernel, dim3(C), dim3(64), 0, c->stream, c->hbuf, c->ypitch, T);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_tail, c->stream));
     c->gate0_queued = false;
@@ -1489,8 +1393,6 @@ static int compact_into(m17hip_ctx* c, FrameRec* dev_out, uint64_t cap, uint64_t
     HIPCHK(c, hipMemcpyAsync(ovf, c->overflow, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (count) *count = total;
-    c->persist_skips = ovf[2];
-    if (ovf[1]) return M17HIP_ETIMEOUT;
     if (ovf[0]) return M17HIP_EOVERFLOW;
     if (dev_out && total > cap) return M17HIP_ETRUNC;
     return M17HIP_OK;
@@ -1650,7 +1552,7 @@ int m17hip_set_channel_base(m17hip_ctx* c, uint32_t channel_base)
 int m17hip_kalman_trace(m17hip_ctx* c, const float* z_host, const uint32_t* dt_host, uint32_t rows, uint32_t n, int wrap, float z0, int order,
                         float* out_host)
 {
-    if (!c || !z_host || !dt_host || !out_host || rows == 0 || n == 0 || order < 0 || order > 7 || (wrap != 0 && wrap != 10)) return M17HIP_EINVAL;
+    if (!c || !z_host || !dt_host || !out_host || rows == 0 || n == 0 || order < 0 || order > 7 || (wrap != 0 && wrap != 10 && wrap != -1)) return M17HIP_EINVAL;
     GUARD(c);
     const size_t cnt = (size_t)rows * n;
     const size_t o1 = round_up(cnt * 4, 256), o2 = o1 + round_up(cnt * 4, 256);
@@ -1660,7 +1562,7 @@ int m17hip_kalman_trace(m17hip_ctx* c, const float* z_host, const uint32_t* dt_h
     HIPCHK(c, hipMemcpyAsync(b, z_host, cnt * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(b + o1, dt_host, cnt * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(kalman_kernel, dim3((rows + 63) / 64), dim3(64), 0, c->stream, (const float*)b, (const uint32_t*)(b + o1), rows, n, wrap, z0,
-                       (uint32_t)order, (float*)(b + o2));
+                       (uint32_t)order, (float*)(b + o2), c->level_gain + (size_t)order * core::LEVEL_SCHED_N);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out_host, b + o2, cnt * 24, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1825,15 +1727,14 @@ int m17hip_gather_frames_device(m17hip_ctx* c, m17hip_comm* m, int root, m17_fra
 
 int m17hip_comm_last_error(const m17hip_comm* m) { return m ? m->last_rccl : 0; }
 
-int m17hip_persist_stats(m17hip_ctx* c, uint32_t out[2])
+int m17hip_replay_drops(m17hip_ctx* c, uint64_t* count)
 {
-    if (!c || !out) return M17HIP_EINVAL;
+    if (!c || !count) return M17HIP_EINVAL;
     GUARD(c);
     uint32_t w[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(w, c->overflow, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    out[0] = w[1];
-    out[1] = w[2];
+    *count = w[1];
     return M17HIP_OK;
 }
 
@@ -1843,23 +1744,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     GUARD(c);
     if (c->front_pending) return M17HIP_ESTATE;
     switch (key) {
-    case 0:  // waves (= channels) per workgroup of the sequential kernel: 0 (default 4), 1, 2, 4 or 8
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return M17HIP_EINVAL;
-        c->seq_lanes = (uint32_t)value;
-        return M17HIP_OK;
-    case 1:  // per-channel tick counters of the sequential kernel on/off (m17hip_debug_counters)
-        c->profile = value != 0;
-        return M17HIP_OK;
-    case 2:  // K2 (speculative limit filter ahead of K5) on/off; off = K5 carries the filter itself
-        c->speculate = value != 0;
-        return M17HIP_OK;
+    // ---- deployment knobs (include/m17hip.h) ----------------------------------------------------------------------------------
     case 3:  // samples per K2+K5 segment of a run (0 = whole run)
         if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
         c->seg_len = (uint32_t)value;
-        return M17HIP_OK;
-    case 5:  // segments the front end may run ahead of K5 (0 = unlimited)
-        if (value < 0 || value > 1000) return M17HIP_EINVAL;
-        c->front_ahead = (uint32_t)value;
         return M17HIP_OK;
     case 6:  // BERT statistics (m17hip_bert_stats) on/off
         c->bert = value != 0;
@@ -1881,38 +1769,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         HIPCHK(c, hipGetLastError());
         return M17HIP_OK;
     }
-    case 12:  // segments of K1 complete before the first K5 (0 / 1 = its own only)
-        if (value < 0 || value > 1000) return M17HIP_EINVAL;
-        c->front_first = (uint32_t)value;
-        return M17HIP_OK;
-    case 11: {  // stream priorities of the front end: bit 0 = K1's stream lowest, bit 1 = K3's stream lowest, bit 2 = K3's stream highest
-        HIPCHK(c, hipDeviceSynchronize());
-        int least = 0, greatest = 0;
-        HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        hipStreamDestroy(c->side); hipStreamDestroy(c->side2);
-        c->side = c->side2 = nullptr;
-        HIPCHK(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, (value & 2) ? least : ((value & 4) ? greatest : 0)));
-        HIPCHK(c, hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, (value & 1) ? least : 0));
-        return M17HIP_OK;
-    }
-    case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1, default), or in K5 (0)
-        c->defer_decode = value != 0;
-        if (!c->defer_decode && c->defer_llr) {   // give the stores back (a run in flight may still use them: wait for it)
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            hipFree(c->defer_llr); hipFree(c->defer_hist);
-            c->defer_llr = nullptr; c->defer_hist = nullptr;
-        }
-        return M17HIP_OK;
-    case 14:  // LDS bytes per workgroup of the sequential kernel (at least its need: decides how many of them share a CU), 0 = default
-        if (value < 0 || value > 65536) return M17HIP_EINVAL;
-        c->seq_lds_bytes = (uint32_t)value;
-        return M17HIP_OK;
-    case 13:  // K1 form: 1 = rolled tap loop (default), 0 = straight-line (167 VGPRs), 2 = rolled with 11 outputs per lane (62 VGPRs)
-        if (value < 0 || value > 2) return M17HIP_EINVAL;
-        c->fir_form = (int)value;
-        return M17HIP_OK;
-    case 10:  // K3 form: 0 = one wave per 32 channels (default: best step time), 1 = four-wave pipeline (1.8x faster alone)
-        c->dcd_pipeline = value != 0;
+    case 8:  // record slots per channel and run actually used (0 = all that were allocated): exercises M17HIP_EOVERFLOW
+        if (value < 0 || value > (int64_t)c->rec_cap_alloc) return M17HIP_EINVAL;
+        c->rec_cap = value ? (uint32_t)value : c->rec_cap_alloc;
+        c->recs_valid = false;   // the slots of the last run were written with the old stride: nothing to fetch until the next run
         return M17HIP_OK;
     case 9: {  // diagnostic log: room for `value` diagnostic callbacks per channel and run, 0 = off (m17hip_diag_log_fetch)
         if (value < 0 || value > (1 << 20)) return M17HIP_EINVAL;
@@ -1926,10 +1786,40 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         c->diag_cap = (uint32_t)value;
         return M17HIP_OK;
     }
-    case 8:  // record slots per channel and run actually used (0 = all that were allocated): exercises M17HIP_EOVERFLOW
-        if (value < 0 || value > (int64_t)c->rec_cap_alloc) return M17HIP_EINVAL;
-        c->rec_cap = value ? (uint32_t)value : c->rec_cap_alloc;
-        c->recs_valid = false;   // the slots of the last run were written with the old stride: nothing to fetch until the next run
+    case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1, default), or in K5 (0)
+        c->defer_decode = value != 0;
+        if (!c->defer_decode && c->defer_llr) {   // give the stores back (a run in flight may still use them: wait for it)
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->defer_llr); hipFree(c->defer_hist);
+            c->defer_llr = nullptr; c->defer_hist = nullptr;
+        }
+        return M17HIP_OK;
+    case 16:  // the in-place producers (m17hip_upload_i16, m17hip_upload_i16_device, m17hip_synth_i16) write the STAGING slab instead
+        c->stage_inputs = value != 0;
+        return M17HIP_OK;
+#ifdef M17_TOOLS
+    // ---- measurement / experiment knobs: only in the tools build (make -C csrc tools -> libm17hip_tools.so), used by tools/*.py ------
+    case 1:  // section timers and counters of the sequential kernel (PROF instantiation; one segment per run) -> m17hip_debug_counters
+        c->profile = value != 0;
+        return M17HIP_OK;
+    case 19:  // per-wave working time of the sequential kernel, per segment (TIMED instantiation): m17hip_debug_counters slot = segment
+        c->wave_times = value != 0;
+        return M17HIP_OK;
+    case 4:  // samples of the first segment of a run (0 = like the others)
+        if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
+        c->seg0_len = (uint32_t)value;
+        return M17HIP_OK;
+    case 5:  // segments the front end may run ahead of K5 (0 = unlimited)
+        if (value < 0 || value > 1000) return M17HIP_EINVAL;
+        c->front_ahead = (uint32_t)value;
+        return M17HIP_OK;
+    case 12:  // segments of K1 complete before the first K5 (0 / 1 = its own only)
+        if (value < 0 || value > 1000) return M17HIP_EINVAL;
+        c->front_first = (uint32_t)value;
+        return M17HIP_OK;
+    case 14:  // LDS bytes per workgroup of the sequential kernel (at least its need: decides how many of them share a CU), 0 = default
+        if (value < 0 || value > 65536) return M17HIP_EINVAL;
+        c->seq_lds_bytes = (uint32_t)value;
         return M17HIP_OK;
     case 21:  // the matched filter of a staged run waits for K5 of this segment (1-based) of the run before it (0 = starts at once)
         if (value < 0 || value > 1000) return M17HIP_EINVAL;
@@ -1939,32 +1829,7 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         if (value != 0 && value != 1) return M17HIP_EINVAL;
         c->gate0_early = (int)value;
         return M17HIP_OK;
-    case 22:  // persistent K2 / K5: one launch of each per run, segment boundaries handed over in memory (PersistParams, m17_state.hpp)
-        if (value != 0 && value != 1) return M17HIP_EINVAL;
-        c->persist = (int)value;
-        return M17HIP_OK;
-    case 23:  // microseconds the persistent K2 waits for a channel's K5 at a boundary before it goes on without it
-        if (value < 1 || value > 10000000) return M17HIP_EINVAL;
-        c->k2_wait_us = (uint32_t)value;
-        return M17HIP_OK;
-    case 24:  // microseconds the persistent K5 waits for its replay wave before it declares the run void (M17HIP_ETIMEOUT)
-        if (value < 1 || value > 10000000) return M17HIP_EINVAL;
-        c->k5_wait_us = (uint32_t)value;
-        return M17HIP_OK;
-    case 20:  // redo policy: 1 = beside K5, state only (default); 0 = on the main stream ahead of K5, with the history stored
-        if (value != 0 && value != 1) return M17HIP_EINVAL;
-        c->redo_mode = (int)value;
-        return M17HIP_OK;
-    case 19:  // per-wave working time of the sequential kernel, per segment (production build): m17hip_debug_counters slot = segment
-        c->wave_times = value != 0;
-        return M17HIP_OK;
-    case 16:  // the in-place producers (m17hip_upload_i16, m17hip_upload_i16_device, m17hip_synth_i16) write the STAGING slab instead
-        c->stage_inputs = value != 0;
-        return M17HIP_OK;
-    case 4:  // samples of the first segment of a run (0 = like the others)
-        if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
-        c->seg0_len = (uint32_t)value;
-        return M17HIP_OK;
+#endif
     default: return M17HIP_EINVAL;
     }
 }
@@ -1974,7 +1839,7 @@ int m17hip_debug_counters(m17hip_ctx* c, uint64_t* host, uint32_t max_waves, uin
     if (!c || !host || !waves) return M17HIP_EINVAL;
     GUARD(c);
     const uint32_t n = std::min(max_waves, c->dbg_waves);
-    HIPCHK(c, hipMemcpy(host, c->dbg, (size_t)n * 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(host, c->dbg, (size_t)n * DBG_SLOTS * sizeof(uint64_t), hipMemcpyDeviceToHost));
     *waves = n;
     return M17HIP_OK;
 }

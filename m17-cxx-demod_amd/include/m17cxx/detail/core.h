@@ -160,14 +160,20 @@ M17_HD void kalman2_reset(Kalman2& k, float z)
 }
 // wrap != 0: KalmanFilter<float,SPS> (index filter, modulo SPS, :41-65); 0: SymbolKalmanFilter (:91-107).
 // The order is a template parameter so that each variant is straight-line code (the kernels dispatch once per update).
+//
+// The update is written as its two independent halves.  The COVARIANCE half (P = F P F^T + Q; S = H P H^T + R; P = P - K H P) never
+// reads x or z: it leaves the covariance after the predict step and 1 / S — all the state half needs — in a Kalman2Gain.  The STATE
+// half (x = F x; y = z - H x; x += K y) reads that gain and nothing of P.  kalman2_update_as = the one after the other, operation for
+// operation what the single function of rounds 1-3 did.
+struct Kalman2Gain {
+    float p00, p01, p10, p11;   // P after the predict step
+    double invS;
+};
 template <uint32_t order>
-M17_HD void kalman2_update_as(Kalman2& k, float z, uint32_t dt_u, int wrap)
+M17_HD void kalman2_cov_step(Kalman2& k, uint32_t dt_u, Kalman2Gain& g)
 {
     const float F00 = 1.f, F01 = (float)dt_u, F10 = 0.f, F11 = 1.f;
     const float Q00 = (float)6.25e-13, Q01 = (float)1.25e-12, Q10 = (float)1.25e-12, Q11 = (float)2.50e-12;
-    const float nx0 = F00 * k.x0 + F01 * k.x1;
-    const float nx1 = F10 * k.x0 + F11 * k.x1;
-    k.x0 = nx0; k.x1 = nx1;
     float B00, B01, B10, B11;
     if (!(order & 4u)) {
         const float A00 = F00 * k.p00 + F01 * k.p10, A01 = F00 * k.p01 + F01 * k.p11;
@@ -187,27 +193,7 @@ M17_HD void kalman2_update_as(Kalman2& k, float z, uint32_t dt_u, int wrap)
     const float ph0 = k.p00 * 1.f + k.p01 * 0.f;
     const float ph1 = k.p10 * 1.f + k.p11 * 0.f;
     const double invS = 1.0 / (double)S;
-    const double K0 = (double)ph0 * invS, K1 = (double)ph1 * invS;
-    const float fw = (float)wrap;
-    if (wrap) {
-        if ((double)(z - k.x0) < ((double)wrap / -2.0)) z += fw;
-        else if ((double)(z - k.x0) > ((double)wrap / 2.0)) z -= fw;
-    }
-    const float y = z - (1.f * k.x0 + 0.f * k.x1);
-    if (order & 1u) {
-        const float hy0 = 1.f * y, hy1 = 0.f * y;
-        const float t0 = k.p00 * hy0 + k.p01 * hy1;
-        const float t1 = k.p10 * hy0 + k.p11 * hy1;
-        k.x0 = (float)((double)k.x0 + (double)t0 * invS);
-        k.x1 = (float)((double)k.x1 + (double)t1 * invS);
-    } else {
-        k.x0 = (float)((double)k.x0 + K0 * (double)y);
-        k.x1 = (float)((double)k.x1 + K1 * (double)y);
-    }
-    if (wrap) {
-        while (k.x0 >= fw) k.x0 -= fw;
-        while (k.x0 < 0.f) k.x0 += fw;
-    }
+    g.p00 = k.p00; g.p01 = k.p01; g.p10 = k.p10; g.p11 = k.p11; g.invS = invS;
     float n00, n01, n10, n11;
     if (order & 2u) {
         const float G00 = ph0 * 1.f, G01 = ph0 * 0.f, G10 = ph1 * 1.f, G11 = ph1 * 0.f;
@@ -218,6 +204,7 @@ M17_HD void kalman2_update_as(Kalman2& k, float z, uint32_t dt_u, int wrap)
         n10 = (float)((double)k.p10 - (double)T10 * invS);
         n11 = (float)((double)k.p11 - (double)T11 * invS);
     } else {
+        const double K0 = (double)ph0 * invS, K1 = (double)ph1 * invS;
         const double KH00 = K0 * 1.0, KH01 = K0 * 0.0, KH10 = K1 * 1.0, KH11 = K1 * 0.0;
         n00 = (float)((double)k.p00 - (KH00 * (double)k.p00 + KH01 * (double)k.p10));
         n01 = (float)((double)k.p01 - (KH00 * (double)k.p01 + KH01 * (double)k.p11));
@@ -225,6 +212,44 @@ M17_HD void kalman2_update_as(Kalman2& k, float z, uint32_t dt_u, int wrap)
         n11 = (float)((double)k.p11 - (KH10 * (double)k.p01 + KH11 * (double)k.p11));
     }
     k.p00 = n00; k.p01 = n01; k.p10 = n10; k.p11 = n11;
+}
+template <uint32_t order>
+M17_HD void kalman2_state_step(float& x0, float& x1, float z, uint32_t dt_u, int wrap, const Kalman2Gain& g)
+{
+    const float F00 = 1.f, F01 = (float)dt_u, F10 = 0.f, F11 = 1.f;
+    const float nx0 = F00 * x0 + F01 * x1;
+    const float nx1 = F10 * x0 + F11 * x1;
+    x0 = nx0; x1 = nx1;
+    const float fw = (float)wrap;
+    if (wrap) {
+        if ((double)(z - x0) < ((double)wrap / -2.0)) z += fw;
+        else if ((double)(z - x0) > ((double)wrap / 2.0)) z -= fw;
+    }
+    const float y = z - (1.f * x0 + 0.f * x1);
+    if (order & 1u) {
+        const float hy0 = 1.f * y, hy1 = 0.f * y;
+        const float t0 = g.p00 * hy0 + g.p01 * hy1;
+        const float t1 = g.p10 * hy0 + g.p11 * hy1;
+        x0 = (float)((double)x0 + (double)t0 * g.invS);
+        x1 = (float)((double)x1 + (double)t1 * g.invS);
+    } else {
+        const float ph0 = g.p00 * 1.f + g.p01 * 0.f;
+        const float ph1 = g.p10 * 1.f + g.p11 * 0.f;
+        const double K0 = (double)ph0 * g.invS, K1 = (double)ph1 * g.invS;
+        x0 = (float)((double)x0 + K0 * (double)y);
+        x1 = (float)((double)x1 + K1 * (double)y);
+    }
+    if (wrap) {
+        while (x0 >= fw) x0 -= fw;
+        while (x0 < 0.f) x0 += fw;
+    }
+}
+template <uint32_t order>
+M17_HD void kalman2_update_as(Kalman2& k, float z, uint32_t dt_u, int wrap)
+{
+    Kalman2Gain g;
+    kalman2_cov_step<order>(k, dt_u, g);
+    kalman2_state_step<order>(k.x0, k.x1, z, dt_u, wrap, g);
 }
 M17_HD void kalman2_update(Kalman2& k, float z, uint32_t dt_u, int wrap, uint32_t order)
 {
@@ -238,6 +263,47 @@ M17_HD void kalman2_update(Kalman2& k, float z, uint32_t dt_u, int wrap, uint32_
     case 6: kalman2_update_as<6>(k, z, dt_u, wrap); break;
     default: kalman2_update_as<7>(k, z, dt_u, wrap); break;
     }
+}
+
+// ---- a10: the gain SCHEDULE of FreqDevEstimator's two level filters (FreqDevEstimator.h:31-48: both are updated with dt = 192 and
+// reset together, KalmanFilter.h:91-107).  Their covariance is therefore a function of the number of updates since the reset alone,
+// the same for both, and in fp32 it reaches a FIXED POINT after 558 / 559 updates under every evaluation order (checked where the
+// table is built and in tests/cxx/mirror_check.cpp): entry n = the gain of update n + 1 after a reset, entry LEVEL_SCHED_LAST for
+// every later one.  A filter is then (x0, x1) plus the shared count: an update is kalman2_state_step with a table entry — no
+// covariance arithmetic, no f64 division.
+constexpr uint32_t LEVEL_DT = 192;
+constexpr int LEVEL_SCHED_N = 576, LEVEL_SCHED_LAST = LEVEL_SCHED_N - 1;
+template <uint32_t order>
+inline bool level_schedule_as(Kalman2Gain* tab)   // [LEVEL_SCHED_N]; false if the covariance has not settled (cannot happen: see above)
+{
+    Kalman2 k;
+    kalman2_reset(k, 0.f);
+    for (int n = 0; n < LEVEL_SCHED_N; ++n) kalman2_cov_step<order>(k, LEVEL_DT, tab[n]);
+    Kalman2 k2 = k;
+    Kalman2Gain g;
+    kalman2_cov_step<order>(k2, LEVEL_DT, g);
+    const Kalman2Gain& l = tab[LEVEL_SCHED_LAST];
+    return k2.p00 == k.p00 && k2.p01 == k.p01 && k2.p10 == k.p10 && k2.p11 == k.p11 && g.p00 == l.p00 && g.p01 == l.p01 && g.p10 == l.p10 &&
+           g.p11 == l.p11 && g.invS == l.invS;
+}
+inline bool level_schedule(Kalman2Gain* tab, uint32_t order)
+{
+    switch (order & 7u) {
+    case 0: return level_schedule_as<0>(tab);
+    case 1: return level_schedule_as<1>(tab);
+    case 2: return level_schedule_as<2>(tab);
+    case 3: return level_schedule_as<3>(tab);
+    case 4: return level_schedule_as<4>(tab);
+    case 5: return level_schedule_as<5>(tab);
+    case 6: return level_schedule_as<6>(tab);
+    default: return level_schedule_as<7>(tab);
+    }
+}
+// one level filter, scheduled: (x0, x1) after the update that uses entry g; `order` only selects how x += K y is associated (bit 0)
+M17_HD void level_update(float& x0, float& x1, float z, const Kalman2Gain& g, uint32_t order)
+{
+    if (order & 1u) kalman2_state_step<1>(x0, x1, z, LEVEL_DT, 0, g);
+    else kalman2_state_step<0>(x0, x1, z, LEVEL_DT, 0, g);
 }
 
 // ClockRecovery (ClockRecovery.h:54-88): int8 wrap of the rounded estimate into 0..9

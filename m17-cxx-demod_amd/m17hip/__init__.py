@@ -39,7 +39,7 @@ EXPORTS = [
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_packets_fetch", "m17hip_packets_feed", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
     "m17hip_set_kalman_order", "m17hip_kalman_trace", "m17hip_set_channel_base", "m17hip_upload_wait", "m17hip_comm_get_id", "m17hip_comm_create",
     "m17hip_comm_destroy", "m17hip_comm_last_error", "m17hip_gather_frames", "m17hip_gather_frames_device", "m17hip_diag_log_fetch",
-    "m17hip_upload_i16_device_async", "m17hip_input_alternate", "m17hip_demod_front", "m17hip_advice", "m17hip_persist_stats",
+    "m17hip_upload_i16_device_async", "m17hip_input_alternate", "m17hip_demod_front", "m17hip_advice", "m17hip_replay_drops",
 ]
 ETRUNC = -6
 COMM_ID_BYTES = 128
@@ -106,7 +106,7 @@ class Context:
         self._chk(self.lib.m17hip_ctx_create(C.c_int(device), C.c_uint32(max_channels), C.c_uint32(max_samples), C.byref(self.h)))
         if stream is not None:
             self.set_stream(stream)
-        if self.lib.m17hip_advice(self.h) & 1 and not Context._warned:
+        if not Context._warned and self.lib.m17hip_advice(self.h) & 1:
             Context._warned = True
             import warnings
             warnings.warn("m17hip: GPU_MAX_HW_QUEUES is unset or below 8 — the streams of a context (and of several contexts) will share "
@@ -350,17 +350,17 @@ class Context:
         n = np.ascontiguousarray(counts, dtype=np.uint32)
         self._chk(self.lib.m17hip_packets_feed(self.h, _ptr(r), _ptr(n), C.c_uint32(r.shape[0]), C.c_uint32(r.shape[1])))
 
-    def persist_stats(self):
-        """(sequential waves that gave up waiting, boundaries the replay did not wait for) — m17hip_persist_stats."""
-        out = (C.c_uint32 * 2)()
-        self._chk(self.lib.m17hip_persist_stats(self.h, out))
-        return int(out[0]), int(out[1])
+    def replay_drops(self):
+        """Times a channel left the limit-filter replay since the last reset (m17hip_replay_drops)."""
+        n = C.c_uint64(0)
+        self._chk(self.lib.m17hip_replay_drops(self.h, C.byref(n)))
+        return int(n.value)
 
     def tune(self, key, value):
         self._chk(self.lib.m17hip_tune(self.h, C.c_int(key), C.c_int64(value)))
 
     def debug_counters(self, max_waves=4096):
-        buf = np.zeros((max_waves, 24), dtype=np.uint64)
+        buf = np.zeros((max_waves, 40), dtype=np.uint64)   # (csrc/m17_state.hpp DBG_SLOTS)
         n = C.c_uint32(0)
         self._chk(self.lib.m17hip_debug_counters(self.h, _ptr(buf), C.c_uint32(max_waves), C.byref(n)))
         return buf[: n.value]

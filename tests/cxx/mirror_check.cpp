@@ -284,6 +284,21 @@ int main(int argc, char** argv)
         save(argv[7], out);
         return 0;
     }
+    if (mode == "kalman_sched") {   // kalman_sched order z0 z.f32 out.f32 : a level filter in its scheduled form (core::level_schedule +
+                                    // core::level_update, what kernel K5 runs): x0, x1 after every update; exit code 3 if the covariance has no fixed point
+        const uint32_t order = (uint32_t)std::atoi(argv[2]);
+        float x0 = (float)std::atof(argv[3]), x1 = 0.f;
+        auto z = load<float>(argv[4]);
+        std::vector<core::Kalman2Gain> tab(core::LEVEL_SCHED_N);
+        if (!core::level_schedule(tab.data(), order)) return 3;
+        std::vector<float> out;
+        for (size_t i = 0; i < z.size(); ++i) {
+            core::level_update(x0, x1, z[i], tab[std::min<size_t>(i, core::LEVEL_SCHED_LAST)], order);
+            out.push_back(x0); out.push_back(x1);
+        }
+        save(argv[5], out);
+        return 0;
+    }
     if (mode == "clock") {   // clock op.u8 index.u8 count.u32 out.f32 : ClockRecovery<float,10>; per step (sample_index, clock_estimate)
         auto op = load<uint8_t>(argv[2]); auto idx = load<uint8_t>(argv[3]); auto cnt = load<uint32_t>(argv[4]);
         ClockRecovery<float, 10> c;

@@ -19,6 +19,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.m17hip_strerror(-2) == b"HIP runtime error"
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """`nm -D --defined-only`: only m17hip_* (no kernel stubs, no helpers, no C++ symbols) — csrc/m17hip.map."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", m17hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [line.split()[-1] for line in out.splitlines() if line.strip()]
+    assert names, "no dynamic symbols listed"
+    stray = [n for n in names if not n.startswith("m17hip_")]
+    assert not stray, stray
+    assert sorted(names) == sorted(m17hip.EXPORTS)
+
+
 def test_record_layouts_match_header():
     import oracle_lib as ol
     assert m17hip.FRAME_REC == ol.FRAME_REC and m17hip.DIAG == ol.DIAG

@@ -185,6 +185,13 @@ def test_kalman_clock_and_deviation_classes_equal_the_oracle(exe, tmp_path):
                 lib.m17o_kalman_trace(ol._p(zz), ol._p(np.ascontiguousarray(dd, dtype=np.uint32)), C.c_size_t(300), C.c_int(wrap), C.c_float(z0), ol._p(exp))
                 run(exe, "kalman", order, wrap, z0, tmp_path / zf, tmp_path / df, tmp_path / "k.f32")
                 assert np.array_equal(np.fromfile(tmp_path / "k.f32", dtype=np.float32).reshape(300, 6), exp), (order, wrap)
+            # the level filters as kernel K5 runs them: covariance from the gain schedule (its last entry = the fixed point), state arithmetic only
+            lv2 = (5.2 * (1 + rng.normal(0, 0.05, 900))).astype(np.float32); lv2[800] = np.inf
+            lv2.tofile(tmp_path / "lv2.f32")
+            exp = np.zeros((900, 6), dtype=np.float32)
+            lib.m17o_kalman_trace(ol._p(lv2), ol._p(np.full(900, 192, np.uint32)), C.c_size_t(900), C.c_int(0), C.c_float(5.0), ol._p(exp))
+            run(exe, "kalman_sched", order, 5.0, tmp_path / "lv2.f32", tmp_path / "ks.f32")
+            assert np.array_equal(np.fromfile(tmp_path / "ks.f32", dtype=np.float32).reshape(900, 2), exp[:, :2], equal_nan=True), order
     finally:
         lib.m17o_set_kalman_order(C.c_int(3))
     op = rng.choice([0, 1, 1, 1, 2, 2], 400).astype(np.uint8); op[0] = 0

@@ -191,44 +191,22 @@ def test_two_batches_in_flight_equal_one_after_the_other():
 
 
 def test_performance_knobs_do_not_change_results():
-    """m17hip_tune keys that only move work around (K1 form, K3 form, LDS request of the sequential kernel, waves per workgroup,
-    segment length, K2 on / off): the same records and diagnostics under every setting."""
+    """m17hip_tune keys that only move work around (segment length, where payload frames are decoded): the same records under every
+    setting; keys the production library does not have (the measurement build's) are M17HIP_EINVAL."""
     x = _signals(48, 96000, seed=71, sigma=900.0)
     exp = _oracle_flat(x)
     c = m17hip.Context(48, 96000)
     c.upload(x)
-    for settings in ({}, {13: 0}, {13: 2}, {10: 1}, {14: 1}, {14: 40000}, {0: 8}, {0: 1}, {3: 19200}, {2: 0}, {3: 0, 13: 0, 14: 65536}, {15: 0}, {15: 0, 3: 7001}, {20: 0}, {20: 0, 3: 19200}, {3: 4800}):
+    for settings in ({}, {3: 19200}, {3: 0}, {15: 0}, {15: 0, 3: 7001}, {3: 4800}, {3: 1000}):
         for k, v in settings.items():
             c.tune(k, v)
         c.reset(); c.run()
         assert c.frames().tobytes() == exp.tobytes(), settings
         for k in settings:
-            c.tune(k, {13: 1, 10: 0, 14: 0, 0: 0, 3: 48000, 2: 1, 15: 1, 20: 1}[k])   # back to the defaults
+            c.tune(k, {3: 48000, 15: 1}[k])   # back to the defaults
     import ctypes as C_
-    assert c.lib.m17hip_tune(c.h, 14, C_.c_int64(70000)) == -1 and c.lib.m17hip_tune(c.h, 13, C_.c_int64(3)) == -1
-    c.close()
-
-
-def test_persistent_hand_over_timeout_is_reported_and_recoverable():
-    """m17hip_tune key 22 (persistent replay / sequential kernels): a sequential wave that gives up waiting for its replay wave makes the
-    fetch calls return M17HIP_ETIMEOUT — nothing hangs — and a reset clears it.  Forced here with a 1 us patience (key 24); with the
-    defaults the same run delivers the oracle's records and no wave gives up."""
-    x = _signals(40, 96000, seed=73, sigma=900.0)
-    exp = _oracle_flat(x)
-    c = m17hip.Context(40, 96000)
-    c.tune(22, 1); c.tune(3, 9600)
-    c.upload(x); c.reset(); c.run()
-    assert c.frames().tobytes() == exp.tobytes()
-    assert c.persist_stats()[0] == 0
-    c.tune(24, 1); c.tune(23, 100)          # K5 waits 1 us for its replay, the replay 100 us for K5
-    c.reset(); c.run()
-    with pytest.raises(m17hip.M17HipError, match="error -8"):
-        c.frames()
-    assert c.persist_stats()[0] > 0
-    c.tune(24, 2000000); c.tune(23, 20000)
-    c.reset(); c.run()                        # (the reset clears the flag)
-    assert c.frames().tobytes() == exp.tobytes()
-    assert c.persist_stats()[0] == 0
+    for key in (0, 1, 2, 4, 5, 10, 12, 13, 14, 19, 20, 21, 22, 25):
+        assert c.lib.m17hip_tune(c.h, key, C_.c_int64(1)) == -1, key
     c.close()
 
 

@@ -55,6 +55,15 @@ def test_kalman_update_bit_exact_each_order(ctx, oracle_order, order):
     exp = _oracle_trace(lv, d192, 0, float(lv[0, 0]))
     assert np.array_equal(got, exp, equal_nan=True)
     assert np.isnan(got[3, 50:, :2]).all() and np.isfinite(got[7]).all()   # a NaN measurement poisons x, never P
+    # the level filters as K5 runs them — the covariance from the gain schedule (detail/core.h level_schedule), state arithmetic only —
+    # over more updates than the schedule is long (its last entry is the covariance's fixed point)
+    n2 = 900
+    lv = (rng.choice([-5.2, 5.2, 0.6], (rows, 1)) * (1 + rng.normal(0, 0.05, (rows, n2)))).astype(np.float32)
+    lv[3, 700] = np.nan; lv[4, 10] = np.inf; lv[6, :] = 0.0
+    d192 = np.full((rows, n2), 192, dtype=np.uint32)
+    got = ctx.kalman_trace(lv, d192, -1, z0=float(lv[0, 0]), order=order)
+    exp = _oracle_trace(lv, d192, 0, float(lv[0, 0]))
+    assert np.array_equal(got[..., :2], exp[..., :2], equal_nan=True)
 
 
 @pytest.mark.parametrize("order", [0, 1, 2, 3, 7])

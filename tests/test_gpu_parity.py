@@ -23,21 +23,13 @@ def _oracle_records(x, invert=0):
     return flat, counts, diags
 
 
-@pytest.fixture(scope="module", params=[(1, 0, 1, 1, 0), (0, 0, 1, 1, 0), (1, 1, 0, 1, 0), (1, 0, 1, 0, 0), (1, 0, 1, 1, 1)],
-                ids=["limit_ahead", "limit_inline", "k3_pipeline_decode_in_k5", "redo_on_main_stream", "persistent_k2_k5"])
+@pytest.fixture(scope="module", params=[1, 0], ids=["default", "decode_in_k5"])
 def ctx(request):
-    """Every test runs three times: with the correlator's limit filter run ahead of the sequential kernel (K2, the default), with
-    the sequential kernel carrying it itself (tuning knob 2 = 0, also the fallback of a dropped speculation), and with the
-    carrier-detect kernel K3 in its four-wave pipeline form (tuning knob 10 = 1) instead of one wave per 32 channels."""
+    """Every test runs twice: with the payload frames of running transmissions decoded after the run, one lane per frame (the default),
+    and with every frame decoded by the sequential kernel's wave where it completes (m17hip_tune key 15 = 0)."""
     c = m17hip.Context(256, 96000)
-    c.tune(2, request.param[0])
-    c.tune(10, request.param[1])
-    c.tune(15, request.param[2])   # payload frames decoded after the run (default) / where they complete
-    c.tune(20, request.param[3])   # the replay's redo beside K5, state only (default) / on the main stream ahead of K5
-    c.tune(22, request.param[4])   # K2 and K5 of a run as one launch each, segment boundaries handed over in memory
-    c.limit_ahead = bool(request.param[0])
+    c.tune(15, request.param)
     yield c
-    assert c.persist_stats()[0] == 0   # (persistent form: no sequential wave gave up waiting for its replay)
     c.close()
 
 
@@ -292,24 +284,17 @@ def test_full_chain_lost_sync_drops_limit_speculation(ctx):
     p = ol.gen_params(seed=41, kind=-1, n_frames=6, lead_in=3072, noise_sigma=500.0, tail_sigma=3000.0, lead_sigma=40000.0, total=T)
     x = ol.generate_batch(p, C, T, threads=8)
     exp, counts, diags = _oracle_records(x)
-    ctx.tune(1, 1)
-    try:
-        ctx.upload(x)
-        ctx.reset()
-        ctx.run()
-        dropped = ctx.debug_counters(C)[:, 17]
-    finally:
-        ctx.tune(1, 0)
+    ctx.upload(x)
+    ctx.reset()
+    ctx.run()
     got = ctx.frames()
+    dropped = ctx.replay_drops()
     assert got.tobytes() == exp.tobytes() and got.size > C
     d = ctx.diag()
     for f in ("dcd", "locked", "viterbi_cost", "n_diag", "demod_state", "n_frames"):
         assert np.array_equal(d[f], diags[f]), f
     assert np.array_equal(d["dcd_level"], diags["dcd_level"], equal_nan=True)
-    if ctx.limit_ahead:
-        assert (dropped > 0).sum() >= C // 2, dropped   # the scenario does exercise the fallback
-    else:
-        assert (dropped == 0).all()
+    assert dropped >= C // 2, dropped   # the scenario does exercise the fallback: most channels left the replay at least once
     # ... and the next runs (fresh speculation from the saved state) continue bit-exact: same input as two chunks
     ctx.reset()
     parts = []
@@ -358,7 +343,7 @@ def test_full_chain_two_bursts_across_segments(ctx):
     exp, counts, diags = _oracle_records(x)
     second = exp[exp["sample_pos"] >= 36000] if "sample_pos" in exp.dtype.names else exp
     assert second.size > C   # the second burst does decode in the reference
-    ctx.tune(3, 9600); ctx.tune(4, 0)
+    ctx.tune(3, 9600)
     try:
         ctx.upload(x)
         ctx.reset()
@@ -366,7 +351,7 @@ def test_full_chain_two_bursts_across_segments(ctx):
         got = ctx.frames()
         d = ctx.diag()
     finally:
-        ctx.tune(3, 48000); ctx.tune(4, 0)
+        ctx.tune(3, 48000)
     assert got.tobytes() == exp.tobytes()
     for f in ("dcd", "locked", "viterbi_cost", "n_diag", "demod_state", "n_frames"):
         assert np.array_equal(d[f], diags[f]), f

@@ -32,14 +32,12 @@ def _sorted(parts):
     return got[np.lexsort((got["seq"], got["channel"]))]
 
 
-@pytest.fixture(scope="module", params=[{}, {2: 0}, {10: 1, 15: 0}, {3: 7001}, {20: 0}, {22: 1, 3: 9600}, {22: 1, 3: 7001}, {25: 0}],
-                ids=["default", "limit_inline", "k3_pipeline_decode_in_k5", "seg7001", "redo_on_main_stream", "persistent_seg9600", "persistent_seg7001", "first_replay_queued_by_run"])
+@pytest.fixture(scope="module", params=[{}, {15: 0}, {3: 7001}, {3: 9600, 15: 0}], ids=["default", "decode_in_k5", "seg7001", "seg9600_decode_in_k5"])
 def ctx(request):
     c = m17hip.Context(64, 48000)
     for k, v in request.param.items():
         c.tune(k, v)
     yield c
-    assert c.persist_stats()[0] == 0   # no wave of a persistent sequential kernel ever gave up waiting for its replay
     c.close()
 
 

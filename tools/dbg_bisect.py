@@ -1,5 +1,5 @@
 """Debugging aid: first prefix length at which the HIP chain and the oracle disagree on one channel's live state (demod state, clock
-count, sync counters, frame count, last diagnostics) — usage: [SPEC=0|1 SEG=n INV=0|1] dbg_bisect.py <x.npy> <channel> [lo hi]"""
+count, sync counters, frame count, last diagnostics) — usage: [DEFER=0|1 SEG=n INV=0|1] dbg_bisect.py <x.npy> <channel> [lo hi]"""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -9,8 +9,8 @@ FULL = int(os.environ.get('FULL', 0))   # 1: run the whole batch (neighbouring c
 x = np.load(sys.argv[1])
 if not FULL:
     x = np.concatenate([x[CH:CH + 1], x[CH:CH + 1]]); CH = 0
-SPEC, SEG, INV = int(os.environ.get('SPEC', 0)), int(os.environ.get('SEG', 0)), int(os.environ.get('INV', 0))
-ctx = m17hip.Context(x.shape[0], x.shape[1]); ctx.tune(2, SPEC); ctx.tune(3, SEG); ctx.tune(4, int(os.environ.get('SEG0', 0)))
+DEFER, SEG, INV = int(os.environ.get('DEFER', 1)), int(os.environ.get('SEG', 0)), int(os.environ.get('INV', 0))
+ctx = m17hip.Context(x.shape[0], x.shape[1]); ctx.tune(15, DEFER); ctx.tune(3, SEG)
 FIELDS = ('demod_state', 'n_frames', 'n_diag', 'dcd', 'locked', 'sample_index', 'sync_index', 'clock_index', 'viterbi_cost', 'clock', 'evm', 'offset', 'deviation', 'dcd_level')
 def live(n):
     recs, counts, diags = ol.demod_batch(x[CH:CH + 1, :n], invert=INV, cap=256, threads=1)

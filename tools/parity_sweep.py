@@ -1,5 +1,5 @@
 """Randomised parity sweep on the GPU box: the scenario generator of tests/test_gpu_parity.py::test_full_chain_random_scenarios over
-many seeds, both limit-filter modes, several segment lengths; prints the channels whose records or diagnostics differ from the oracle.
+many seeds, both decode placements, several segment lengths, run boundaries at random samples, pipelined runs; prints the channels whose records or diagnostics differ from the oracle.
 Usage: parity_sweep.py <first seed> <n seeds>"""
 import sys, os, numpy as np
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
@@ -32,12 +32,10 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     recs, counts, diags = ol.demod_batch(x, invert=inv, cap=2 * (T // 1920 + 2) + 4, threads=os.cpu_count())
     cuts = sorted(int(v) for v in rng.integers(1, T, size=2))
     rseg = int(rng.integers(3000, 30000))
-    # (limit filter ahead, segment length, run boundaries, redo policy [m17hip_tune 20], staged + m17hip_demod_front)
-    # redo policy 2 = the persistent form of K2 / K5 (m17hip_tune 22)
-    for spec, seg, pieces, redo, piped in ((1, 19200, None, 1, 0), (1, rseg, None, 1, 0), (1, rseg, None, 0, 0), (0, 0, None, 1, 0), (1, 19200, [0] + cuts + [T], 1, 0),
-                                           (1, 19200, [0] + cuts + [T], 1, 1), (1, rseg, [0] + cuts + [T], 0, 1), (0, 0, [0] + cuts + [T], 1, 0),
-                                           (1, rseg, None, 2, 0), (1, 4800, [0] + cuts + [T], 2, 1)):
-        ctx.tune(2, spec); ctx.tune(3, seg); ctx.tune(20, 1 if redo == 2 else redo); ctx.tune(22, 1 if redo == 2 else 0); ctx.reset()
+    # (payload frames decoded after the run [m17hip_tune 15], segment length, run boundaries, staged + m17hip_demod_front)
+    for spec, seg, pieces, piped in ((1, 19200, None, 0), (1, rseg, None, 0), (0, rseg, None, 0), (1, 0, None, 0), (1, 19200, [0] + cuts + [T], 0),
+                                     (1, 19200, [0] + cuts + [T], 1), (0, rseg, [0] + cuts + [T], 1), (1, 4800, [0] + cuts + [T], 1)):
+        ctx.tune(15, spec); ctx.tune(3, seg); ctx.reset()
         if pieces is None:
             ctx.upload(x); ctx.run(flags=inv); got = ctx.frames()
         elif not piped:   # the same stream as three runs (state, filter history and DCD sums carried between them)
@@ -65,5 +63,5 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
         bad = [c for c in range(C) if got[got['channel'] == c].tobytes() != recs[c, :counts[c]].tobytes()
                or any(not np.array_equal(d[f][c:c + 1], diags[f][c:c + 1], equal_nan=True) for f in d.dtype.names if f in diags.dtype.names)]
         total_bad += len(bad)
-        print(f'seed {seed} invert={inv} limit_ahead={spec} seg={seg} redo={redo} piped={piped} runs={"1" if pieces is None else pieces}: frames {int(counts.sum())}, bad channels {bad}', flush=True)
-print('TOTAL bad channel-runs:', total_bad, ' persistent hand-over (gave up, went on):', ctx.persist_stats())
+        print(f'seed {seed} invert={inv} deferred_decode={spec} seg={seg} piped={piped} runs={"1" if pieces is None else pieces}: frames {int(counts.sum())}, bad channels {bad}', flush=True)
+print('TOTAL bad channel-runs:', total_bad, ' replay drops since the last reset:', ctx.replay_drops())

@@ -1,15 +1,15 @@
 """Timing experiments on the sequential kernel (GPU box): waves-per-block sweep + per-channel tick counters."""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import _toolslib  # noqa: F401  (the measurement build of the library)
 import m17hip, oracle_lib as ol
-if os.environ.get('M17HIP_LIB'): m17hip.LIB_PATH = os.environ['M17HIP_LIB']   # experiment builds
 C, T = int(sys.argv[1]), int(sys.argv[2])
 p = ol.gen_params(seed=20260101, kind=-1, n_frames=T//1920-6, lead_in=3072, noise_sigma=600., tail_sigma=600., lead_sigma=40000.0, total=T)
 x = ol.generate_batch(p, C, T, threads=64)
 ctx = m17hip.Context(C, T); ctx.upload(x)
-for wpb in [int(v) for v in sys.argv[3].split(',')]:
-    ctx.tune(0, wpb); ctx.tune(1, 1); ctx.reset(); ctx.timing(True); ctx.timing_reset(); ctx.run(); d = ctx.diag()
+for wpb in (4,):
+    ctx.tune(1, 1); ctx.reset(); ctx.timing(True); ctx.timing_reset(); ctx.run(); d = ctx.diag()
     dc = ctx.debug_counters(C).astype(np.float64); m = np.median(dc, axis=0); mx = dc.max(axis=0)
     print(f"wpb={wpb} ms: fir={ctx.timing_get('fir_rrc150')[0]:.2f} dcd={ctx.timing_get('dcd')[0]:.2f} seq={ctx.timing_get('demod_seq')[0]:.2f} frames={int(d['n_frames'].sum())}")
     print('   per-channel ticks(10ns) median: total %.3g bulk %.3g scalar %.3g decode %.3g | n_bulk %d n_scalar %d bulk_samples %d flips %d decodes %d | max total %.3g'

@@ -3,8 +3,9 @@
 python tools/slow_channels.py [samples=96000] [channels=4096]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, "m17-cxx-demod_amd"), os.path.join(ROOT, "tests")):
+for p in (os.path.join(ROOT, "m17-cxx-demod_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     sys.path.insert(0, p)
+import _toolslib  # noqa: F401  (the measurement build of the library)
 import numpy as np
 import torch
 import m17hip, oracle_lib as ol
@@ -32,6 +33,9 @@ for c in order[:8]:
 print("around the median:")
 for c in order[C // 2: C // 2 + 3]:
     print(row(int(c)))
+    t = d[int(c)]
+    print("      iterations by kind: none %d init %d quiet %d feed %d frame %d search %d syncwin %d | frame chunks cut by a clock move %d, ended by a pending clock flag %d, by the DCD point %d, by the 480-sample chunk size %d"
+          % tuple(int(t[24 + k]) for k in (0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11)))
 dr = d[:, 17] > 0
 print(f"dropped {int(dr.sum())} channels: mean total {tot[dr].mean():.2f} ms vs {tot[~dr].mean():.2f} ms; mean iir {d[dr, 14].mean()/1e5:.2f}, search {d[dr, 15].mean()/1e5:.2f}, single {d[dr, 2].mean()/1e5:.2f}, "
       f"bulk {d[dr, 1].mean()/1e5:.2f} (not dropped: iir {d[~dr, 14].mean()/1e5:.2f} search {d[~dr, 15].mean()/1e5:.2f} single {d[~dr, 2].mean()/1e5:.2f} bulk {d[~dr, 1].mean()/1e5:.2f})")

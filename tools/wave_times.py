@@ -4,9 +4,9 @@ slowest wave)?  m17hip_tune key 19.  One run of the bench workload alone on the 
 runs before) or after a reset.   python tools/wave_times.py [--reset 1] [--channels 4096] [--tune k=v,...]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, "m17-cxx-demod_amd"), os.path.join(ROOT, "tests")):
+for p in (os.path.join(ROOT, "m17-cxx-demod_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     sys.path.insert(0, p)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import _toolslib  # noqa: F401  (the measurement build of the library)
 import numpy as np
 import torch
 import m17hip, oracle_lib as ol
@@ -35,10 +35,7 @@ if a.reset:
     ctx.reset()
 ctx.input_alternate(C, T); ctx.run()
 ctx.frames_count()
-persist = "22=1" in a.tune.split(",")
-d = ctx.debug_counters(C + C // 16 + 1)
-k2 = d[C:C + (C + 15) // 16] if persist and len(d) > C else None
-d = d[:C]
+d = ctx.debug_counters(C)[:C]
 nseg = (T + 47999) // 48000
 print("segment:  median    p90     p99     max (ms)   dropped   slowest channels (ms, D = dropped the speculation)")
 for k in range(nseg):
@@ -53,15 +50,3 @@ print(f"per channel over the run: median {np.median(tot):.2f} ms, p99 {np.percen
 dd = ((d[:, :nseg] >> np.uint64(62)) & np.uint64(1)).astype(int)
 print("channels that dropped in n segments:", np.bincount(dd.sum(axis=1)))
 print("odd (voice) share of the drops per segment:", [int(dd[1::2, k].sum()) for k in range(nseg)], "of", [int(dd[:, k].sum()) for k in range(nseg)])
-if persist:   # the persistent form: how long each wave WAITED for its replay wave in front of each segment, and what the replay waves did
-    print("waits in front of segment (ms):  median    p90     p99     max")
-    for k in range(1, min(nseg, 12)):
-        w = d[:, 12 + k].astype(np.float64) / 1e5
-        print(f"{k:4d}                          {np.median(w):7.3f} {np.percentile(w, 90):7.3f} {np.percentile(w, 99):7.3f} {w.max():7.3f}")
-    wt = d[:, 13:12 + min(nseg, 12)].astype(np.float64).sum(axis=1) / 1e5
-    print(f"per channel over the run: waiting median {np.median(wt):.2f} ms, p99 {np.percentile(wt, 99):.2f}, max {wt.max():.2f}; working + waiting median {np.median(tot + wt):.2f}, max {(tot + wt).max():.2f}")
-    if k2 is not None:
-        f = k2.astype(np.float64) / 1e5
-        print(f"replay waves ({len(k2)}): waiting median {np.median(f[:, 0]):.2f} max {f[:, 0].max():.2f} ms; redo passes median {np.median(f[:, 1]):.2f} max {f[:, 1].max():.2f} ms "
-              f"({np.median(k2[:, 3]):.0f} / {k2[:, 3].max()} of them); ahead passes median {np.median(f[:, 2]):.2f} max {f[:, 2].max():.2f} ms")
-        print("end of step k (ms since the wave's start), median / max:", " ".join(f"{np.median(f[:, 4 + k]):.1f}/{f[:, 4 + k].max():.1f}" for k in range(min(nseg - 1, 20))))
