@@ -595,7 +595,12 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     o1 = (s.sample_index + 10u - idx0) % 10u;                       // offset of the first payload symbol
                     const uint32_t remaining = (368u - s.framer_idx) >> 1;          // symbols until the frame is complete
                     const uint32_t last = o1 + 10u * (remaining - 1u);              // offset of the completing symbol
-                    n = min(last + 1u, lim);
+                    // (a frame chunk is bounded by neither the sample window nor the carrier-detect update points: it takes its symbol
+                    //  samples from the channel's row and serves the update points that fall inside it on its way)
+                    uint32_t lim_f = P.T - t;
+                    if (s.need_clock_reset | s.need_clock_update) lim_f = min(lim_f, 10u - idx0);
+                    if (diverged) lim_f = min(lim_f, 960u - s.count);   // (a wave that serves itself the limit filter does so from update point to update point: no sample may be passed over)
+                    n = min(last + 1u, lim_f);
                     completes = n == last + 1u;
                     mode = BULK_FRAME;
                 }
@@ -606,15 +611,34 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             n_mode[mode & 7]++;
             if (mode == BULK_FRAME && !completes) {
                 if ((s.need_clock_reset | s.need_clock_update) && n == 10u - s.ring_pos % 10u) n_lim_clock++;
-                else if (n == 960u - s.count) n_lim_count++;
-                else if (n == (uint32_t)WV_YCH) n_lim_room++;
+                else if (n == P.T - t) n_lim_room++;
             }
         }
+        bool frame_done = false;
         if (mode == BULK_FRAME) {
-            // every anti-phase clock_recovery.update() of the chunk (:601-606) must leave sample_index where it is
+            // ---- FRAME CHUNK: up to a whole frame (184 symbols, 1840 samples) at once.  do_frame (:596-654) touches one sample in ten
+            // (the symbol at index() == sample_index) plus the anti-phase clock prediction (:601-606), so the chunk does not go through
+            // the sample window: lane l takes symbols l, l + 64, l + 128 straight from the channel's matched-filter row (three gathers,
+            // in flight during the clock checks), slices them, and the running EVM is folded in order.  Carrier-detect update points
+            // inside the chunk (:742-752: every 960 samples, at most two per frame) are served where they fall — diagnostic callback with
+            // the EVM as of that sample, then dcd.update() — as long as the carrier stays on; the point that would turn it off ends the
+            // chunk (the common tail does the rest).  The chunk also ends before an anti-phase sample that moves sample_index.
+            const unsigned long long b0 = now();
             const uint32_t S = s.sample_index, idx0 = s.ring_pos % 10u;
+            const uint32_t n_asked = n;
+            float ysym[3], yring[2];
+            {
+                const uint32_t voff = (t + o1 + 10u * (uint32_t)wl) * 4u;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ysym[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrsrc, (int)(voff + 2560u * j), 0, 0));
+                // the correlator ring after the chunk = its last 80 samples (Correlator::sample :43-49), asked for now as well
+                const uint32_t r0 = (t + (n > 80u ? n - 80u : 0u) + (uint32_t)wl) * 4u;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) yring[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrsrc, (int)(r0 + 256u * j), 0, 0));
+            }
+            // every anti-phase clock_recovery.update() of the chunk (:601-606) must leave sample_index where it is
             const uint32_t a1 = ((S + 5u) % 10u + 10u - idx0) % 10u;  // offset of the first anti-phase sample
-            // (lane l checks anti-phase samples l and l + 64; the chunk is cut before the first one that would move it)
+            // (lane l checks anti-phase samples l, l + 64, ...; the chunk is cut before the first one that would move it)
             for (uint32_t base = a1; base < n; base += 640u) {
                 const uint32_t a = base + 10u * wl;
                 const float v = core::clock_predict_arg(s.ck_sample_est, s.ck_clock_est, s.ck_count + a + 1u);
@@ -629,7 +653,99 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     break;
                 }
             }
-            if (n < 1u) mode = BULK_NONE;
+            // the first update point inside the chunk: the sample that makes count_ 960.  If the trigger is already gone the carrier falls
+            // there (update_dcd -> dcd_off :260-265): the chunk ends on that sample
+            uint32_t d = 959u - s.count;
+            if (d + 1u < n && !s.dcd_trig) { n = d + 1u; completes = false; }
+            if (n >= 1u) {
+                frame_done = true;
+                const unsigned long long b1 = now();
+                tk_ens += b1 - b0;
+                uint32_t m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;  // payload symbols inside the chunk (<= 184)
+                float* ev = reinterpret_cast<float*>(DL.soft);      // [192] EVM terms of the chunk's symbols (the decoder's array: idle inside a frame; hpf sits above)
+                {
+                    const uint32_t wls = (uint32_t)cold_lane();   // (opaque: the per-lane bases below are recomputed here, not hoisted out of the main loop and spilled)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const uint32_t k = wls + 64u * j;
+                        if (k < m) {
+                            float err;
+                            const float sample = normalise(ysym[j], err);
+                            ev[k] = (err * err) * alpha;
+                            llr16[(s.framer_idx >> 1) + k] = (uint16_t)slice_llr(sample, edges);
+                        }
+                    }
+                }
+                wave_lds_sync();
+                // RunningStandardDeviation::capture (StandardDeviation.h:60-72), sequential, symbol by symbol; stops where an update point wants the value
+                float Sv = s.evm_S;
+                uint32_t kf = 0;
+                auto fold_to = [&](uint32_t kend) {
+                    for (; kf < kend && (kf & 3u); ++kf) { Sv = Sv - Sv * alpha; Sv = Sv + ev[kf]; }
+                    for (; kf + 4 <= kend; kf += 4) {
+                        const float4 g = *reinterpret_cast<const float4*>(ev + kf);
+                        Sv = Sv - Sv * alpha; Sv = Sv + g.x;
+                        Sv = Sv - Sv * alpha; Sv = Sv + g.y;
+                        Sv = Sv - Sv * alpha; Sv = Sv + g.z;
+                        Sv = Sv - Sv * alpha; Sv = Sv + g.w;
+                    }
+                    for (; kf < kend; ++kf) { Sv = Sv - Sv * alpha; Sv = Sv + ev[kf]; }
+                };
+                bool served = false;
+                uint32_t d_last = 0;
+                while (d + 1u < n) {   // an update point INSIDE the chunk: carrier on, trigger set (tail of operator() :742-752)
+                    fold_to(min(m, d >= o1 ? (d - o1) / 10u + 1u : 0u));   // the symbols up to and including sample d
+                    s.evm_S = Sv;
+                    if (a1 <= d) s.ck_sample_index = (int32_t)S;           // (the anti-phase updates up to here returned sample_index)
+                    s.count = 0;
+                    fire_diag(t + d, sqrtf(Sv));
+                    dcd_update_at(t + d);
+                    served = true; d_last = d;
+                    d += 960u;
+                    if (d + 1u < n && !s.dcd_trig) {   // the NEXT point turns the carrier off: the chunk ends on it
+                        n = d + 1u; completes = false;
+                        m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;   // (symbols sliced beyond it are sliced again when their turn comes)
+                    }
+                }
+                fold_to(m);
+                s.evm_S = Sv;
+                s.framer_idx += 2u * m;
+                if (a1 < n) s.ck_sample_index = (int32_t)S;   // the anti-phase updates of the chunk (if any) returned sample_index
+                const unsigned long long b2 = now();
+                tk_sym += b2 - b1;
+                {   // Correlator::sample x n: the ring keeps the last 80 samples
+                    const uint32_t first = n > 80u ? n - 80u : 0u;
+                    if (n != n_asked) {   // (the chunk was cut: its tail lies elsewhere)
+                        const uint32_t r0 = (t + first + (uint32_t)wl) * 4u;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) yring[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrsrc, (int)(r0 + 256u * j), 0, 0));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t o = first + (uint32_t)wl + 64u * j;
+                        if (o < n) ring[(s.ring_pos + o) % 80u] = yring[j];
+                    }
+                    s.prev_pos = (s.ring_pos + n - 1u) % 80u;
+                    s.ring_pos = (s.ring_pos + n) % 80u;
+                    s.run_pos = min(148, s.run_pos + (int32_t)n);
+                }
+                s.count = served ? n - 1u - d_last : s.count + n;
+                s.ck_count += n;
+                wave_lds_sync();
+                t += n;
+                te = t - 1u;
+                tail_dcd = true;
+                if (avail < t) window_reset(t);   // the window was not used: the samples passed over are never read from it
+                if (completes) {  // the last sample of the chunk completed the frame
+                    s.framer_idx = 0;
+                    s.sync_count = 0;
+                    decode_due = true;
+                }
+                ++n_bulk; n_bulk_samples += n;
+                tk_bulk += now() - b0;
+            } else {
+                mode = BULK_NONE;
+            }
         }
         if (mode == BULK_SEARCH || mode == BULK_SYNCWIN) {
             // Up to 64 samples of sync-word search at once: the limit history of every sample is taken from hbuf (or, without
@@ -718,45 +834,14 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             mode = BULK_NONE;  // the very next sample needs the single-sample path
             tk_search += now() - b0;
         }
-        if (mode != BULK_NONE) {
+        if (frame_done) {
+            // (the frame chunk above)
+        } else if (mode != BULK_NONE) {
             const unsigned long long b0 = now();
             ensure(n);
             const unsigned long long b1 = now();
             tk_ens += b1 - b0;
 
-            if (mode == BULK_FRAME) {
-                hw_base = 0x40000000;  // e2 is about to hold EVM terms
-                const uint32_t m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;  // payload symbols inside the chunk (<= 96)
-                const uint32_t wls = (uint32_t)cold_lane();   // (opaque here too: the per-lane bases of the three arrays below, hoisted out of the
-                                                              //  main loop, were what the register allocator spilled; recomputing them is three instructions)
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-                for (uint32_t k = wls; k < m; k += 64) {
-                    float err;
-                    const float sample = normalise(ywin[(t + o1 + 10u * k) & (WV_WIN - 1)], err);
-                    e2[k] = (err * err) * alpha;
-                    llr16[(s.framer_idx >> 1) + k] = (uint16_t)slice_llr(sample, edges);
-                }
-                wave_lds_sync();
-                float S = s.evm_S;
-                uint32_t k = 0;
-                for (; k + 4 <= m; k += 4) {  // RunningStandardDeviation::capture, sequential
-                    const float4 g = *reinterpret_cast<const float4*>(e2 + k);
-                    S = S - S * alpha; S = S + g.x;
-                    S = S - S * alpha; S = S + g.y;
-                    S = S - S * alpha; S = S + g.z;
-                    S = S - S * alpha; S = S + g.w;
-                }
-                for (; k < m; ++k) {
-                    S = S - S * alpha;
-                    S = S + e2[k];
-                }
-                s.evm_S = S;
-                s.framer_idx += 2u * m;
-                {   // the anti-phase updates of the chunk (if any) returned sample_index
-                    const uint32_t a1 = ((s.sample_index + 5u) % 10u + 10u - s.ring_pos % 10u) % 10u;
-                    if (a1 < n) s.ck_sample_index = (int32_t)s.sample_index;
-                }
-            }
             const unsigned long long b2 = now();
             tk_sym += b2 - b1;
             {   // Correlator::sample x n: the ring keeps the last 80 samples (the limit filter's history is in hbuf: K2 / nf_serve_limit)
@@ -783,11 +868,6 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             t += n;
             te = t - 1u;
             tail_dcd = mode != BULK_INIT;
-            if (mode == BULK_FRAME && completes) {  // the last sample of the chunk completed the frame
-                s.framer_idx = 0;
-                s.sync_count = 0;
-                decode_due = true;
-            }
             ++n_bulk; n_bulk_samples += n;
             tk_bulk += now() - b0;
         } else {
