@@ -67,7 +67,8 @@ def main():
     ap.add_argument("--samples", type=int, default=480000, help="samples per channel per step (10 s at 48 kSPS)")
     ap.add_argument("--sigma", type=float, default=600.0, help="AWGN sigma in LSB")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--parity-channels", type=int, default=16)
+    ap.add_argument("--parity-channels", type=int, default=64, help="channels of the last timed step compared with the oracle record for record (+ 16 in the single-stream check)")
+    ap.add_argument("--config2-steps", type=int, default=3, help="N = 1: steps of the BASELINE configs[1] leg (1024 channels, FIR + correlator, outputs materialised) reported as `config2`; 0 = skip")
     ap.add_argument("--h2d-steps", type=int, default=3, help="steps of the PCIe-inclusive leg (fresh pinned host input every step; 0 = skip)")
     ap.add_argument("--gather", choices=("auto", "cabi", "torch"), default="auto", help="N > 1: m17hip_gather_frames_device (C ABI) or m17hip/dist.py")
     ap.add_argument("--in-flight", type=int, default=2, help="independent batches (contexts) whose steps overlap: the tail of one step (K2/K5 "
@@ -369,7 +370,7 @@ def main():
         skern = kernel_times(sctx, KNAMES, args.steps)
         sparity = None
         if rank == 0 and args.parity_channels > 0 and not multi:   # three pipelined runs from a fresh start == the oracle over slab x 3
-            k = min(4, args.parity_channels, Cg)
+            k = min(16 // G if G <= 16 else 1, args.parity_channels, Cg)
             parts = []
             for g, c_ in enumerate(sctx):
                 c_.reset()
@@ -478,6 +479,41 @@ def main():
                "input_GB_per_step": round(C * T * 2 / 1e9, 3)}
         del a, b
 
+    # ---- BASELINE configs[1] beside the headline (N = 1): 1024 channels, FIR + correlator only, every output materialised in HBM ---------
+    config2 = None
+    if not multi and args.config2_steps > 0:
+        for c_ in ctxs[1:]:
+            c_.close()
+        C2 = 1024
+        c2 = m17hip.Context(C2, T, device=local_rank)
+        c2.synth(p, C2, T, chan0=0)
+
+        def step2():
+            c2.fir(fetch=False)
+            c2.correlator_device()
+
+        step2()
+        c2.timing(True); c2.timing_reset()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.config2_steps):
+            step2()
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t2) / args.config2_steps
+        c2.timing(False)
+        k2 = {}
+        for name in ("fir_rrc150", "correlator"):
+            ms, n = c2.timing_get(name)
+            k2[name] = {"ms_avg": (ms / n) if n else None, "ms_per_step": ms / args.config2_steps}
+        dom2 = max(k2, key=lambda k: k2[k]["ms_per_step"])
+        ach2 = FRONT_BYTES * C2 * T / (k2[dom2]["ms_avg"] / 1e3) / 1e9
+        config2 = {"workload": "configs[1]: 1024 independent 48 kSPS channels x %d samples, FIR + Correlator only, outputs (FIR out, limit, 4 correlations) left in HBM" % T,
+                   "value": round(C2 * T / dt2 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt2 * 1e3, 3), "steps": args.config2_steps,
+                   "roofline": {"bound": "hbm", "kernel": dom2, "achieved": round(ach2, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach2 / HBM_PEAK_GBS, 5),
+                                "traffic": None, "alg_bytes_per_sample": FRONT_BYTES, "kernel_ms": {k: round(v["ms_per_step"], 4) for k, v in k2.items()},
+                                "chain_achieved_GBs": round(FRONT_BYTES * C2 * T / dt2 / 1e9, 2), "chain_frac": round(FRONT_BYTES * C2 * T / dt2 / 1e9 / HBM_PEAK_GBS, 6)}}
+        c2.close()
+
     cpu = cpu_baseline(args, ol, x, C, T, ncpu, ncpu_affinity, cpu_quota, chain=True) if (args.cpu_seconds > 0 and not multi) else None
 
     out = {
@@ -493,11 +529,11 @@ def main():
                    "frames_cost_lt_10": good, "parity_vs_oracle_first_channels": parity, "parity_channels": args.parity_channels,
                    "realtime_factor_per_channel": round(value * 1e6 / (C * world) / 48000.0, 1), "input_gen_s": round(t_gen, 1),
                    "parallelism": f"channels sharded contiguously over {world} GPU(s), global channel ids", "gather": gather_kind,
-                   "steps_in_flight": F, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "prewarm_steps": args.prewarm, "batches": "pipelined" if args.stagger else "launched and waited for in groups",
+                   "steps_in_flight": F, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "hw_queue_advice": int(ctx.lib.m17hip_advice(ctx.h)), "prewarm_steps": args.prewarm, "batches": "pipelined" if args.stagger else "launched and waited for in groups",
                    "gathered_set_ordered_and_unique": gathered_ok, "tune": tuned or None},
         "single_stream": single,
         "value_with_h2d": h2d["value_with_h2d"] if h2d else None, "h2d": h2d,
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "config2": config2,
     }
     for m_ in comms:
         m_.close()

@@ -309,6 +309,8 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  *        store, the record reserved) and a lane-per-frame kernel decodes them after the run; 0 = every frame is decoded where it completes.
  * key 16: 1 = m17hip_upload_i16, m17hip_upload_i16_device and m17hip_synth_i16 write the context's STAGING slab (as
  *        m17hip_upload_i16_async does, but complete when they return) and stage it for the next run; 0 (default) = the current slab.
+ * key 30 (tests): fault injection for m17hip_gather_frames*: 1 = this rank's compaction fails inside the call, 2 = the root's staging
+ *        allocation fails; 0 = none.  Every rank still makes all its collective calls and returns the failure.
  * The measurement build of the library (make -C m17-cxx-demod_amd/csrc tools -> libm17hip_tools.so, -DM17_TOOLS; tools/ only) adds
  * key 1 / key 19 (section timers / per-wave working times of the sequential kernel -> m17hip_debug_counters) and the schedule
  * experiments 4, 5, 12, 14, 21, 25 (csrc/m17hip.hip, m17hip_tune). */

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
 
     // ---------------- wave-uniform helpers ------------------------------------------------------------------------
     auto corr_index = [&]() -> uint32_t { return s.prev_pos % 10u; };
+    auto idx0_of = [&](uint32_t ring_pos) -> uint32_t { return ring_pos % 10u; };   // correlator index of the sample that goes into slot ring_pos
     float r8[8];  // the eight ring samples one symbol apart that end at the newest sample (shared by all sync words)
 #pragma unroll
     for (int i = 0; i < 8; ++i) r8[i] = 0.f;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // duration = the slowest wave's.  Slot = segment index (flags bits 8..12).
     // (the start time waits in the slot itself: nothing of this stays in registers across the kernel)
     if constexpr (TIMED) if (wl == 0) P.dbg[(size_t)c * DBG_SLOTS + ((P.flags >> 8) & 31u)] = wall_clock64();
-    unsigned long long tk_bulk = 0, tk_scalar = 0, tk_decode = 0, tk_patch = 0, tk_ens = 0, tk_sym = 0, tk_iir = 0, tk_search = 0, tk_off = 0;
+    unsigned long long tk_bulk = 0, tk_scalar = 0, tk_decode = 0, tk_patch = 0, tk_ens = 0, tk_sym = 0, tk_iir = 0, tk_search = 0, tk_off = 0, tk_sel = 0, tk_tail = 0;
 
     // The first 148 FIR outputs of a gated run still see the tail of the previous run (Q2): recompute them from the
     // 149-sample snapshot + the run's own samples and patch ybuf in place, 64 outputs at a time, so that every later
@@ -500,6 +501,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // ---------------- main loop (wave-uniform control flow) ------------------------------------------------------------
     uint32_t flags_t = 0xFFFFFFFFu;   // sample whose index-0 prologue (:695-709) has already run during chunk selection
     while (t < P.T) {
+        const unsigned long long l0 = now();
         bool decode_due = false, tail_dcd = false;
         uint32_t te = 0;
         if (diverged && t >= h_until && (s.initializing || s.dcd_on)) {
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
 
         // ---- bulk chunk: n samples during which the state machine only feeds the correlator (and, inside a frame, slices
         //      payload symbols at a fixed sample_index) ----------------------------------------------------------------------
-        enum { BULK_NONE, BULK_INIT, BULK_QUIET, BULK_FEED, BULK_FRAME, BULK_SEARCH, BULK_SYNCWIN };
+        enum { BULK_NONE, BULK_INIT, BULK_QUIET, BULK_FEED, BULK_FRAME, BULK_SEARCH, BULK_SYNCWIN, BULK_LSF };
         int mode = BULK_NONE;
         uint32_t n = 0, o1 = 0;
         bool completes = false;   // the chunk ends on the sample that completes the frame (BULK_FRAME) / leaves SYNC_WAIT (BULK_QUIET)
@@ -581,8 +583,14 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     completes = n == q + 1u;
                     mode = BULK_QUIET;
                 } else if (s.st == ST_LSF_SYNC) {   // do_lsf_sync :350-411 acts only where index() == sample_index
-                    n = min((s.sample_index + 10u - idx0) % 10u, lim);
-                    mode = BULK_FEED;
+                    if (!s.need_clock_reset) {      // up to 48 symbols at once (below); a pending clock UPDATE is served on the way
+                        o1 = (s.sample_index + 10u - idx0) % 10u;
+                        n = min(room, 960u - s.count);
+                        mode = BULK_LSF;
+                    } else {
+                        n = min((s.sample_index + 10u - idx0) % 10u, lim);
+                        mode = BULK_FEED;
+                    }
                 } else if (s.st == ST_UNLOCKED) {   // do_unlocked :289-342 while no sync word is (or becomes) triggered
                     const bool phase_a = s.missing_sync_count < 1920;
                     const bool armed = phase_a ? !s.sw_trig[0] : !(s.sw_trig[1] | s.sw_trig[2]);
@@ -607,6 +615,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             }
             if (n < 1u) mode = BULK_NONE;
         }
+        tk_sel += now() - l0;
         if constexpr (PROF) {
             n_mode[mode & 7]++;
             if (mode == BULK_FRAME && !completes) {
@@ -746,6 +755,122 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             } else {
                 mode = BULK_NONE;
             }
+        }
+        if (mode == BULK_LSF) {
+            // ---- LSF_SYNC IN BULK (do_lsf_sync :350-411): the state acts on one sample in ten (index() == sample_index); lane j evaluates
+            // symbol j of the chunk — the three SyncWord::triggered() tests (Correlator.h:150-157) on the correlator's contents as of that
+            // sample, and the outer symbol levels update_values() would take (Correlator.h:81-114) — and the wave then walks the symbols in
+            // order: a preamble hit (:357-362) counts and asks for a clock update, served at the next index-0 sample (:695-709); a quiet
+            // symbol (:403-406) updates the two level filters (state arithmetic only: the gain schedule).  The first symbol that does
+            // anything else — LSF / stream / BERT sync word, the 193rd quiet symbol — ends the chunk: the single-sample path takes it.
+            const unsigned long long b0 = now();
+            ensure(n);
+            const uint32_t S = s.sample_index, rp0 = s.ring_pos;
+            uint32_t m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;   // symbol samples in the chunk (<= 48)
+            const uint32_t q = o1 + 10u * (uint32_t)wl;         // this lane's symbol sample (offset in the chunk)
+            // a sample of the correlator's 80-sample history as of offset q: from the chunk (window) or from before it (ring)
+            auto at_time = [&](int32_t o) -> float {             // the sample fed at offset o (>= -80)
+                return o >= 0 ? ywin[(t + (uint32_t)o) & (WV_WIN - 1)] : ring[(rp0 + 80u + (uint32_t)(o + 80)) % 80u];
+            };
+            bool isA = false, isE = false, isQ = false;
+            float mn = 0.f, mx = 0.f;
+            if ((uint32_t)wl < m) {
+                float r[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r[i] = at_time((int32_t)q - 70 + 10 * i);   // oldest symbol first (Correlator.h:51-64)
+                const int64_t hq = (int64_t)t + q;
+                const float lim_k = iir_output(hrow[hq], hrow[hq - 1], hrow[hq - 2]);
+                auto trig = [&](int w_) -> float {                // SyncWord::triggered
+                    const float v = sync_correlate(w_, r);
+                    return (v > lim_k * SW_MAG1[w_] || v < lim_k * SW_MAG2[w_]) ? v : 0.0f;
+                };
+                const float t0 = trig(0);
+                if ((double)t0 > 0.1) isA = true;
+                else {
+                    const float t1 = trig(1), t2 = trig(2);
+                    if (t2 < 0.f || (double)fabsf(t1) > 0.1) isE = true; else isQ = true;
+                }
+                // Correlator::outer_symbol_levels(sample_index): buffer_[i] in SLOT order; slot i holds the newest sample fed into it
+                core::outer_symbol_levels([&](uint32_t slot) -> float {
+                    const uint32_t back = (rp0 + q + 800u - slot) % 80u;   // how many samples ago slot `slot` was written, as of offset q
+                    return back <= q ? ywin[(t + q - back) & (WV_WIN - 1)] : ring[slot];
+                }, S, mn, mx);
+            }
+            const unsigned long long mA = __ballot(isA), mE = __ballot(isE), mQ = __ballot(isQ);
+            // the quiet symbol that takes missing_sync_count beyond 192 is a transition too (:392-402)
+            const uint32_t nq_here = (uint32_t)__popcll(mQ & ((2ull << wl) - 1ull));
+            const unsigned long long mO = __ballot(isQ && (uint32_t)s.missing_sync_count + nq_here > 192u);
+            const unsigned long long stop = mE | mO;
+            const uint32_t fs = stop ? (uint32_t)(__ffsll((long long)stop) - 1) : m;   // symbols served here
+            const uint32_t nc = fs < m ? o1 + 10u * fs : n;                            // samples committed here
+            if (nc >= 1u) {
+                // walk the symbols: clock updates fall on index-0 samples (idx0 + offset = 0 mod 10), the one at or before symbol j first
+                const uint32_t ck_entry = s.ck_count;
+                int32_t ckz = -1;                  // offset of the last clock update inside the chunk
+                const int32_t z_done = flags_t == t ? 0 : -1;   // the prologue of offset 0 has run already (chunk selection: a clock RESET may have left an update pending)
+                bool pend = s.need_clock_update != 0;
+                auto clock_at = [&](uint32_t z) {  // ClockRecovery::update(sync_sample_index) in the prologue of offset z
+                    const ClockOut o = nf_clock_update_idx(cd, s.sync_sample_index, ckz < 0 ? ck_entry + z : z - (uint32_t)ckz, P.kalman_order);
+                    s.ck_sample_est = o.sample_est; s.ck_clock_est = o.clock_est; s.ck_sample_index = o.sample_index;
+                    ckz = (int32_t)z; pend = false;
+                };
+                float a0 = cd->min_x0, a1 = cd->min_x1, b0v = cd->max_x0, b1v = cd->max_x1;
+                uint32_t ln = cd->lvl_n, nupd = 0;
+                float lmn = 0.f, lmx = 0.f;
+                bool rst_seen = false;
+                uint32_t served = 0;
+                for (uint32_t j = 0; j < fs; ++j) {
+                    const uint32_t qj = o1 + 10u * j;
+                    if (pend && qj >= S && (int32_t)(qj - S) > z_done) clock_at(qj - S);   // the index-0 sample at or before symbol j (index(qj) = S)
+                    if ((mA >> j) & 1ull) { pend = true; s.sync_count += 1; }
+                    else {   // quiet: ++missing_sync_count, update_values(sample_index) (:233-241)
+                        s.missing_sync_count += 1;
+                        lmn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mn), (int)j));
+                        lmx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), (int)j));
+                        const core::Kalman2Gain g = P.level_gain[ln];
+                        core::level_update(a0, a1, lmn, g, P.kalman_order);
+                        core::level_update(b0v, b1v, lmx, g, P.kalman_order);
+                        ln = min(ln + 1u, (uint32_t)core::LEVEL_SCHED_LAST);
+                        ++nupd;
+                        if (cd->dev_reset || isnan(a0) || isnan(a1) || isnan(b0v) || isnan(b1v)) {   // FreqDevEstimator::update :40-48
+                            a0 = lmn; a1 = 0.f; b0v = lmx; b1v = 0.f; ln = 0; cd->dev_reset = 0; rst_seen = true;
+                        } else rst_seen = false;
+                    }
+                    served = j + 1u;
+                }
+                if (nupd) {
+                    cd->min_x0 = a0; cd->min_x1 = a1; cd->max_x0 = b0v; cd->max_x1 = b1v; cd->lvl_n = ln;
+                    if (rst_seen) { s.offset = (lmn + lmx) / 2.f; s.idev = core::freqdev_idev(lmx, lmn); }
+                    else { s.offset = core::freqdev_offset(b0v, a0); s.idev = core::freqdev_idev(b0v, a0); }
+                    s.sync_sample_index = S;
+                }
+                // a clock update still pending falls on the first index-0 sample behind the last symbol served, if the chunk reaches it
+                if (pend) {
+                    const uint32_t from = served ? o1 + 10u * (served - 1u) + 1u : 0u;
+                    uint32_t z = from + (10u - (idx0_of(rp0) + from) % 10u) % 10u;
+                    if ((int32_t)z <= z_done) z += 10u;
+                    if (z < nc) clock_at(z);
+                }
+                s.need_clock_update = pend ? 1u : 0u;
+                s.ck_count = ckz < 0 ? ck_entry + nc : nc - (uint32_t)ckz;
+                {   // Correlator::sample x nc
+                    const uint32_t first = nc > 80u ? nc - 80u : 0u;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                    for (uint32_t o = first + wl; o < nc; o += 64) ring[(rp0 + o) % 80u] = ywin[(t + o) & (WV_WIN - 1)];
+                    s.prev_pos = (rp0 + nc - 1u) % 80u;
+                    s.ring_pos = (rp0 + nc) % 80u;
+                    s.run_pos = min(148, s.run_pos + (int32_t)nc);
+                }
+                s.count += nc;
+                wave_lds_sync();
+                t += nc;
+                if (s.count == 960u) dcd_point_on(t - 1u);
+                ++n_bulk; n_bulk_samples += nc;
+                tk_search += now() - b0;
+                continue;
+            }
+            mode = BULK_NONE;   // the very next sample is a transition: the single-sample path
+            tk_search += now() - b0;
         }
         if (mode == BULK_SEARCH || mode == BULK_SYNCWIN) {
             // Up to 64 samples of sync-word search at once: the limit history of every sample is taken from hbuf (or, without
@@ -1033,7 +1158,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             ++n_decode;
             tk_decode += now() - d0;
         }
-        if (tail_dcd && s.count == 960u) dcd_point_on(te);
+        { const unsigned long long q0 = now(); if (tail_dcd && s.count == 960u) dcd_point_on(te); tk_tail += now() - q0; }
     }
 
     // ---------------- save state ------------------------------------------------------------------------------
@@ -1075,7 +1200,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         o[0] = now() - tk0; o[1] = tk_bulk; o[2] = tk_scalar; o[3] = tk_decode;
         o[4] = n_bulk; o[5] = n_scalar; o[6] = n_bulk_samples; o[7] = n_flip | (n_decode << 32);
         for (int k = 0; k < 8; ++k) o[24 + k] = n_mode[k];
-        o[32] = n_flip; o[33] = n_lim_clock; o[34] = n_lim_count; o[35] = n_lim_room;
+        o[32] = n_flip; o[33] = n_lim_clock; o[34] = n_lim_count; o[35] = n_lim_room; o[36] = tk_sel; o[37] = tk_tail;
     }
     if (P.bnd_out && left_replay) {   // what the replay needs to take this channel up again: its state at this boundary
         Boundary* b = P.bnd_out + c;

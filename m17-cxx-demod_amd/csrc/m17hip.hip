@@ -95,6 +95,7 @@ struct m17hip_ctx {
     uint32_t* diag_count = nullptr;   // [maxC]
     uint32_t diag_cap = 0;
     uint32_t kalman_order = 3;        // evaluation order of the Kalman updates (m17hip_set_kalman_order)
+    int gather_fault = 0;             // tuning knob 30 (tests): 1 = this rank's compaction fails inside the gather, 2 = the root's staging allocation fails
     uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
     uint32_t front_first = 0;         // tuning knob 12: segments of K1 that must be complete before the first K5 starts (0 = its own only)
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
@@ -139,7 +140,8 @@ struct m17hip_comm {
     int device = 0;                   // any context on this device may gather through the communicator (one call at a time)
     int rank = 0, nranks = 1;
     int last_rccl = 0;
-    uint64_t* counts_dev = nullptr;   // [nranks]
+    uint64_t* counts_dev = nullptr;   // [2 * nranks] words of the status / count exchanges
+    uint32_t serial = 0;              // gather calls made through this communicator (every rank counts the same)
     FrameRec* gathered = nullptr;     // root: every rank's records, rank after rank
     uint64_t gathered_cap = 0;
 };
@@ -1603,7 +1605,8 @@ int m17hip_comm_create(m17hip_ctx* c, const void* id128, int rank, int nranks, m
     std::memcpy(&id, id128, sizeof(id));
     const ncclResult_t r = R.CommInitRank(&m->comm, nranks, id, rank);
     if (r != ncclSuccess) { c->last_hip = 0x10000 | (int)r; delete m; return M17HIP_ECOMM; }   // (no communicator to ask: the ncclResult_t is left in m17hip_last_hip_error, | 0x10000)
-    const hipError_t e = hipMalloc((void**)&m->counts_dev, (size_t)nranks * sizeof(uint64_t));
+    hipError_t e = hipMalloc((void**)&m->counts_dev, 2 * (size_t)nranks * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemset(m->counts_dev, 0xFF, 2 * (size_t)nranks * sizeof(uint64_t));   // (no slot looks like a word of call 1)
     if (e != hipSuccess) { c->last_hip = (int)e; R.CommDestroy(m->comm); delete m; return M17HIP_ENOMEM; }
     *out = m;
     return M17HIP_OK;
@@ -1622,20 +1625,29 @@ void m17hip_comm_destroy(m17hip_comm* m)
     delete m;
 }
 
+// Every rank makes the same sequence of collective calls whatever goes wrong locally: a failure travels as a status inside the words
+// that are exchanged anyway, and all ranks return together (a rank that left early would leave its peers waiting inside RCCL).
+//   exchange 1 (all-gather, two words per rank):  [0] = record count (48 bits) | call serial (8 bits) | status (8 bits: -code)
+//                                                 [1] = the ROOT's staging capacity in records (0 from the other ranks)
+//       the serial makes a stale word recognisable: a rank whose own word could not be written to the device (its HIP calls fail)
+//       still joins the all-gather, and what its peers then read in its slot is the word of the PREVIOUS call
+//   exchange 2 (all-gather, one word per rank) only if the gathered set does not fit the root's staging: the root grows it and says
+//       whether that worked (the others say "ok"); every rank knows from exchange 1 that this exchange is due
+//   exchange 3: grouped ncclSend / ncclRecv of the exact record sets, rank after rank = global (channel, seq) order
 static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* counts_host,
                               uint64_t* total_out, bool dest_is_device)
 {
     if (!c || !m || m->device != c->device || root < 0 || root >= m->nranks || (m->rank == root && capacity && !recs_host)) return M17HIP_EINVAL;
     GUARD(c);
     const Rccl& R = rccl();
-    // 1. this rank's records, dense and (channel, seq)-ordered, in the context's compaction buffer.  Whatever goes wrong on THIS rank
-    //    from here on is carried through the collective as a status word (every rank makes the same calls and returns together): a
-    //    rank that left early would leave the others waiting in the all-gather.
+    const bool is_root = m->rank == root;
+    auto hip_code = [&](hipError_t e) { c->last_hip = (int)e; return e == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP; };
+    // 1. this rank's records, dense and (channel, seq)-ordered, in the context's compaction buffer
     uint64_t mine = 0;
     int local = c->recs_valid ? M17HIP_OK : M17HIP_ESTATE;
     bool overflow = false;
     if (local == M17HIP_OK) {
-        int r = compact_into(c, c->compact, c->compact_cap, &mine);
+        int r = c->gather_fault == 1 ? M17HIP_EHIP : compact_into(c, c->compact, c->compact_cap, &mine);
         // the dense buffer must hold ALL of this rank's records before anything is sent from it, whatever the first pass said
         // (an overflowed run reports EOVERFLOW before the truncation is looked at)
         if ((r == M17HIP_OK || r == M17HIP_ETRUNC || r == M17HIP_EOVERFLOW) && mine > c->compact_cap) {
@@ -1643,48 +1655,69 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
             c->compact = nullptr; c->compact_cap = 0;
             const uint64_t want = std::max<uint64_t>(mine + mine / 8, 1024);
             const hipError_t e = hipMalloc((void**)&c->compact, (size_t)want * sizeof(FrameRec));
-            if (e != hipSuccess) { c->last_hip = (int)e; r = e == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP; }
+            if (e != hipSuccess) r = hip_code(e);
             else { c->compact_cap = want; r = compact_into(c, c->compact, c->compact_cap, &mine); }
         }
         overflow = r == M17HIP_EOVERFLOW;
         if (r && !overflow) { local = r; mine = 0; }
     }
-    // 2. every rank learns every rank's count and status: word = count | (error code, negated) << 56
-#define RCCLCHK(expr) do { const ncclResult_t q_ = (expr); if (q_ != ncclSuccess) { m->last_rccl = (int)q_; return M17HIP_ECOMM; } } while (0)
-    std::vector<uint64_t> words((size_t)m->nranks, 0);
-    const uint64_t word = (mine & 0x00FFFFFFFFFFFFFFull) | ((uint64_t)(uint8_t)(-local) << 56);
-    HIPCHK(c, hipMemcpyAsync(m->counts_dev + m->rank, &word, 8, hipMemcpyHostToDevice, c->stream));
-    RCCLCHK(R.AllGather(m->counts_dev + m->rank, m->counts_dev, 1, ncclUint64, m->comm, c->stream));
-    HIPCHK(c, hipMemcpyAsync(words.data(), m->counts_dev, (size_t)m->nranks * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (is_root && !m->gathered && local == M17HIP_OK) {   // a first staging buffer (grown below when a gathered set outgrows it)
+        const uint64_t want = std::max<uint64_t>(2 * mine * (uint64_t)m->nranks, 1024);
+        if (c->gather_fault != 2 && hipMalloc((void**)&m->gathered, (size_t)want * sizeof(FrameRec)) == hipSuccess) m->gathered_cap = want;
+        else { m->gathered = nullptr; m->gathered_cap = 0; }
+    }
+    // 2. exchange 1
+    const uint64_t serial = (uint64_t)(++m->serial & 0xFFu);
+    uint64_t word[2] = {(mine & 0x0000FFFFFFFFFFFFull) | (serial << 48) | ((uint64_t)(uint8_t)(-local) << 56), is_root ? m->gathered_cap : 0ull};
+    std::vector<uint64_t> words(2 * (size_t)m->nranks, 0);
+    {
+        hipError_t e = hipMemcpyAsync(m->counts_dev + 2 * m->rank, word, 16, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess && !local) local = hip_code(e);     // (our slot keeps the previous call's word: its serial gives it away)
+        const ncclResult_t q = R.AllGather(m->counts_dev + 2 * m->rank, m->counts_dev, 2, ncclUint64, m->comm, c->stream);
+        if (q != ncclSuccess) { m->last_rccl = (int)q; return M17HIP_ECOMM; }   // (the collective itself failed: nothing more can be agreed on)
+        e = hipMemcpyAsync(words.data(), m->counts_dev, words.size() * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_code(e);   // (this rank cannot read what was agreed on: it cannot take part in the rest; its peers' calls fail with it)
+    }
     std::vector<uint64_t> counts((size_t)m->nranks, 0);
     uint64_t total = 0;
     int remote = M17HIP_OK;
     for (int k = 0; k < m->nranks; ++k) {
-        counts[k] = words[k] & 0x00FFFFFFFFFFFFFFull;
+        const uint64_t w = words[2 * (size_t)k];
+        int code = -(int)(w >> 56);
+        if (((w >> 48) & 0xFFu) != serial) code = M17HIP_ECOMM;   // a stale word: that rank could not deliver this call's
+        counts[k] = code ? 0 : (w & 0x0000FFFFFFFFFFFFull);
         total += counts[k];
-        const int code = -(int)(words[k] >> 56);
         if (code && !remote) remote = code;
     }
     if (counts_host) std::memcpy(counts_host, counts.data(), counts.size() * 8);
     if (total_out) *total_out = total;
     if (local) return local;
     if (remote) return M17HIP_ECOMM;   // some other rank could not deliver its records: nobody sends, everybody returns
-    // 3. the records travel to the root with their exact sizes, rank after rank = global channel order
-    int rc = M17HIP_OK;
-    if (m->rank == root) {
-        if (total > m->gathered_cap) {
+    // 3. exchange 2, only if the root's staging is too small (every rank sees that in the root's second word)
+    if (total > words[2 * (size_t)root + 1]) {
+        int rc = M17HIP_OK;
+        if (is_root) {
             if (m->gathered) hipFree(m->gathered);
             m->gathered = nullptr; m->gathered_cap = 0;
             const uint64_t want = std::max<uint64_t>(total + total / 8, 1024);
-            const hipError_t e = hipMalloc((void**)&m->gathered, (size_t)want * sizeof(FrameRec));
-            if (e != hipSuccess) { c->last_hip = (int)e; rc = e == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP; }
-            else m->gathered_cap = want;
+            const hipError_t e = c->gather_fault == 2 ? hipErrorOutOfMemory : hipMalloc((void**)&m->gathered, (size_t)want * sizeof(FrameRec));
+            if (e != hipSuccess) rc = hip_code(e); else m->gathered_cap = want;
         }
-        if (rc) return rc;   // (no room for the gathered set on the root: the other ranks' sends stay unmatched — fatal for the communicator)
+        const uint64_t st = (uint64_t)(uint8_t)(-rc);
+        hipError_t e = hipMemcpyAsync(m->counts_dev + 2 * m->rank, &st, 8, hipMemcpyHostToDevice, c->stream);
+        const ncclResult_t q = R.AllGather(m->counts_dev + 2 * m->rank, m->counts_dev, 2, ncclUint64, m->comm, c->stream);
+        if (q != ncclSuccess) { m->last_rccl = (int)q; return M17HIP_ECOMM; }
+        if (e == hipSuccess) e = hipMemcpyAsync(words.data(), m->counts_dev, words.size() * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_code(e);
+        if (rc) return rc;
+        if (words[2 * (size_t)root] & 0xFFu) return M17HIP_ECOMM;   // the root has no room for the gathered set: nobody sends
+    }
+    // 4. the records travel to the root with their exact sizes, rank after rank = global channel order
+    if (is_root) {
         ncclResult_t q = R.GroupStart();
         uint64_t off = 0;
-        hipError_t he = hipSuccess;
         for (int k = 0; k < m->nranks && q == ncclSuccess; ++k) {
             if (k != root && counts[k]) q = R.Recv(m->gathered + off, (size_t)counts[k] * sizeof(FrameRec), ncclUint8, k, m->comm, c->stream);
             off += counts[k];
@@ -1693,11 +1726,12 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
         if (q == ncclSuccess) q = qe;
         if (q != ncclSuccess) { m->last_rccl = (int)q; return M17HIP_ECOMM; }
         off = 0;
+        hipError_t he = hipSuccess;
         for (int k = 0; k < m->nranks; ++k) {   // the root's own share: a plain copy, outside the group
             if (k == root && mine) he = hipMemcpyAsync(m->gathered + off, c->compact, (size_t)mine * sizeof(FrameRec), hipMemcpyDeviceToDevice, c->stream);
             off += counts[k];
         }
-        if (he != hipSuccess) { c->last_hip = (int)he; return M17HIP_EHIP; }
+        if (he != hipSuccess) return hip_code(he);
         const uint64_t n = std::min(total, capacity);
         if (n) HIPCHK(c, hipMemcpyAsync(recs_host, m->gathered, (size_t)n * sizeof(FrameRec), dest_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1712,7 +1746,6 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
         if (q != ncclSuccess) { m->last_rccl = (int)q; return M17HIP_ECOMM; }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-#undef RCCLCHK
     return overflow ? M17HIP_EOVERFLOW : M17HIP_OK;
 }
 
@@ -1793,6 +1826,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
             hipFree(c->defer_llr); hipFree(c->defer_hist);
             c->defer_llr = nullptr; c->defer_hist = nullptr;
         }
+        return M17HIP_OK;
+    case 30:  // fault injection for m17hip_gather_frames (tests): 0 = none, 1 = this rank's compaction fails, 2 = the root's staging allocation fails
+        if (value < 0 || value > 2) return M17HIP_EINVAL;
+        c->gather_fault = (int)value;
         return M17HIP_OK;
     case 16:  // the in-place producers (m17hip_upload_i16, m17hip_upload_i16_device, m17hip_synth_i16) write the STAGING slab instead
         c->stage_inputs = value != 0;

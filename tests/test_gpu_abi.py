@@ -240,6 +240,17 @@ def test_rccl_gather_single_rank():
     c3 = m17hip.Context(4, 4800)
     assert c3.lib.m17hip_gather_frames(c3.h, comm.h, 0, big.ctypes.data_as(C.c_void_p), C.c_uint64(big.size), None, C.byref(tot)) == -4
     c3.close(); c2.close()
+    # fault injection (m17hip_tune key 30): a rank whose compaction fails, a root whose staging allocation fails — the call makes all
+    # its collective calls and returns the failure; the communicator stays usable
+    comm2 = m17hip.Comm(c, m17hip.comm_get_id(), 0, 1)
+    c.tune(30, 2)
+    assert c.lib.m17hip_gather_frames(c.h, comm2.h, 0, big.ctypes.data_as(C.c_void_p), C.c_uint64(big.size), None, C.byref(tot)) == -3   # ENOMEM on the root
+    c.tune(30, 1)
+    assert c.lib.m17hip_gather_frames(c.h, comm2.h, 0, big.ctypes.data_as(C.c_void_p), C.c_uint64(big.size), None, C.byref(tot)) == -2   # this rank's records: EHIP
+    c.tune(30, 0)
+    again, counts = c.gather_frames(comm2, root=0)
+    assert again.tobytes() == recs.tobytes()
+    comm2.close()
     comm.close(); c.close()
 
 

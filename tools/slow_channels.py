@@ -36,6 +36,8 @@ for c in order[C // 2: C // 2 + 3]:
     t = d[int(c)]
     print("      iterations by kind: none %d init %d quiet %d feed %d frame %d search %d syncwin %d | frame chunks cut by a clock move %d, ended by a pending clock flag %d, by the DCD point %d, by the 480-sample chunk size %d"
           % tuple(int(t[24 + k]) for k in (0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11)))
+    print("      chunk selection %.2f ms, update points at the tail %.2f ms; single-sample steps by state: UNLOCKED %d LSF_SYNC %d STREAM_SYNC %d PACKET_SYNC %d BERT_SYNC %d SYNC_WAIT/FRAME %d"
+          % ((t[36] / 1e5, t[37] / 1e5) + tuple(int(t[18 + q]) for q in range(6))))
 dr = d[:, 17] > 0
 print(f"dropped {int(dr.sum())} channels: mean total {tot[dr].mean():.2f} ms vs {tot[~dr].mean():.2f} ms; mean iir {d[dr, 14].mean()/1e5:.2f}, search {d[dr, 15].mean()/1e5:.2f}, single {d[dr, 2].mean()/1e5:.2f}, "
       f"bulk {d[dr, 1].mean()/1e5:.2f} (not dropped: iir {d[~dr, 14].mean()/1e5:.2f} search {d[~dr, 15].mean()/1e5:.2f} single {d[~dr, 2].mean()/1e5:.2f} bulk {d[~dr, 1].mean()/1e5:.2f})")
