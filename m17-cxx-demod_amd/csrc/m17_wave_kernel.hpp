@@ -568,14 +568,13 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 if (s.need_clock_reset | s.need_clock_update) lim = min(lim, 10u - idx0);  // stop before the next index-0 sample
                 const bool is_sync = s.st == ST_STREAM_SYNC || s.st == ST_PACKET_SYNC || s.st == ST_BERT_SYNC;
                 if (is_sync) {
-                    if (s.sync_count < 77) {
-                        n = min((uint32_t)(77 - s.sync_count), lim); mode = BULK_QUIET;
-                        const int32_t target = (int32_t)t + (77 - (int32_t)s.sync_count) - 3;
-                        if (hpf_base != target && (!diverged || target + 64 <= (int32_t)h_until)) hpf_issue(target);
-                    }
-                    else if (s.sync_count < 86) {   // the window where the next sync word is looked for (:420-574), up to the sample
-                        n = min(min(10u, (uint32_t)(86 - s.sync_count)), lim);   // before its trigger falls / EOT / the count runs out
+                    if (s.sync_count < 86) {   // the samples that only count (sync_count + 1 < MIN_SYNC_COUNT = 78) and the window where the next sync
+                        n = min((uint32_t)(86 - s.sync_count), lim);   // word is looked for (:420-574), up to the sample before its trigger falls / EOT / the count runs out
                         mode = BULK_SYNCWIN;
+                        if (s.sync_count < 77) {   // the limit history the window will want: into LDS ahead of its use (issued behind the frame decode as a rule)
+                            const int32_t target = (int32_t)t + (77 - (int32_t)s.sync_count) - 3;
+                            if (hpf_base != target && (!diverged || target + 64 <= (int32_t)h_until)) hpf_issue(target);
+                        }
                     }
                 } else if (s.st == ST_SYNC_WAIT) {  // do_sync_wait :583-593: count up to MAX_SYNC_COUNT, then one transition sample
                     const uint32_t q = s.sync_count < 86 ? (uint32_t)(86 - s.sync_count) : 0u;
@@ -872,13 +871,81 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             mode = BULK_NONE;   // the very next sample is a transition: the single-sample path
             tk_search += now() - b0;
         }
-        if (mode == BULK_SEARCH || mode == BULK_SYNCWIN) {
-            // Up to 64 samples of sync-word search at once: the limit history of every sample is taken from hbuf (or, without
-            // K2, advanced as one chain into LDS), lane k then evaluates SyncWord::triggered (Correlator.h:150-157) for sample k.
-            // BULK_SEARCH (UNLOCKED): the samples before the first one that triggers are committed as quiet, the triggering one
-            // goes through the single-sample path.  BULK_SYNCWIN (*_SYNC states, sync_count 77..85): the quiet samples AND the
-            // samples of the trigger run (SyncWord::operator() :179-186 just stores them) are committed; the sample on which the
-            // trigger falls (peak search, state change), an EOT hit and the sample that exhausts the count stay single-sample.
+        if (mode == BULK_SYNCWIN) {
+            // ---- *_SYNC STATES (do_stream_sync :420-482, do_packet_sync :489-530, do_bert_sync :536-574) up to the sample on which something
+            // happens.  The first samples only count (sync_count + 1 < 78); from then on SyncWord::operator() (Correlator.h:179-200) runs on
+            // every sample: lane j evaluates sample kw + j of the chunk (at most nine of them), the quiet samples AND the samples of the
+            // trigger run (:179-186 just stores them) are committed; the sample on which the trigger falls (peak search, state change),
+            // an EOT hit and the sample that exhausts the count go through the single-sample path.
+            const unsigned long long b0 = now();
+            ensure(n);
+            const uint32_t rp0 = s.ring_pos;
+            const uint32_t kw = s.sync_count < 77 ? (uint32_t)(77 - s.sync_count) : 0u;   // samples in front of the window
+            const uint32_t nw = n > kw ? n - kw : 0u;                                     // window samples in the chunk (<= 9)
+            const uint32_t k = kw + (uint32_t)wl;
+            const int wd = (s.st == ST_STREAM_SYNC) ? 1 : 2;   // the word a *_SYNC state looks for
+            bool hit = false, trg = false;
+            float vk = 0.f;
+            if ((uint32_t)wl < nw) {
+                float h0k, h1k, h2k;   // the limit filter's history after sample k
+                const int32_t off = (int32_t)(t + k) - hpf_base;
+                if (off >= 2 && off < 64) { hpf_ready(); h0k = hpf[off]; h1k = hpf[off - 1]; h2k = hpf[off - 2]; }
+                else { const int64_t hq = (int64_t)t + k; h0k = hrow[hq]; h1k = hrow[hq - 1]; h2k = hrow[hq - 2]; }
+                const float lim_k = iir_output(h0k, h1k, h2k);
+                float r[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {   // samples k - 70, k - 60, ..., k: from the chunk (window) or from before it (ring)
+                    const int32_t o = (int32_t)k - 70 + 10 * i;
+                    r[i] = o >= 0 ? ywin[(t + (uint32_t)o) & (WV_WIN - 1)] : ring[(rp0 + 80u + (uint32_t)(o + 80)) % 80u];
+                }
+                auto corr = [&](int w_) { return sync_correlate(w_, r); };
+                auto beyond = [&](int w_, float v) { return v > lim_k * SW_MAG1[w_] || v < lim_k * SW_MAG2[w_]; };
+                vk = corr(wd);
+                trg = beyond(wd, vk) && vk != 0.f;   // SyncWord::operator() tests the RETURNED value: an exact 0 beyond a negative limit is no trigger
+                if (s.st == ST_STREAM_SYNC) { const float v3 = corr(3); hit = beyond(3, v3) && v3 > 0.1f; }   // EOT :424
+            }
+            unsigned long long mask = __ballot(hit);
+            const unsigned long long tmask = __ballot(trg);
+            const uint32_t was_trig = s.sw_trig[wd];
+            {   // + the first sample on which the trigger falls
+                unsigned long long fall = ~tmask;
+                if (!was_trig) fall = tmask ? (fall & ~((2ull << (__ffsll((long long)tmask) - 1)) - 1ull)) : 0ull;
+                mask |= fall & ((1ull << nw) - 1ull);
+            }
+            const uint32_t fw = mask ? (uint32_t)(__ffsll((long long)mask) - 1) : nw;   // window samples committed here
+            const uint32_t f = min(kw, n) + fw;                                          // samples committed here
+            if (f > 0u) {
+                const uint32_t first = f > 80u ? f - 80u : 0u;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                for (uint32_t o = first + wl; o < f; o += 64) ring[(rp0 + o) % 80u] = ywin[(t + o) & (WV_WIN - 1)];
+                s.prev_pos = (rp0 + f - 1u) % 80u;
+                s.ring_pos = (rp0 + f) % 80u;
+                s.run_pos = min(148, s.run_pos + (int32_t)f);
+                s.count += f;
+                s.ck_count += f;
+                s.sync_count += (int32_t)f;
+                if (tmask & ((1ull << fw) - 1ull)) {   // SyncWord::operator() on the triggered samples: (clear,) store at index()
+                    if (!was_trig) {
+                        if (wl < 10) swsm[wd * 10 + wl] = 0.f;
+                        wave_lds_sync();
+                        s.sw_trig[wd] = 1;
+                    }
+                    if ((uint32_t)wl < fw && trg) swsm[wd * 10 + (int)((rp0 + k) % 10u)] = vk;
+                }
+                wave_lds_sync();
+                t += f;
+                if (s.count == 960u) dcd_point_on(t - 1u);
+                ++n_bulk; n_bulk_samples += f;
+                tk_search += now() - b0;
+                continue;
+            }
+            mode = BULK_NONE;  // the very next sample needs the single-sample path
+            tk_search += now() - b0;
+        }
+        if (mode == BULK_SEARCH) {
+            // ---- UNLOCKED (do_unlocked :289-342) while no sync word is triggered: up to 64 samples at once.  The limit history of every
+            // sample comes from hbuf, lane k evaluates SyncWord::triggered (Correlator.h:150-157) for sample k; the samples before the first
+            // one that triggers are committed as quiet, the triggering one goes through the single-sample path.
             const unsigned long long b0 = now();
             ensure(n);
             float* W = reinterpret_cast<float*>(DL.soft);   // [80 + 64] correlator ring in time order, then the new samples
@@ -899,9 +966,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             }
             wave_lds_sync();
             const bool phase_a = s.missing_sync_count < 1920;
-            const int wd = (s.st == ST_STREAM_SYNC) ? 1 : 2;   // the word a *_SYNC state looks for
-            bool hit = false, trg = false;
-            float vk = 0.f;
+            bool hit = false;
             if (wl < n) {
                 const float lim_k = iir_output(hb[3u + wl], hb[2u + wl], hb[1u + wl]);
                 float r[8];
@@ -909,25 +974,11 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 for (int i = 0; i < 8; ++i) r[i] = W[10u + wl + 10u * i];   // samples k-70, k-60, ..., k
                 auto corr = [&](int w_) { return sync_correlate(w_, r); };
                 auto beyond = [&](int w_, float v) { return v > lim_k * SW_MAG1[w_] || v < lim_k * SW_MAG2[w_]; };
-                if (mode == BULK_SEARCH) {
-                    hit = phase_a ? beyond(0, corr(0)) : (beyond(1, corr(1)) || beyond(2, corr(2)));
-                } else {
-                    vk = corr(wd);
-                    trg = beyond(wd, vk) && vk != 0.f;   // SyncWord::operator() tests the RETURNED value: an exact 0 beyond a negative limit is no trigger
-                    if (s.st == ST_STREAM_SYNC) { const float v3 = corr(3); hit = beyond(3, v3) && v3 > 0.1f; }   // EOT :424
-                }
+                hit = phase_a ? beyond(0, corr(0)) : (beyond(1, corr(1)) || beyond(2, corr(2)));
             }
-            unsigned long long mask = __ballot(hit);
-            const unsigned long long tmask = __ballot(trg);
-            const uint32_t was_trig = s.sw_trig[wd];
-            if (mode == BULK_SYNCWIN) {   // + the first sample on which the trigger falls
-                unsigned long long fall = ~tmask;
-                if (!was_trig) fall = tmask ? (fall & ~((2ull << (__ffsll((long long)tmask) - 1)) - 1ull)) : 0ull;
-                mask |= fall & ((1ull << n) - 1ull);
-            }
+            const unsigned long long mask = __ballot(hit);
             const uint32_t f = mask ? (uint32_t)(__ffsll((long long)mask) - 1) : n;   // leading samples that are committed here
             if (f > 0u) {
-                const uint32_t rp0 = s.ring_pos;
                 const uint32_t first = f > 80u ? f - 80u : 0u;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                 for (uint32_t o = first + wl; o < f; o += 64) ring[(s.ring_pos + o) % 80u] = W[80u + o];
@@ -936,19 +987,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 s.run_pos = min(148, s.run_pos + (int32_t)f);
                 s.count += f;
                 s.ck_count += f;
-                if (mode == BULK_SEARCH) {
-                    if (phase_a) s.missing_sync_count += (int32_t)f;
-                } else {
-                    s.sync_count += (int32_t)f;
-                    if (tmask & ((1ull << f) - 1ull)) {   // SyncWord::operator() on the triggered samples: (clear,) store at index()
-                        if (!was_trig) {
-                            if (wl < 10) swsm[wd * 10 + wl] = 0.f;
-                            wave_lds_sync();
-                            s.sw_trig[wd] = 1;
-                        }
-                        if (wl < f && trg) swsm[wd * 10 + (int)((rp0 + wl) % 10u)] = vk;
-                    }
-                }
+                if (phase_a) s.missing_sync_count += (int32_t)f;
                 wave_lds_sync();
                 t += f;
                 if (s.count == 960u) dcd_point_on(t - 1u);
@@ -1156,6 +1195,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             s.viterbi_cost = r.x;
             s.st = (r.y == 1u || r.y == 0u) ? ST_STREAM_SYNC : (r.y == 4u ? ST_BERT_SYNC : ST_PACKET_SYNC);
             ++n_decode;
+            {   // the limit history the next sync window (77 samples on) will want: on its way into LDS while the next chunk is set up
+                const int32_t target = (int32_t)t + 77 - 3;
+                if (t < P.T && (!diverged || target + 64 <= (int32_t)h_until)) hpf_issue(target);
+            }
             tk_decode += now() - d0;
         }
         { const unsigned long long q0 = now(); if (tail_dcd && s.count == 960u) dcd_point_on(te); tk_tail += now() - q0; }
