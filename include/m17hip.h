@@ -305,6 +305,9 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * key 8: record slots per channel and run actually used, 0 = all that were allocated (2 per 1920 samples + 8, which a run cannot
  *        outgrow) — a smaller value makes M17HIP_EOVERFLOW reachable for tests.
  * key 9: diagnostic log, value = diagnostic callbacks of room per channel and run (m17hip_diag_log_fetch; default 0 = off).
+ * key 10: form of the carrier-detect kernel K3: 0 = one wave per 32 channels (least wave slots: batch throughput), 1 = four-wave pipeline per
+ *        32 channels (1.8x shorter chain, four times the wave slots: stream latency), -1 (default) = the pipeline for runs whose front end
+ *        was queued by m17hip_demod_front (a continued stream waits for K3's chain), the one-wave form otherwise.  Same table either way.
  * key 15: 1 (default) = the sequential kernel leaves the payload frames of running stream / BERT transmissions undecoded (LLRs to a
  *        store, the record reserved) and a lane-per-frame kernel decodes them after the run; 0 = every frame is decoded where it completes.
  * key 16: 1 = m17hip_upload_i16, m17hip_upload_i16_device and m17hip_synth_i16 write the context's STAGING slab (as

@@ -381,7 +381,43 @@ __global__ __launch_bounds__(64 * DCD_WPB) void dcd_kernel(const int16_t* __rest
 }
 
 
-// hand-over between the roles of limit_pipe_kernel: LDS only.  (__syncthreads() would also fence GLOBAL memory, i.e. wait for the producer's prefetches
+// =====================================================================================================
+// K3 as a PIPELINE OF FOUR WAVES — the LATENCY form of K3 (m17hip_tune key 10; default: runs whose front end was queued by m17hip_demod_front,
+// i.e. a continued stream, where K3's ten-launch chain is what a run waits for; batch runs use dcd_kernel above, which costs the
+// kernels beside it a quarter of the wave slots).
+// The sliding-DFT recurrence is a latency chain: a lone wave issues one instruction per ~2.6 ns whatever it depends on, so the
+// time of this kernel is (instructions per sample ON THE WAVE THAT CARRIES THE RECURRENCE) x 2.6 ns x samples.  In dcd_kernel
+// that wave also converts the samples, squares the bins and feeds six running sums: ~13 instructions per sample, 16.8 ms per
+// 480 000 samples.  Here a workgroup of four waves (32 channels, one wave per SIMD of a CU) splits the work by ROLE and hands
+// blocks of 32 samples from role to role through LDS, one barrier per block:
+//   P  (wave 0)  int16 -> float scaling of x[n] and x[n-120] (packed fp32: v_pk_mul / v_pk_fma), delta = x[n] - x[n-120]
+//                for 32 channels x 32 samples, 16-byte loads issued one block ahead                 -> dbuf[2][32][36]
+//   R  (wave 1)  the recurrence and nothing else: t = Xr + delta; X = (t,t)*(cr,ci) + (Xi,Xi)*(-ci,cr)   (4 VALU per sample,
+//                2 lanes per channel = the two DFT bins, as in dcd_kernel)                          -> xb[2][16][64] (re, im pairs)
+//   A0 (wave 2)  norm = re*re + im*im and the running sums restarted at ticks = 0,1,2,3 (mod 5); table columns 0..3
+//   A1 (wave 3)  norm again and the sum restarted at ticks = 4 (mod 5) + the sum since the stream start; table columns 4..5
+// Arithmetic, summation order and table layout are dcd_kernel's (and the reference's): bit-identical tables.
+// Runs whose start and length are multiples of 32 samples take this kernel (every block whole, tick boundaries = block
+// boundaries); anything else (ragged streaming chunks) takes dcd_kernel.
+// =====================================================================================================
+constexpr int DP_BLK = 32;               // samples per pipeline stage
+constexpr int DP_CPB = 32;               // channels per workgroup
+constexpr int DP_DPITCH = DP_BLK + 4;    // delta row pitch in floats (conflict-free 16-byte reads)
+constexpr int DP_PF = 3;                 // blocks of input the producer keeps in flight
+
+template <bool INVERT>
+__device__ __forceinline__ v2f dcd_scale2(int a, int b)   // core::scale_i16 on two samples at once
+{
+    if (INVERT) { a = (int)(int16_t)(-a); b = (int)(int16_t)(-b); }
+    const v2f rcp = {1.0f / 41067.0f, 1.0f / 41067.0f};
+    const v2f k = {41067.0f, 41067.0f};
+    const v2f fs = {(float)a, (float)b};
+    const v2f q = fs * rcp;
+    const v2f r = __builtin_elementwise_fma(-q, k, fs);
+    return __builtin_elementwise_fma(r, rcp, q);
+}
+
+// hand-over between the roles of the pipeline kernels: LDS only.  (__syncthreads() would also fence GLOBAL memory, i.e. wait for the producer's prefetches
 // of the blocks to come — vmcnt(0) at every barrier — and expose a full HBM round trip per block.)  Every role executes the
 // same number of these, each in its own loop: the hardware counts arrivals per workgroup, not program counters.
 __device__ __forceinline__ void dp_handover()
@@ -390,6 +426,161 @@ __device__ __forceinline__ void dp_handover()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+
+// preconditions (the host launches dcd_kernel otherwise): T and pos0 are multiples of DP_BLK, T >= 4 blocks, so every block
+// is whole and tick boundaries (192 = 6 x 32 samples) are block boundaries
+template <bool INVERT>
+__global__ __launch_bounds__(256) void dcd_pipe_kernel(const int16_t* __restrict__ x, size_t xpitch, DcdState* __restrict__ state,
+                                                       float* __restrict__ table, uint32_t ticks_cap, uint32_t C, uint32_t T,
+                                                       uint64_t pos0, DcdCoef k, uint32_t flags)
+{
+    __shared__ __attribute__((aligned(16))) float dbuf[2][DP_CPB][DP_DPITCH];
+    __shared__ __attribute__((aligned(16))) float4 xb[2][DP_BLK / 2][64];
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 1, bin = lane & 1;
+    uint32_t c = blockIdx.x * DP_CPB + g;
+    const bool live = c < C;   // lanes beyond the last channel shadow it and never store
+    if (!live) c = C - 1;
+    const int16_t* xr = x + (size_t)c * xpitch + XPRE;
+    DcdState* st = state + c;
+    const uint32_t NB = T / DP_BLK;       // blocks
+    // every role runs NI hand-overs: NB + 2 for pipeline fill and drain, rounded up to a multiple of DP_PF so that the
+    // producer's unrolled loop has no early exit (its registers stay in fixed slots and its waits stay partial)
+    const uint32_t NI = (NB + 2u + DP_PF - 1u) / DP_PF * DP_PF;
+
+    if (role == 0) {
+        // ---- P: scaling and delta.  A block lasts ~0.5 us, an HBM round trip twice that: the loads of block b are issued DP_PF
+        // blocks ahead (slot = b % DP_PF is a compile-time constant: the loop is unrolled DP_PF times and every body issues the
+        // same loads — past the end the last block again — so the wait for a slot leaves the other slots in flight).
+        int4 pa[DP_PF][2], pb[DP_PF][2];
+        auto issue = [&](uint32_t b, int slot) {   // lane (g, bin) converts samples [16 bin, 16 bin + 16) of its channel's block
+            const int16_t* p = xr + (size_t)min(b, NB - 1u) * DP_BLK + 16 * bin;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                pa[slot][q] = *reinterpret_cast<const int4*>(p + 8 * q);
+                pb[slot][q] = *reinterpret_cast<const int4*>(p + 8 * q - 120);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < DP_PF; ++j) issue((uint32_t)j, j);
+        auto lo = [](int w) { return (int)(int16_t)(w & 0xFFFF); };
+        auto hi = [](int w) { return w >> 16; };
+        for (uint32_t i0 = 0; i0 < NI; i0 += DP_PF) {
+#pragma unroll
+            for (int slot = 0; slot < DP_PF; ++slot) {
+                const uint32_t i = i0 + (uint32_t)slot;
+                {
+                    float4 o[4];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int4 a = pa[slot][q], d = pb[slot][q];
+                        const v2f u0 = dcd_scale2<INVERT>(lo(a.x), hi(a.x)) - dcd_scale2<INVERT>(lo(d.x), hi(d.x));
+                        const v2f u1 = dcd_scale2<INVERT>(lo(a.y), hi(a.y)) - dcd_scale2<INVERT>(lo(d.y), hi(d.y));
+                        const v2f u2 = dcd_scale2<INVERT>(lo(a.z), hi(a.z)) - dcd_scale2<INVERT>(lo(d.z), hi(d.z));
+                        const v2f u3 = dcd_scale2<INVERT>(lo(a.w), hi(a.w)) - dcd_scale2<INVERT>(lo(d.w), hi(d.w));
+                        o[2 * q] = make_float4(u0.x, u0.y, u1.x, u1.y);
+                        o[2 * q + 1] = make_float4(u2.x, u2.y, u3.x, u3.y);
+                    }
+                    issue(i + DP_PF, slot);   // this slot's registers are free again: block i + DP_PF goes in flight
+                    if (i < NB && !(flags & 16u)) {
+                        float* wrow = &dbuf[i & 1u][g][16 * bin];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(wrow + 4 * q) = o[q];
+                    }
+                    dp_handover();
+                }
+            }
+        }
+    } else if (role == 1) {
+        // ---- R: the recurrence and nothing else
+        v2f X = v2f{st->xr[bin], st->xi[bin]};
+        const v2f cc = bin ? v2f{k.c1r, k.c1i} : v2f{k.c0r, k.c0i};
+        const v2f cs = v2f{-cc.y, cc.x};
+        auto step = [&](float delta) {
+            const float a = X.x + delta;
+            const v2f m1 = v2f{a, a} * cc;          // (ac, ad)
+            const v2f m2 = v2f{X.y, X.y} * cs;      // (-bd, bc)
+            X = m1 + m2;                            // (ac - bd, ad + bc)
+        };
+        for (uint32_t i = 0; i < NI; ++i) {
+            if (i >= 1u && i <= NB && !(flags & 32u)) {
+                const uint32_t b = i - 1u;
+                const float* drow = &dbuf[b & 1u][g][0];
+                float4* out = &xb[b & 1u][0][lane];
+                float d[DP_BLK];
+#pragma unroll
+                for (int u = 0; u < DP_BLK / 4; ++u) {
+                    const float4 v = *reinterpret_cast<const float4*>(drow + 4 * u);
+                    d[4 * u] = v.x; d[4 * u + 1] = v.y; d[4 * u + 2] = v.z; d[4 * u + 3] = v.w;
+                }
+#pragma unroll
+                for (int u = 0; u < DP_BLK; u += 2) {
+                    step(d[u]); const v2f x0 = X;
+                    step(d[u + 1]);
+                    out[(u / 2) * 64] = make_float4(x0.x, x0.y, X.x, X.y);
+                }
+            }
+            dp_handover();
+        }
+        if (live) { st->xr[bin] = X.x; st->xi[bin] = X.y; }
+    } else {
+        // ---- A0 / A1: norms and running sums; A0 (role 2) owns the sums restarted at ticks = 0..3 (mod 5), A1 the one restarted
+        // at ticks = 4 (mod 5) and the one that runs from the stream start
+        const bool a0 = role == 2;
+        v2f s01 = a0 ? v2f{st->acc[0][bin], st->acc[1][bin]} : v2f{st->acc[4][bin], st->acc[5][bin]};
+        v2f s23 = a0 ? v2f{st->acc[2][bin], st->acc[3][bin]} : v2f{0.f, 0.f};
+        uint32_t phase = (uint32_t)(pos0 % TICK);
+        uint64_t tick = pos0 / TICK;
+        uint32_t row = 0;
+        float* tab = table + (size_t)c * ticks_cap * 12 + bin * 6;
+        const bool skip = flags & (a0 ? 64u : 128u);
+        for (uint32_t i = 0; i < NI; ++i) {
+            if (i >= 2u && i < NB + 2u && !skip) {
+                const uint32_t b = i - 2u;
+                const float4* in = &xb[b & 1u][0][lane];
+                if (phase == 0) {   // the sum that restarts with this tick
+                    const uint32_t j = (uint32_t)(tick % 5);
+                    if (a0) { if (j == 0) s01.x = 0.f; if (j == 1) s01.y = 0.f; if (j == 2) s23.x = 0.f; if (j == 3) s23.y = 0.f; }
+                    else if (j == 4) s01.x = 0.f;
+                }
+                auto acc = [&](float re, float im) {
+                    const v2f xx = {re, im};
+                    const v2f p = xx * xx;
+                    const float nrm = p.x + p.y;
+                    const v2f nn = {nrm, nrm};
+                    s01 = s01 + nn;
+                    if (a0) s23 = s23 + nn;
+                };
+#pragma unroll
+                for (int u = 0; u < DP_BLK / 2; ++u) {
+                    const float4 v = in[u * 64];
+                    acc(v.x, v.y);
+                    acc(v.z, v.w);
+                }
+                phase += DP_BLK;
+                if (phase == TICK) {
+                    if (live) {
+                        float* o = tab + (size_t)row * 12;
+                        if (a0) {
+                            *reinterpret_cast<float2*>(o) = make_float2(s01.x, s01.y);
+                            *reinterpret_cast<float2*>(o + 2) = make_float2(s23.x, s23.y);
+                        } else {
+                            *reinterpret_cast<float2*>(o + 4) = make_float2(s01.x, s01.y);
+                        }
+                    }
+                    phase = 0; ++tick; ++row;
+                }
+            }
+            dp_handover();
+        }
+        if (live) {
+            if (a0) { st->acc[0][bin] = s01.x; st->acc[1][bin] = s01.y; st->acc[2][bin] = s23.x; st->acc[3][bin] = s23.y; }
+            else { st->acc[4][bin] = s01.x; st->acc[5][bin] = s01.y; }
+        }
+    }
+}
+
 
 // =====================================================================================================
 // The correlator's limit filter for the per-operator entry point (m17hip_correlator, BASELINE config 2) as a pipeline of roles,

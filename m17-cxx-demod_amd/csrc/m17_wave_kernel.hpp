@@ -646,7 +646,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             }
             // every anti-phase clock_recovery.update() of the chunk (:601-606) must leave sample_index where it is
             const uint32_t a1 = ((S + 5u) % 10u + 10u - idx0) % 10u;  // offset of the first anti-phase sample
-            // (lane l checks anti-phase samples l, l + 64, ...; the chunk is cut before the first one that would move it)
+            // (lane l checks anti-phase samples l, l + 64, ...; the first one that moves it is the chunk's last sample: do_frame does nothing
+            //  else on that sample — it is no symbol sample — so the move itself is committed with the chunk, and the next chunk starts
+            //  from the new sample_index)
+            int32_t S_moved = -1;
             for (uint32_t base = a1; base < n; base += 640u) {
                 const uint32_t a = base + 10u * wl;
                 const float v = core::clock_predict_arg(s.ck_sample_est, s.ck_clock_est, s.ck_count + a + 1u);
@@ -655,8 +658,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     bad = a < n && (uint32_t)(uint8_t)clock_predict(s.ck_sample_est, s.ck_clock_est, s.ck_count + a + 1u) != S;
                 const unsigned long long mask = __ballot(bad);
                 if (mask != 0ull) {
-                    n = base + 10u * (uint32_t)(__ffsll((long long)mask) - 1);
+                    const uint32_t af = base + 10u * (uint32_t)(__ffsll((long long)mask) - 1);
+                    n = af + 1u;
                     completes = false;
+                    S_moved = clock_predict(s.ck_sample_est, s.ck_clock_est, s.ck_count + af + 1u);   // ClockRecovery::update() :76-88 on that sample
                     ++n_flip;
                     break;
                 }
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             // the first update point inside the chunk: the sample that makes count_ 960.  If the trigger is already gone the carrier falls
             // there (update_dcd -> dcd_off :260-265): the chunk ends on that sample
             uint32_t d = 959u - s.count;
-            if (d + 1u < n && !s.dcd_trig) { n = d + 1u; completes = false; }
+            if (d + 1u < n && !s.dcd_trig) { n = d + 1u; completes = false; S_moved = -1; }
             if (n >= 1u) {
                 frame_done = true;
                 const unsigned long long b1 = now();
@@ -711,14 +716,15 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     served = true; d_last = d;
                     d += 960u;
                     if (d + 1u < n && !s.dcd_trig) {   // the NEXT point turns the carrier off: the chunk ends on it
-                        n = d + 1u; completes = false;
+                        n = d + 1u; completes = false; S_moved = -1;
                         m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;   // (symbols sliced beyond it are sliced again when their turn comes)
                     }
                 }
                 fold_to(m);
                 s.evm_S = Sv;
                 s.framer_idx += 2u * m;
-                if (a1 < n) s.ck_sample_index = (int32_t)S;   // the anti-phase updates of the chunk (if any) returned sample_index
+                if (a1 < n) s.ck_sample_index = (int32_t)S;   // the anti-phase updates of the chunk (if any) returned sample_index ...
+                if (S_moved >= 0) { s.ck_sample_index = S_moved; s.sample_index = (uint32_t)(uint8_t)S_moved; }   // ... but for the last one, which moved it (:601-606)
                 const unsigned long long b2 = now();
                 tk_sym += b2 - b1;
                 {   // Correlator::sample x n: the ring keeps the last 80 samples

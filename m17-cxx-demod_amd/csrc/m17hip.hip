@@ -98,6 +98,8 @@ struct m17hip_ctx {
     int gather_fault = 0;             // tuning knob 30 (tests): 1 = this rank's compaction fails inside the gather, 2 = the root's staging allocation fails
     uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
     uint32_t front_first = 0;         // tuning knob 12: segments of K1 that must be complete before the first K5 starts (0 = its own only)
+    int dcd_form = -1;                // tuning knob 10: K3 as one wave per 32 channels (0), as the four-wave latency pipeline (1), or chosen per run (-1: the pipeline for runs queued by m17hip_demod_front)
+    bool dcd_latency = false;         // what the launches of the run being queued use
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     uint32_t seg0_len = 0;            // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others; measured neutral)
     float* dcd_table = nullptr;
@@ -559,8 +561,16 @@ int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_
     Timed tm(c, KT_DCD, st);
     // table rows are numbered from the first tick of the RUN: a later segment continues where the previous one stopped
     const uint64_t row0 = (c->pos + t0) / TICK - c->pos / TICK;
-    hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW * DCD_WPB - 1) / (DCD_CPW * DCD_WPB)), dim3(64 * DCD_WPB), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
-                       c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
+    // (the pipeline needs whole 32-sample blocks that start on a block boundary of the stream: ragged pieces take the one-wave form)
+    if (!c->dcd_latency || T % DP_BLK != 0 || (c->pos + t0) % DP_BLK != 0 || t0 % 8 != 0 || T < 4 * DP_BLK)
+        hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW * DCD_WPB - 1) / (DCD_CPW * DCD_WPB)), dim3(64 * DCD_WPB), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+                           c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
+    else if (flags & 1u)
+        hipLaunchKernelGGL(dcd_pipe_kernel<true>, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+                           c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
+    else
+        hipLaunchKernelGGL(dcd_pipe_kernel<false>, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+                           c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
@@ -937,6 +947,7 @@ int m17hip_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* sum
     HIPCHK(c, hipMemsetAsync(c->dcd_state, 0, (size_t)C * sizeof(DcdState), c->stream));
     const uint64_t saved = c->pos;
     c->pos = 0;
+    c->dcd_latency = c->dcd_form == 1;
     int r = launch_dcd(c, C, T, flags, c->stream);
     c->pos = saved;
     if (r) return r;
@@ -1135,7 +1146,7 @@ static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStre
 // A staged run begins: the slab pairs swap, the 152-sample tail of the previous input is carried into the new slab's prefix, and the
 // front end (K1, K3: nothing in them depends on the outcome of the run before) is queued on the side streams — NOT ordered behind
 // the main stream, where K2 / K5 of the previous run may still have a long way to go.
-static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
+static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, bool from_front)
 {
     if (C != c->stagedC || T != c->stagedT) return M17HIP_EINVAL;
     if (c->have_run && C != c->lastC) return M17HIP_EINVAL;  // a continued stream keeps its channel count
@@ -1171,6 +1182,7 @@ static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     int r = ensure_seg_events(c, c->slot, sp.nseg);
     if (r) return r;
     const uint32_t ahead = c->front_ahead ? c->front_ahead : sp.nseg;
+    c->dcd_latency = c->dcd_form < 0 ? from_front : c->dcd_form == 1;
     c->front_segs = std::min(ahead, sp.nseg);
     for (uint32_t k = 0; k < c->front_segs; ++k)
         if ((r = launch_front_seg(c, sp, k, C, flags))) return r;
@@ -1186,7 +1198,7 @@ int m17hip_demod_front(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT || (flags & ~M17HIP_FLAG_INVERT)) return M17HIP_EINVAL;
     GUARD(c);
     if (c->front_pending || !c->staged) return M17HIP_ESTATE;
-    int r = begin_staged(c, C, T, flags);
+    int r = begin_staged(c, C, T, flags, true);
     if (r) return r;
     c->front_pending = true;
     // The replay of the staged run's first segment (K2 from K5's state) needs the run in flight only up to its last K5 launch and its
@@ -1217,7 +1229,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         c->front_pending = false;
         staged_run = true;
     } else if (c->staged) {   // input staged by m17hip_upload_i16_async and friends: swap the slabs, queue the front end
-        if ((r = begin_staged(c, C, T, flags))) return r;
+        if ((r = begin_staged(c, C, T, flags, false))) return r;
         staged_run = true;
     }
     if (!c->uploaded) return M17HIP_ESTATE;
@@ -1251,6 +1263,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
         HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork, 0));
+        c->dcd_latency = c->dcd_form == 1;
         c->front_segs = std::min(ahead, nseg);
         for (uint32_t k = 0; k < c->front_segs; ++k)
             if ((r = launch_front_seg(c, sp, k, C, flags))) return r;
@@ -1819,6 +1832,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         c->diag_cap = (uint32_t)value;
         return M17HIP_OK;
     }
+    case 10:  // K3 form: 0 = one wave per 32 channels (throughput), 1 = four-wave pipeline (latency), -1 (default) = the pipeline for the runs m17hip_demod_front queues
+        if (value < -1 || value > 1) return M17HIP_EINVAL;
+        c->dcd_form = (int)value;
+        return M17HIP_OK;
     case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1, default), or in K5 (0)
         c->defer_decode = value != 0;
         if (!c->defer_decode && c->defer_llr) {   // give the stores back (a run in flight may still use them: wait for it)

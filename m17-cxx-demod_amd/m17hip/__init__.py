@@ -195,11 +195,12 @@ class Context:
         """Same computation, results left in device memory (benchmarks)."""
         self._chk(self.lib.m17hip_correlator(self.h, C.c_uint32(self.C), C.c_uint32(self.T), None, None))
 
-    def dcd(self, flags=0, fetch=True):
-        ticks = self.T // 192
+    def dcd(self, flags=0, fetch=True, samples=None):
+        T = int(samples) if samples is not None else self.T
+        ticks = T // 192
         sums = np.empty((self.C, ticks, 2, 6), dtype=np.float32) if fetch else None
         n = C.c_uint32(0)
-        self._chk(self.lib.m17hip_dcd(self.h, C.c_uint32(self.C), C.c_uint32(self.T), C.c_uint32(flags), _ptr(sums), C.byref(n)))
+        self._chk(self.lib.m17hip_dcd(self.h, C.c_uint32(self.C), C.c_uint32(T), C.c_uint32(flags), _ptr(sums), C.byref(n)))
         assert n.value == ticks
         return sums
 

@@ -43,6 +43,13 @@ def test_dcd_sums_and_levels_equal_reference(ctx, golden):
     for tag, s, inv in _sets(golden):
         ctx.upload(s[None, :])
         sums = ctx.dcd(flags=inv)[0]                      # [ticks][2 bins][6 sums]
+        n32 = s.size // 32 * 32                            # the four-wave latency form of K3 (m17hip_tune key 10) needs whole 32-sample blocks
+        ctx.tune(10, 1)
+        try:
+            sums_p = ctx.dcd(flags=inv, samples=n32)[0]
+        finally:
+            ctx.tune(10, -1)
+        assert np.array_equal(sums_p.view(np.uint32), sums[: n32 // 192].view(np.uint32)), tag
         if tag + "dcd_sums" in golden:
             for st, ln, l1, l2 in golden[tag + "dcd_sums"]:
                 a0, k = int(st) // 192, (int(st) + int(ln)) // 192 - 1

@@ -23,12 +23,14 @@ def _oracle_records(x, invert=0):
     return flat, counts, diags
 
 
-@pytest.fixture(scope="module", params=[1, 0], ids=["default", "decode_in_k5"])
+@pytest.fixture(scope="module", params=[(1, -1), (0, -1), (1, 1)], ids=["default", "decode_in_k5", "k3_latency_form"])
 def ctx(request):
-    """Every test runs twice: with the payload frames of running transmissions decoded after the run, one lane per frame (the default),
-    and with every frame decoded by the sequential kernel's wave where it completes (m17hip_tune key 15 = 0)."""
+    """Every test runs three times: with the payload frames of running transmissions decoded after the run, one lane per frame (the default),
+    with every frame decoded by the sequential kernel's wave where it completes (m17hip_tune key 15 = 0), and with the carrier-detect
+    kernel K3 in its four-wave latency form (key 10 = 1; by default only the runs m17hip_demod_front queues use it)."""
     c = m17hip.Context(256, 96000)
-    c.tune(15, request.param)
+    c.tune(15, request.param[0])
+    c.tune(10, request.param[1])
     yield c
     c.close()
 
