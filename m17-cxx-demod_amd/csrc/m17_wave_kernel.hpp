@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     const bool phase_a = s.missing_sync_count < 1920;
                     const bool armed = phase_a ? !s.sw_trig[0] : !(s.sw_trig[1] | s.sw_trig[2]);
                     if (armed) {
-                        n = min(64u, lim);
+                        n = lim;   // (up to a whole window chunk: 64 samples per pass below)
                         if (phase_a) n = min(n, (uint32_t)(1920 - s.missing_sync_count));
                         mode = BULK_SEARCH;
                     }
@@ -949,47 +949,44 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             tk_search += now() - b0;
         }
         if (mode == BULK_SEARCH) {
-            // ---- UNLOCKED (do_unlocked :289-342) while no sync word is triggered: up to 64 samples at once.  The limit history of every
-            // sample comes from hbuf, lane k evaluates SyncWord::triggered (Correlator.h:150-157) for sample k; the samples before the first
-            // one that triggers are committed as quiet, the triggering one goes through the single-sample path.
+            // ---- UNLOCKED (do_unlocked :289-342) while no sync word is triggered: up to a whole chunk (480 samples) at once, 64 samples per
+            // pass.  The limit history of the chunk is staged from hbuf in one go, lane k of a pass evaluates SyncWord::triggered
+            // (Correlator.h:150-157) for its sample; the samples before the first one that triggers are committed as quiet, the triggering
+            // one goes through the single-sample path.
             const unsigned long long b0 = now();
             ensure(n);
-            float* W = reinterpret_cast<float*>(DL.soft);   // [80 + 64] correlator ring in time order, then the new samples
-            float* hb = W + 160;                            // [3 + 64] h0 trajectory: hb[2], hb[1], hb[0] = h0, h1, h2 before the chunk
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-            for (uint32_t k = wl; k < 80u; k += 64) W[k] = ring[(s.prev_pos + 1u + k) % 80u];   // oldest first
-            if (wl < n) W[80u + wl] = ywin[(t + wl) & (WV_WIN - 1)];
-            {   // the trajectory is in hbuf: hb[k] = history after sample t - 3 + k
-                const int32_t off = (int32_t)t - 3 - hpf_base;
-                if (off >= 0 && off + (int32_t)n + 3 <= 64) {   // ... and already in LDS
-                    hpf_ready();
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-                    for (uint32_t k = wl; k < n + 3u; k += 64) hb[k] = hpf[off + (int32_t)k];
-                } else {
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-                    for (uint32_t k = wl; k < n + 3u; k += 64) hb[k] = hrow[(int64_t)t - 3 + k];
-                }
-            }
+            const uint32_t rp0 = s.ring_pos;
+            float* hb = reinterpret_cast<float*>(DL.soft);   // [3 + n] h0 trajectory: hb[k] = history after sample t - 3 + k
+            hpf_ready(); hpf_base = -0x40000000; hw_base = 0x40000000;   // (the staging takes the whole decoder array: the prefetched and the single-sample history windows with it)
+#pragma clang loop vectorize(disable) interleave(disable)
+            for (uint32_t k = wl; k < n + 3u; k += 64) hb[k] = hrow[(int64_t)t - 3 + k];
             wave_lds_sync();
             const bool phase_a = s.missing_sync_count < 1920;
-            bool hit = false;
-            if (wl < n) {
-                const float lim_k = iir_output(hb[3u + wl], hb[2u + wl], hb[1u + wl]);
-                float r[8];
+            uint32_t f = n;                                   // leading samples that are committed here
+            for (uint32_t base = 0; base < n; base += 64u) {
+                const uint32_t k = base + (uint32_t)wl;
+                bool hit = false;
+                if (k < n) {
+                    const float lim_k = iir_output(hb[3u + k], hb[2u + k], hb[1u + k]);
+                    float r[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) r[i] = W[10u + wl + 10u * i];   // samples k-70, k-60, ..., k
-                auto corr = [&](int w_) { return sync_correlate(w_, r); };
-                auto beyond = [&](int w_, float v) { return v > lim_k * SW_MAG1[w_] || v < lim_k * SW_MAG2[w_]; };
-                hit = phase_a ? beyond(0, corr(0)) : (beyond(1, corr(1)) || beyond(2, corr(2)));
+                    for (int i = 0; i < 8; ++i) {   // samples k - 70, k - 60, ..., k: from the chunk (window) or from before it (ring)
+                        const int32_t o = (int32_t)k - 70 + 10 * i;
+                        r[i] = o >= 0 ? ywin[(t + (uint32_t)o) & (WV_WIN - 1)] : ring[(rp0 + 80u + (uint32_t)(o + 80)) % 80u];
+                    }
+                    auto corr = [&](int w_) { return sync_correlate(w_, r); };
+                    auto beyond = [&](int w_, float v) { return v > lim_k * SW_MAG1[w_] || v < lim_k * SW_MAG2[w_]; };
+                    hit = phase_a ? beyond(0, corr(0)) : (beyond(1, corr(1)) || beyond(2, corr(2)));
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (mask) { f = base + (uint32_t)(__ffsll((long long)mask) - 1); break; }
             }
-            const unsigned long long mask = __ballot(hit);
-            const uint32_t f = mask ? (uint32_t)(__ffsll((long long)mask) - 1) : n;   // leading samples that are committed here
             if (f > 0u) {
                 const uint32_t first = f > 80u ? f - 80u : 0u;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-                for (uint32_t o = first + wl; o < f; o += 64) ring[(s.ring_pos + o) % 80u] = W[80u + o];
-                s.prev_pos = (s.ring_pos + f - 1u) % 80u;
-                s.ring_pos = (s.ring_pos + f) % 80u;
+                for (uint32_t o = first + wl; o < f; o += 64) ring[(rp0 + o) % 80u] = ywin[(t + o) & (WV_WIN - 1)];
+                s.prev_pos = (rp0 + f - 1u) % 80u;
+                s.ring_pos = (rp0 + f) % 80u;
                 s.run_pos = min(148, s.run_pos + (int32_t)f);
                 s.count += f;
                 s.ck_count += f;
