@@ -211,9 +211,18 @@ __device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float
 }
 struct ClockOut { float sample_est, clock_est; int32_t sample_index; };
 // ClockRecovery::update(uint8_t) (ClockRecovery.h:54-67)
+// KORDER >= 0: the evaluation order is a compile-time constant and the update is inlined (the production kernel of the default order: no
+// call, hence no stack, in the whole kernel); KORDER < 0: the run-time order through the out-of-line variants.
+template <int KORDER = -1>
 __device__ __forceinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32_t index, uint32_t ck_count, uint32_t order)
 {
-    kal_update(&cd->ck, (float)index, ck_count, 10, order);
+    if constexpr (KORDER >= 0) {
+        Kal2 k = lds_get(&cd->ck);
+        core::kalman2_update_as<(uint32_t)KORDER>(k, (float)index, ck_count, 10);
+        lds_put(&cd->ck, k);
+    } else {
+        kal_update(&cd->ck, (float)index, ck_count, 10, order);
+    }
     ClockOut o;
     o.sample_est = cd->ck.x0;
     o.sample_index = core::clock_index_of(o.sample_est);
@@ -246,9 +255,11 @@ __device__ __forceinline__ void nf_fire_diag(M17_LDS Cold* cd, uint32_t dcd_on, 
     d.viterbi_cost = (int32_t)vcost; d.dcd_level = cd->dcd_level; d.n_diag++;
     lds_put(&cd->diag, d);
 }
-__device__ __noinline__ void nf_snapshot_hist(int16_t* hist, const int16_t* xr, uint32_t te)
+// the 149 raw samples that end with sample te: the FIR history a later gated run splices in front of its own samples (lane-parallel)
+__device__ __forceinline__ void nf_snapshot_hist(int16_t* hist, const int16_t* xr, uint32_t te, int lane)
 {
-    for (int k = 0; k < 149; ++k) hist[k] = xr[(int64_t)te - 148 + k];
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int k = lane; k < 149; k += 64) hist[k] = xr[(int64_t)te - 148 + k];
 }
 // =====================================================================================================
 }  // namespace m17

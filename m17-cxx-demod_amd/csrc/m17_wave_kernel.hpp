@@ -70,7 +70,7 @@ __device__ __forceinline__ uint2 nf_decode_wave(const DecodeTables* tb, DecodeLd
 // the next block's loads in flight during the recurrence.  h[3] = history after sample from - 1 on entry, after to - 1 on exit.
 struct Hist3 { float h0, h1, h2; };
 typedef float m17_v4f __attribute__((ext_vector_type(4)));
-__device__ __noinline__ Hist3 nf_serve_limit(const float* yr, float* hr, M17_LDS float* B, uint32_t from, uint32_t to, float h0, float h1, float h2)
+__device__ __forceinline__ Hist3 nf_serve_limit(const float* yr, float* hr, M17_LDS float* B, uint32_t from, uint32_t to, float h0, float h1, float h2)
 {
     const uint32_t l = threadIdx.x & 63u;
     float nx[4];
@@ -113,7 +113,9 @@ __device__ __noinline__ Hist3 nf_serve_limit(const float* yr, float* hr, M17_LDS
 // PROF: compile the 100 MHz section timers and counters in (diagnostics, tools/seq_ablate.py); the production
 // instantiation carries none of them.
 // TIMED: per-wave working time per segment (both only in the tools build, -DM17_TOOLS).
-template <int WPB, bool PROF = false, bool TIMED = false>
+// KORDER: the Kalman evaluation order as a compile-time constant (3 = the default order: its clock update is inlined and the kernel makes no
+// call at all: no stack, no scratch), or -1: the order of SeqParams at run time through the out-of-line variants (m17hip_set_kalman_order).
+template <int WPB, bool PROF = false, bool TIMED = false, int KORDER = -1>
 __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(SeqParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     auto cold_lane = [&]() -> int { int l = wl; asm volatile("" : "+v"(l)); return l; };
     const uint32_t c = blockIdx.x * WPB + wave;
     if (c >= P.C) return;
+    const uint32_t korder = KORDER >= 0 ? (uint32_t)KORDER : P.kalman_order;
     uint32_t* wb = lds + WV_TAB_WORDS + wave * WV_WAVE_WORDS;
     float* ring = reinterpret_cast<float*>(wb);              // [80]  Correlator::buffer_
     float* swsm = ring + 80;                                 // [4][10] SyncWord::samples_
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     };
     auto sw_updated = [&](int w) -> int32_t { const int32_t r = s.sw_updated[w]; s.sw_updated[w] = 0; return r; };
     auto update_values = [&](uint32_t index) {  // M17Demodulator.h:233-241
-        const float2 r = nf_update_values(cd, ring, 1, 0, s.sample_index, P.kalman_order, P.level_gain);
+        const float2 r = nf_update_values(cd, ring, 1, 0, s.sample_index, korder, P.level_gain);
         s.idev = r.x; s.offset = r.y;
         s.sync_sample_index = index;
     };
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             s.need_clock_reset = 0;
             s.sample_index = s.sync_sample_index;
         } else if (s.need_clock_update) {
-            const ClockOut o = nf_clock_update_idx(cd, s.sync_sample_index, s.ck_count, P.kalman_order);
+            const ClockOut o = nf_clock_update_idx<KORDER>(cd, s.sync_sample_index, s.ck_count, korder);
             s.ck_sample_est = o.sample_est; s.ck_clock_est = o.clock_est; s.ck_sample_index = o.sample_index;
             s.ck_count = 0;
             s.need_clock_update = 0;
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             if (diverged) pick_hist(te);   // the history freezes here; the next gated run of this segment starts from it
             s.st = ST_UNLOCKED;
             s.dcd_on = 0;
-            nf_snapshot_hist(gs->hist, xr, te);
+            nf_snapshot_hist(gs->hist, xr, te, cold_lane());
         }
         s.count = 0;
         fire_diag(te, sqrtf(s.evm_S));
@@ -815,7 +818,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 const int32_t z_done = flags_t == t ? 0 : -1;   // the prologue of offset 0 has run already (chunk selection: a clock RESET may have left an update pending)
                 bool pend = s.need_clock_update != 0;
                 auto clock_at = [&](uint32_t z) {  // ClockRecovery::update(sync_sample_index) in the prologue of offset z
-                    const ClockOut o = nf_clock_update_idx(cd, s.sync_sample_index, ckz < 0 ? ck_entry + z : z - (uint32_t)ckz, P.kalman_order);
+                    const ClockOut o = nf_clock_update_idx<KORDER>(cd, s.sync_sample_index, ckz < 0 ? ck_entry + z : z - (uint32_t)ckz, korder);
                     s.ck_sample_est = o.sample_est; s.ck_clock_est = o.clock_est; s.ck_sample_index = o.sample_index;
                     ckz = (int32_t)z; pend = false;
                 };
@@ -833,8 +836,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                         lmn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mn), (int)j));
                         lmx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), (int)j));
                         const core::Kalman2Gain g = P.level_gain[ln];
-                        core::level_update(a0, a1, lmn, g, P.kalman_order);
-                        core::level_update(b0v, b1v, lmx, g, P.kalman_order);
+                        core::level_update(a0, a1, lmn, g, korder);
+                        core::level_update(b0v, b1v, lmx, g, korder);
                         ln = min(ln + 1u, (uint32_t)core::LEVEL_SCHED_LAST);
                         ++nupd;
                         if (cd->dev_reset || isnan(a0) || isnan(a1) || isnan(b0v) || isnan(b1v)) {   // FreqDevEstimator::update :40-48
@@ -1022,7 +1025,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             if (mode == BULK_INIT) {
                 s.initializing -= (int32_t)n;
                 s.count = 0;
-                if (s.initializing == 0) nf_snapshot_hist(gs->hist, xr, t + n - 1u);  // the init run ends; the carrier is off
+                if (s.initializing == 0) nf_snapshot_hist(gs->hist, xr, t + n - 1u, cold_lane());  // the init run ends; the carrier is off
             } else {
                 s.count += n;
                 s.ck_count += n;
@@ -1053,12 +1056,12 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         if (s.initializing) {
             --s.initializing;
             s.count = 0;
-            if (s.initializing == 0) nf_snapshot_hist(gs->hist, xr, tt);
+            if (s.initializing == 0) nf_snapshot_hist(gs->hist, xr, tt, cold_lane());
             ++t;
             tk_scalar += now() - c0;
             continue;
         }
-        if (corr_index() == 0 && flags_t != tt) clock_flags();   // (once per index-0 sample: a pending reset AND update take two of them)
+        // (the index-0 prologue (:695-709) of this sample has run in chunk selection: every sample goes through it, and nothing in between sets a flag)
         s.ck_count++;
 #pragma unroll
         for (int i = 0; i < 8; ++i) r8[i] = 0.f;   // (dead outside this step: without the assignment the eight registers stay live across the whole loop)

@@ -1350,7 +1350,8 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         else if (c->wave_times) hipLaunchKernelGGL((demod_wave_kernel<4, false, true>), grid, block, lds, c->stream, P);
         else
 #endif
-        hipLaunchKernelGGL(demod_wave_kernel<4>, grid, block, lds, c->stream, P);
+        if (c->kalman_order == 3u) hipLaunchKernelGGL((demod_wave_kernel<4, false, false, 3>), grid, block, lds, c->stream, P);   // (the default order: no call in the kernel)
+        else hipLaunchKernelGGL(demod_wave_kernel<4>, grid, block, lds, c->stream, P);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(ev_seq[k], c->stream));
         if (k + ahead < nseg && (r = launch_front_seg(c, sp, k + ahead, C, flags))) return r;
