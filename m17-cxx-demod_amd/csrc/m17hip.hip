@@ -60,6 +60,7 @@ struct m17hip_ctx {
     hipEvent_t ev_end[2] = {nullptr, nullptr};   // the last run on slab pair 0 / 1 is done with its slabs
     hipEvent_t ev_mark = nullptr;     // last main-stream operation a front end must not overtake (reset)
     bool slot_used[2] = {false, false};
+    bool inplace_after_run = false;   // the current input slab was overwritten in place after its last run: its data region no longer holds that run's tail
     int slot = 0;                     // slab pair the pointers xbuf / ybuf / hbuf / dcd_table name
     bool staged = false, staged_h2d = false;
     bool stage_inputs = false;        // tuning knob 16: the in-place producers write the staging slab
@@ -767,6 +768,7 @@ static void input_done(m17hip_ctx* c, const InputTarget& t, uint32_t C, uint32_t
     c->uploaded = true;
     c->slabC[c->slot] = C; c->slabT[c->slot] = T;
     c->lastC = C; c->lastT = T;
+    if (c->have_run) c->inplace_after_run = true;
 }
 
 int m17hip_upload_i16(m17hip_ctx* c, const int16_t* host, uint32_t C, uint32_t T, size_t pitch)
@@ -1070,6 +1072,7 @@ int m17hip_demod_reset(m17hip_ctx* c)
     HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));   // the front end of a staged run starts on its own streams: not before this
     c->pos = 0;
     c->have_run = false;
+    c->inplace_after_run = false;
     c->recs_valid = false;
     return M17HIP_OK;
 }
@@ -1162,9 +1165,9 @@ static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, b
     // the new slab's prefix, behind the staged copy on the copy stream; the slab pair itself is free since ev_end[slot] (the copy
     // stream waited for it when the input was staged — m17hip_input_alternate stages without a copy, so wait here as well)
     if (c->slot_used[c->slot]) HIPCHK(c, hipStreamWaitEvent(c->copy, c->ev_end[c->slot], 0));
-    if (c->carryT >= (uint32_t)XPRE)   // the tail of the previous input, where it lies (that slab is only read while its run is in flight)
+    if (c->carryT >= (uint32_t)XPRE && !c->inplace_after_run)   // the tail of the previous input, where it lies (that slab is only read while its run is in flight)
         hipLaunchKernelGGL(copy_tail_i16_kernel, dim3(C), dim3(64), 0, c->copy, xprev, c->xbuf, c->xpitch, c->carryT);
-    else if (c->carryT) {              // a run shorter than the prefix: its tail reaches into its own prefix, which its last kernel rewrites — wait for that
+    else if (c->carryT) {              // (or its data region was overwritten in place since: the tail its last kernel carried into its prefix)              // a run shorter than the prefix: its tail reaches into its own prefix, which its last kernel rewrites — wait for that
         HIPCHK(c, hipStreamWaitEvent(c->copy, c->ev_end[c->slot ^ 1], 0));
         hipLaunchKernelGGL(copy_prefix_i16_kernel, dim3(C), dim3(64), 0, c->copy, xprev, c->xbuf, c->xpitch);
     } else HIPCHK(c, hipMemset2DAsync(c->xbuf, c->xpitch * sizeof(int16_t), 0, XPRE * sizeof(int16_t), C, c->copy));
@@ -1382,6 +1385,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     HIPCHK(c, hipEventRecord(c->ev_end[q], c->stream));
     c->slot_used[q] = true;
     c->pos += T;
+    c->inplace_after_run = false;
     c->lastC = C; c->lastT = T; c->runT = T; c->last_nseg = nseg;
     c->have_run = true;
     c->recs_valid = true;

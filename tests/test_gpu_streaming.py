@@ -122,6 +122,27 @@ def test_two_resident_slabs_alternate_without_copies(ctx):
     _check_diag(ctx, Cn, diags)
 
 
+def test_staged_run_after_an_in_place_overwrite_of_the_previous_slab(ctx):
+    """a run in place, then the same slab overwritten in place (an input that is never run), then the NEXT chunk staged and run:
+    the staged run's 152-sample prefix must be the tail the last RUN carried, not what the data region holds now."""
+    import torch
+    Cn, T = 16, 24000
+    x = _signals(Cn, 2 * T, seed=131, sigma=600.0)
+    exp, diags = _oracle(x)
+    junk = np.full((Cn, T), 12345, dtype=np.int16)
+    pinned = torch.from_numpy(np.ascontiguousarray(x[:, T:])).pin_memory()
+    ctx.reset()
+    ctx.upload(x[:, :T]); ctx.run(channels=Cn, samples=T)
+    parts = [ctx.frames().copy()]
+    ctx.upload(junk)                                   # overwrites the slab the run used (never run)
+    ctx.upload_async(pinned.data_ptr(), Cn, T)         # the real continuation, staged
+    ctx.run(channels=Cn, samples=T)
+    parts.append(ctx.frames().copy())
+    ctx.upload_wait()
+    assert _sorted(parts).tobytes() == exp.tobytes()
+    _check_diag(ctx, Cn, diags)
+
+
 def test_pipelined_ragged_chunks_and_mixed_staging(ctx):
     """Chunks shorter than the carried prefixes (152 input samples, 96 filter outputs), not multiples of 8 / 192 / 1920, staged runs
     with and without m17hip_demod_front and in-place runs in between."""
