@@ -201,11 +201,19 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state
         }
     };
     while (t < segT) {
-        // ---- steady state: every channel of the wave is inside a gated run, past its first 148 samples, and this tick holds
-        //      no update point — nothing but the filter -------------------------------------------------------------------------
+        // ---- steady state: every channel of the wave is inside a gated run, past its first 148 samples — nothing but the filter, and,
+        //      where the tick ends on a carrier-on update point (every fifth one), that point (tail of operator() :742-752) ------------
         {
-            const bool steady = !valid || (init <= 0 && on != 0 && run_pos >= 148 && count + TICK < 960u);
+            const bool steady = !valid || (init <= 0 && on != 0 && run_pos >= 148 && count + TICK <= 960u);
             if (phase == 0 && t + TICK <= segT && ((pos0 + t) & 3u) == 0 && __ballot(!steady) == 0ull) {
+                const bool upd = valid && count + TICK == 960u;
+                float l1 = 0.f, l2 = 0.f;
+                if (upd) {   // the sums the point will want: in flight during the recurrence
+                    const uint64_t krow = min(k_cur - P.tick_row0, (uint64_t)P.ticks_cap - 1);
+                    const float* row = tab + (size_t)krow * 12;
+                    const int jsum = (uint32_t)(k_cur + 1 - seg) > 5 ? 5 : (int)(seg % 5u);
+                    l1 = row[jsum]; l2 = row[6 + jsum];
+                }
                 stage_tick();
                 lds_sync();
                 if (r == 0) iir_tick();
@@ -213,6 +221,11 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state
                 if (valid && store) store_tick();
                 lds_sync();
                 count += TICK;
+                if (upd) {
+                    if (!trig) { on = 0; end_in_run = true; end_t = (int32_t)(t + TICK - 1u); }
+                    count = 0;
+                    dcd_update(k_cur, l1, l2);
+                }
                 t += TICK;
                 ++k_cur;
                 continue;
@@ -353,7 +366,8 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state
     }
 }
 
-__global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
+// (at most 128 VGPRs: a wave of it has to fit into what four K5 waves leave of a SIMD)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void limit_track_kernel(GateParams P)
 {
     __builtin_amdgcn_s_setprio(3);  // K5 of the next segment waits for this kernel: issue ahead of whatever shares the SIMD
     const int lane = threadIdx.x;
@@ -364,8 +378,10 @@ __global__ __launch_bounds__(64) void limit_track_kernel(GateParams P)
         valid = valid && P.only[c] != 0;
         if (!__ballot(valid)) return;   // nothing to redo for these sixteen channels
     }
-    __shared__ __attribute__((aligned(16))) float lds_static[GT_LDS_FLOATS];
-    limit_track_pass(P, (P.flags & 2u) != 0, c, valid, P.chain_in != nullptr, P.only ? P.bnd : nullptr, lds_static);
+    // (dynamic LDS, GT_LDS_FLOATS floats: with a static allocation the compiler sizes the register budget for the LDS-limited occupancy and
+    //  ignores the waves-per-SIMD attribute above)
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    limit_track_pass(P, (P.flags & 2u) != 0, c, valid, P.chain_in != nullptr, P.only ? P.bnd : nullptr, lds_dyn);
 }
 
 }  // namespace m17

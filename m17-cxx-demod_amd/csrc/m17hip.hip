@@ -1141,7 +1141,7 @@ static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStre
     G.only = redo ? c->dropped + (size_t)((k - 1u) & 1u) * c->maxC : nullptr;   // (flags by segment parity)
     G.bnd = redo ? c->bnd + (size_t)(k & 1u) * c->maxC : nullptr;   // (written by K5 of segment k - 1)
     G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags | (redo ? 2u : 0u);
-    hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), 0, st, G);
+    hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), GT_LDS_FLOATS * sizeof(float), st, G);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
