@@ -218,16 +218,17 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         pf_pending = false;
         wave_lds_sync();
     };
+    // (on demand: while a transmission runs the window is read for the ~95 samples of a sync phase per frame — the frame chunks gather their
+    //  symbols from the row — so a granule loaded ahead was thrown away more often than used, and its eight registers were live across the
+    //  whole main loop)
     auto ensure = [&](uint32_t need) {  // make [t, t + need) readable from the window (need <= WV_PF)
         while (avail < t + need && avail < P.T) {
-            if (!pf_pending) pf_issue();
+            pf_issue();
             pf_commit();
-            if (avail < P.T) pf_issue();
         }
     };
     // after ybuf was patched / the window was used as scratch: refill from the granule that holds t0
     auto window_reset = [&](uint32_t t0) { avail = t0 & ~(uint32_t)(WV_PF - 1); pf_pending = false; };
-    pf_issue();
 
     // ---------------- wave-uniform helpers ------------------------------------------------------------------------
     auto corr_index = [&]() -> uint32_t { return s.prev_pos % 10u; };
