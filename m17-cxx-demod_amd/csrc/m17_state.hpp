@@ -231,17 +231,18 @@ __device__ __forceinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32
 }
 // DataCarrierDetect::update (:63-69) with the sums K3 produced for the segment [seg_start_tick, k]; returns the trigger.
 // (have: the two sums were fetched ahead, pl1 / pl2)
-__device__ __forceinline__ uint32_t nf_dcd_update(M17_LDS Cold* cd, const float* tab, uint64_t tick0, uint64_t k, uint32_t trig,
+// (k: the tick that ends at the point, as the 32-bit tick count seg_start_tick is kept in; row: its row in the table of this run)
+__device__ __forceinline__ uint32_t nf_dcd_update(M17_LDS Cold* cd, const float* tab, uint32_t row_index, uint32_t k, uint32_t trig,
                                                   bool have = false, float pl1 = 0.f, float pl2 = 0.f)
 {
-    const float* row = tab + (size_t)(k - tick0) * 12;
-    const uint32_t span = (uint32_t)(k + 1 - cd->seg_start_tick);
+    const float* row = tab + (size_t)row_index * 12;
+    const uint32_t span = k + 1u - cd->seg_start_tick;
     const int j = span > 5 ? 5 : (int)(cd->seg_start_tick % 5u);
     float l1, l2;  // table row: [2 bins][6 sums]
     if (have) { l1 = pl1; l2 = pl2; } else { l1 = row[j]; l2 = row[6 + j]; }
     const float level = core::dcd_level(cd->dcd_level, l1, l2);
     cd->dcd_level = level;
-    cd->seg_start_tick = (uint32_t)(k + 1);
+    cd->seg_start_tick = k + 1u;
     return trig ? (level > 0.1f) : (level > 4.0f);
 }
 // arguments of the diagnostic callback (M17Demodulator.h:681-685, 746-750)

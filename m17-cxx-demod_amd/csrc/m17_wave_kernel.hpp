@@ -191,13 +191,15 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // Sample window: ybuf samples [t, avail) are in LDS; the next WV_PF samples are in flight in registers (pf) so that the
     // HBM/L2 latency of this channel's row is paid ~WV_PF samples ahead of its use instead of at the head of every step.
     float pf[WV_PF / 64];
-    bool pf_pending = false;
     uint32_t avail = 0;
 
     const int16_t* xr = P.x + (size_t)c * P.xpitch + XPRE;
     float* yr = const_cast<float*>(P.y) + (size_t)c * P.ypitch + YPRE;  // K1's output; the first 148 samples of a gated run are patched in place
     const float* tab = P.dcd_table + (size_t)c * P.ticks_cap * 12;
-    const uint64_t tick0 = P.tick_row0;
+    // tick arithmetic in 32 bits: sample 0 of this segment lies pos0_ph samples into tick k0 (its low word: the width seg_start_tick is kept in),
+    // which is row row_k0 of the table of this run
+    const uint32_t pos0_ph = (uint32_t)(P.pos0 % TICK), k0 = (uint32_t)(P.pos0 / TICK), k0_mod5 = (uint32_t)((P.pos0 / TICK) % 5u);
+    const uint32_t row_k0 = (uint32_t)(P.pos0 / TICK - P.tick_row0);
     FrameRec* rec_base = P.recs + (size_t)c * P.rec_cap;
     uint32_t t = 0;  // next sample (relative to this run)
     // Loads go through a buffer resource over this channel's row [0, T): the bounds check is the hardware's (a dword at or beyond
@@ -208,14 +210,12 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         const uint32_t voff = (avail + (uint32_t)wl) * 4u;
 #pragma unroll
         for (int k = 0; k < WV_PF / 64; ++k) pf[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrsrc, (int)(voff + 256u * k), 0, 0));
-        pf_pending = true;
     };
     auto pf_commit = [&]() {  // the loads issued a whole granule ago have landed: move them into the window
         float* dst = ywin + (avail & (WV_WIN - 1)) + wl;
 #pragma unroll
         for (int k = 0; k < WV_PF / 64; ++k) dst[64 * k] = pf[k];
         avail += WV_PF;
-        pf_pending = false;
         wave_lds_sync();
     };
     // (on demand: while a transmission runs the window is read for the ~95 samples of a sync phase per frame — the frame chunks gather their
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         }
     };
     // after ybuf was patched / the window was used as scratch: refill from the granule that holds t0
-    auto window_reset = [&](uint32_t t0) { avail = t0 & ~(uint32_t)(WV_PF - 1); pf_pending = false; };
+    auto window_reset = [&](uint32_t t0) { avail = t0 & ~(uint32_t)(WV_PF - 1); };
 
     // ---------------- wave-uniform helpers ------------------------------------------------------------------------
     auto corr_index = [&]() -> uint32_t { return s.prev_pos % 10u; };
@@ -258,19 +258,19 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // in the decoder's cost-word array (idle between frames; every decode invalidates it).
     float* hpf = reinterpret_cast<float*>(DL.soft) + 240;
     int32_t hpf_base = -0x40000000;
-    bool hpf_wait = false;
+    SReg<uint32_t> hpf_wait; hpf_wait = 0u;   // (wave-uniform flags as scalar WORDS: as bools the long-lived ones were kept as 64-bit lane masks)
     auto hpf_issue = [&](int32_t base) {
         const int64_t i = min((int64_t)base + cold_lane(), (int64_t)P.T - 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hrow + i), (__attribute__((address_space(3))) void*)hpf, 4, 0, 0);
         hpf_base = base;
-        hpf_wait = true;
+        hpf_wait = 1u;
     };
     // The DCD sums of the NEXT update point (two floats of one table row) are fetched the same way right after each update:
     // the point is 960 (carrier on) or 384 samples away and the sum it will read is the one that restarted with the next tick.
     float* dpf = reinterpret_cast<float*>(hot_lds) + 62;   // two spare words of the hot slot
-    uint64_t dpf_tick = ~0ull;
+    uint32_t dpf_tick = 0xFFFFFFFFu;   // relative tick (from k0) whose sums are in dpf (none)
     auto hpf_ready = [&] {
-        if (hpf_wait) { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); hpf_wait = false; }   // vmcnt(0)
+        if (hpf_wait) { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); hpf_wait = 0u; }   // vmcnt(0)
     };
     auto cur_lim = [&]() -> float {
         const int32_t tt = (int32_t)cur_tt;
@@ -294,18 +294,18 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // point) — and keeps reading hbuf like everybody else.  The next segment starts from a fresh replay (K2 redoes the channel from this
     // wave's state).  While diverged, s.h0..h2 = the filter's history after the last sample served / fed.
     unsigned long long n_despec = 0;
-    bool diverged = false;
+    SReg<uint32_t> diverged; diverged = 0u;
     uint32_t h_until = P.T;   // hbuf holds this channel's true history for every fed sample below this (relative) index
     auto pick_hist = [&](uint32_t tt) {   // the history after sample tt, from hbuf (tt < h_until)
         s.h0 = hrow[(int64_t)tt]; s.h1 = hrow[(int64_t)tt - 1]; s.h2 = hrow[(int64_t)tt - 2];
     };
-    bool left_replay = false;   // a forced unlock fell into THIS segment: the replay that is (or was) run for it ends in a state that is not this channel's
+    SReg<uint32_t> left_replay; left_replay = 0u;   // a forced unlock fell into THIS segment: the replay that is (or was) run for it ends in a state that is not this channel's
     auto despec = [&](uint32_t tt) {      // tt: the sample being processed; s.count already counts it
-        left_replay = true;
+        left_replay = 1u;
         if (!diverged) {
             ++n_despec;
             if (cold_lane() == 0) atomicAdd(P.overflow + 1, 1u);   // (statistics: m17hip_replay_drops)
-            diverged = true;
+            diverged = 1u;
             h_until = min(P.T, tt + (960u - min((uint32_t)s.count, 960u)) + 1u);
         }
     };
@@ -376,20 +376,20 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     };
     // DataCarrierDetect::update at the point that ends with relative sample te, then the fetch for the next point
     auto dcd_update_at = [&](uint32_t te) {
-        const uint64_t k = (P.pos0 + te + 1) / TICK - 1;
+        const uint32_t kr = (pos0_ph + te + 1u) / TICK - 1u;          // the tick that ends with sample te, counted from k0
         bool have = false;
         float l1 = 0.f, l2 = 0.f;
-        if (dpf_tick == k) { hpf_ready(); l1 = dpf[0]; l2 = dpf[1]; have = true; }
-        s.dcd_trig = nf_dcd_update(cd, tab, tick0, k, s.dcd_trig, have, l1, l2);
-        const uint64_t kn = k + (s.dcd_on ? 5u : 2u);                 // 960 / 384 samples on
-        const uint64_t ten = (kn + 1) * TICK - 1 - P.pos0;            // relative sample of that point
-        dpf_tick = ~0ull;
-        if (ten < (uint64_t)P.T && kn - tick0 < (uint64_t)P.ticks_cap) {
-            const float* rown = tab + (size_t)(kn - tick0) * 12 + (size_t)((k + 1) % 5u);
+        if (dpf_tick == kr) { hpf_ready(); l1 = dpf[0]; l2 = dpf[1]; have = true; }
+        s.dcd_trig = nf_dcd_update(cd, tab, row_k0 + kr, k0 + kr, s.dcd_trig, have, l1, l2);
+        const uint32_t krn = kr + (s.dcd_on ? 5u : 2u);               // 960 / 384 samples on
+        const uint32_t ten = (krn + 1u) * TICK - 1u - pos0_ph;        // relative sample of that point
+        dpf_tick = 0xFFFFFFFFu;
+        if (ten < P.T && row_k0 + krn < P.ticks_cap) {
+            const float* rown = tab + (size_t)(row_k0 + krn) * 12 + (size_t)((k0_mod5 + kr + 1u) % 5u);
             const int l = cold_lane();
             if (l < 2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rown + 6 * l), (__attribute__((address_space(3))) void*)dpf, 4, 0, 0);
-            dpf_tick = kn;
-            hpf_wait = true;
+            dpf_tick = krn;
+            hpf_wait = 1u;
         }
     };
     const float alpha = core::EVM_ALPHA;  // RunningStandardDeviation<float,184>::alpha
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // a state that is not this channel's; K2 is re-deriving the replay's state from this wave's while we run): it serves itself from
     // its first sample on.  The next segment's replay is good again.
     if (P.dropped_in && P.dropped_in[c]) {
-        diverged = true;
+        diverged = 1u;
         h_until = 0;
         if ((s.initializing || s.dcd_on) && wl == 0) { float* hw = const_cast<float*>(hrow); hw[-1] = s.h0; hw[-2] = s.h1; hw[-3] = s.h2; }
     }
