@@ -185,8 +185,16 @@ using core::clock_predict;
 // ---- out-of-line helpers on COLD state ------------------------------------------------------------------------------
 // M17Demodulator::update_values (:233-241) = Correlator::outer_symbol_levels (Correlator.h:81-114) +
 // FreqDevEstimator::update (FreqDevEstimator.h:31-48).  Returns (idev, offset).
+// WAVE-UNIFORM ARITHMETIC ON SIXTEEN LANES.  The helpers below compute one value per channel = per wave; every lane would compute the same.
+// A VALU instruction costs the same issue time from 16 enabled lanes up (2.7 x more below 16, NOTES 3.5 of round 2) but a quarter of the
+// lane energy, and the matched filter this kernel shares the chip with runs at its power limit: they run under `uniform16()` and hand
+// their results back through scalar registers (SReg / readfirstlane: lane 0 is among the sixteen) or through LDS.
+__device__ __forceinline__ bool uniform16() { return (threadIdx.x & 63u) < 16u; }
+
 __device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float* ring, int stride, int lane, uint32_t si, uint32_t order, const core::Kalman2Gain* gain)
 {
+    float2 out = make_float2(0.f, 0.f);
+    if (uniform16()) {
     // the gain of this update: a function of the update count alone (core.h, level_schedule) — in flight while the levels are formed
     const uint32_t n = cd->lvl_n;
     const core::Kalman2Gain g = gain[n];
@@ -207,7 +215,9 @@ __device__ __forceinline__ float2 nf_update_values(M17_LDS Cold* cd, const float
     }
     cd->min_x0 = a0; cd->min_x1 = a1; cd->max_x0 = b0; cd->max_x1 = b1; cd->lvl_n = nn;
     cd->dev_reset = 0;
-    return make_float2(idev, offset);
+    out = make_float2(idev, offset);
+    }
+    return out;
 }
 struct ClockOut { float sample_est, clock_est; int32_t sample_index; };
 // ClockRecovery::update(uint8_t) (ClockRecovery.h:54-67)
@@ -216,17 +226,22 @@ struct ClockOut { float sample_est, clock_est; int32_t sample_index; };
 template <int KORDER = -1>
 __device__ __forceinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32_t index, uint32_t ck_count, uint32_t order)
 {
+    ClockOut o{0.f, 0.f, 0};
     if constexpr (KORDER >= 0) {
-        Kal2 k = lds_get(&cd->ck);
-        core::kalman2_update_as<(uint32_t)KORDER>(k, (float)index, ck_count, 10);
-        lds_put(&cd->ck, k);
+        if (uniform16()) {
+            Kal2 k = lds_get(&cd->ck);
+            core::kalman2_update_as<(uint32_t)KORDER>(k, (float)index, ck_count, 10);
+            lds_put(&cd->ck, k);
+            o.sample_est = k.x0;
+            o.sample_index = core::clock_index_of(o.sample_est);
+            o.clock_est = k.x1;
+        }
     } else {
-        kal_update(&cd->ck, (float)index, ck_count, 10, order);
+        kal_update(&cd->ck, (float)index, ck_count, 10, order);   // (a call: every lane)
+        o.sample_est = cd->ck.x0;
+        o.sample_index = core::clock_index_of(o.sample_est);
+        o.clock_est = cd->ck.x1;
     }
-    ClockOut o;
-    o.sample_est = cd->ck.x0;
-    o.sample_index = core::clock_index_of(o.sample_est);
-    o.clock_est = cd->ck.x1;
     return o;
 }
 // DataCarrierDetect::update (:63-69) with the sums K3 produced for the segment [seg_start_tick, k]; returns the trigger.
@@ -235,26 +250,32 @@ __device__ __forceinline__ ClockOut nf_clock_update_idx(M17_LDS Cold* cd, uint32
 __device__ __forceinline__ uint32_t nf_dcd_update(M17_LDS Cold* cd, const float* tab, uint32_t row_index, uint32_t k, uint32_t trig,
                                                   bool have = false, float pl1 = 0.f, float pl2 = 0.f)
 {
-    const float* row = tab + (size_t)row_index * 12;
-    const uint32_t span = k + 1u - cd->seg_start_tick;
-    const int j = span > 5 ? 5 : (int)(cd->seg_start_tick % 5u);
-    float l1, l2;  // table row: [2 bins][6 sums]
-    if (have) { l1 = pl1; l2 = pl2; } else { l1 = row[j]; l2 = row[6 + j]; }
-    const float level = core::dcd_level(cd->dcd_level, l1, l2);
-    cd->dcd_level = level;
-    cd->seg_start_tick = k + 1u;
-    return trig ? (level > 0.1f) : (level > 4.0f);
+    uint32_t out = 0;
+    if (uniform16()) {
+        const float* row = tab + (size_t)row_index * 12;
+        const uint32_t span = k + 1u - cd->seg_start_tick;
+        const int j = span > 5 ? 5 : (int)(cd->seg_start_tick % 5u);
+        float l1, l2;  // table row: [2 bins][6 sums]
+        if (have) { l1 = pl1; l2 = pl2; } else { l1 = row[j]; l2 = row[6 + j]; }
+        const float level = core::dcd_level(cd->dcd_level, l1, l2);
+        cd->dcd_level = level;
+        cd->seg_start_tick = k + 1u;
+        out = trig ? (level > 0.1f) : (level > 4.0f);
+    }
+    return out;
 }
 // arguments of the diagnostic callback (M17Demodulator.h:681-685, 746-750)
 __device__ __forceinline__ void nf_fire_diag(M17_LDS Cold* cd, uint32_t dcd_on, float evm_arg, float idev, float offset, uint32_t locked, float clock,
                                           uint32_t sample_index, uint32_t sync_index, int32_t clock_index, uint32_t vcost)
 {
-    Diag d = lds_get(&cd->diag);
-    d.dcd = (int32_t)dcd_on; d.evm = evm_arg; d.deviation = 2400.f / idev; d.offset = offset;
-    d.locked = (int32_t)locked; d.clock = clock; d.sample_index = (int32_t)sample_index;
-    d.sync_index = (int32_t)sync_index; d.clock_index = (int32_t)(uint8_t)clock_index;
-    d.viterbi_cost = (int32_t)vcost; d.dcd_level = cd->dcd_level; d.n_diag++;
-    lds_put(&cd->diag, d);
+    if (uniform16()) {
+        Diag d = lds_get(&cd->diag);
+        d.dcd = (int32_t)dcd_on; d.evm = evm_arg; d.deviation = 2400.f / idev; d.offset = offset;
+        d.locked = (int32_t)locked; d.clock = clock; d.sample_index = (int32_t)sample_index;
+        d.sync_index = (int32_t)sync_index; d.clock_index = (int32_t)(uint8_t)clock_index;
+        d.viterbi_cost = (int32_t)vcost; d.dcd_level = cd->dcd_level; d.n_diag++;
+        lds_put(&cd->diag, d);
+    }
 }
 // the 149 raw samples that end with sample te: the FIR history a later gated run splices in front of its own samples (lane-parallel)
 __device__ __forceinline__ void nf_snapshot_hist(int16_t* hist, const int16_t* xr, uint32_t te, int lane)

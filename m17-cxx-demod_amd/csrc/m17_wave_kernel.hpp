@@ -86,20 +86,22 @@ __device__ __forceinline__ Hist3 nf_serve_limit(const float* yr, float* hr, M17_
         for (int j = 0; j < 4; ++j) B[l + 64u * j] = nx[j];
         wave_lds_sync();
         if (b + 256u < to) load(b + 256u);
-        uint32_t i = 0;
-        for (; i + 4 <= n; i += 4) {
-            const m17_v4f v = *reinterpret_cast<const M17_LDS m17_v4f*>(B + i);
-            m17_v4f o;
-            o.x = iir_advance_pk(fabsf(v.x), h0, m2); h2 = h1; h1 = h0; h0 = o.x;
-            o.y = iir_advance_pk(fabsf(v.y), h0, m2); h2 = h1; h1 = h0; h0 = o.y;
-            o.z = iir_advance_pk(fabsf(v.z), h0, m2); h2 = h1; h1 = h0; h0 = o.z;
-            o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
-            *reinterpret_cast<M17_LDS m17_v4f*>(B + i) = o;
-        }
-        for (; i < n; ++i) {
-            const float hn = iir_advance_pk(fabsf(B[i]), h0, m2);
-            h2 = h1; h1 = h0; h0 = hn;
-            B[i] = hn;
+        if (l < 16u) {   // the recurrence is one value per sample for the whole wave: sixteen lanes (uniform16, m17_state.hpp)
+            uint32_t i = 0;
+            for (; i + 4 <= n; i += 4) {
+                const m17_v4f v = *reinterpret_cast<const M17_LDS m17_v4f*>(B + i);
+                m17_v4f o;
+                o.x = iir_advance_pk(fabsf(v.x), h0, m2); h2 = h1; h1 = h0; h0 = o.x;
+                o.y = iir_advance_pk(fabsf(v.y), h0, m2); h2 = h1; h1 = h0; h0 = o.y;
+                o.z = iir_advance_pk(fabsf(v.z), h0, m2); h2 = h1; h1 = h0; h0 = o.z;
+                o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
+                *reinterpret_cast<M17_LDS m17_v4f*>(B + i) = o;
+            }
+            for (; i < n; ++i) {
+                const float hn = iir_advance_pk(fabsf(B[i]), h0, m2);
+                h2 = h1; h1 = h0; h0 = hn;
+                B[i] = hn;
+            }
         }
         wave_lds_sync();
 #pragma unroll
@@ -697,16 +699,24 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 // RunningStandardDeviation::capture (StandardDeviation.h:60-72), sequential, symbol by symbol; stops where an update point wants the value
                 float Sv = s.evm_S;
                 uint32_t kf = 0;
+                // (wave-uniform arithmetic: sixteen lanes enabled — the issue time of a VALU instruction is the same from 16 lanes up, the
+                //  energy is not, and the matched filter this kernel shares the chip with is power-limited)
                 auto fold_to = [&](uint32_t kend) {
-                    for (; kf < kend && (kf & 3u); ++kf) { Sv = Sv - Sv * alpha; Sv = Sv + ev[kf]; }
-                    for (; kf + 4 <= kend; kf += 4) {
-                        const float4 g = *reinterpret_cast<const float4*>(ev + kf);
-                        Sv = Sv - Sv * alpha; Sv = Sv + g.x;
-                        Sv = Sv - Sv * alpha; Sv = Sv + g.y;
-                        Sv = Sv - Sv * alpha; Sv = Sv + g.z;
-                        Sv = Sv - Sv * alpha; Sv = Sv + g.w;
+                    const uint32_t k0f = kf;
+                    if (wl < 16) {
+                        uint32_t k = k0f;
+                        for (; k < kend && (k & 3u); ++k) { Sv = Sv - Sv * alpha; Sv = Sv + ev[k]; }
+                        for (; k + 4 <= kend; k += 4) {
+                            const float4 g = *reinterpret_cast<const float4*>(ev + k);
+                            Sv = Sv - Sv * alpha; Sv = Sv + g.x;
+                            Sv = Sv - Sv * alpha; Sv = Sv + g.y;
+                            Sv = Sv - Sv * alpha; Sv = Sv + g.z;
+                            Sv = Sv - Sv * alpha; Sv = Sv + g.w;
+                        }
+                        for (; k < kend; ++k) { Sv = Sv - Sv * alpha; Sv = Sv + ev[k]; }
                     }
-                    for (; kf < kend; ++kf) { Sv = Sv - Sv * alpha; Sv = Sv + ev[kf]; }
+                    Sv = SReg<float>::uni(Sv);
+                    kf = max(k0f, kend);
                 };
                 bool served = false;
                 uint32_t d_last = 0;
@@ -836,19 +846,24 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                         s.missing_sync_count += 1;
                         lmn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mn), (int)j));
                         lmx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), (int)j));
-                        const core::Kalman2Gain g = P.level_gain[ln];
-                        core::level_update(a0, a1, lmn, g, korder);
-                        core::level_update(b0v, b1v, lmx, g, korder);
+                        uint32_t rst = 0;
+                        if (uniform16()) {
+                            const core::Kalman2Gain g = P.level_gain[ln];
+                            core::level_update(a0, a1, lmn, g, korder);
+                            core::level_update(b0v, b1v, lmx, g, korder);
+                            rst = (cd->dev_reset || isnan(a0) || isnan(a1) || isnan(b0v) || isnan(b1v)) ? 1u : 0u;   // FreqDevEstimator::update :40-48
+                        }
+                        rst = SReg<uint32_t>::uni(rst);
                         ln = min(ln + 1u, (uint32_t)core::LEVEL_SCHED_LAST);
                         ++nupd;
-                        if (cd->dev_reset || isnan(a0) || isnan(a1) || isnan(b0v) || isnan(b1v)) {   // FreqDevEstimator::update :40-48
-                            a0 = lmn; a1 = 0.f; b0v = lmx; b1v = 0.f; ln = 0; cd->dev_reset = 0; rst_seen = true;
-                        } else rst_seen = false;
+                        if (rst) { a0 = lmn; a1 = 0.f; b0v = lmx; b1v = 0.f; ln = 0; cd->dev_reset = 0; rst_seen = true; }
+                        else rst_seen = false;
                     }
                     served = j + 1u;
                 }
                 if (nupd) {
-                    cd->min_x0 = a0; cd->min_x1 = a1; cd->max_x0 = b0v; cd->max_x1 = b1v; cd->lvl_n = ln;
+                    if (uniform16()) { cd->min_x0 = a0; cd->min_x1 = a1; cd->max_x0 = b0v; cd->max_x1 = b1v; }   // (the filters' state lives in those lanes)
+                    cd->lvl_n = ln;
                     if (rst_seen) { s.offset = (lmn + lmx) / 2.f; s.idev = core::freqdev_idev(lmx, lmn); }
                     else { s.offset = core::freqdev_offset(b0v, a0); s.idev = core::freqdev_idev(b0v, a0); }
                     s.sync_sample_index = S;
