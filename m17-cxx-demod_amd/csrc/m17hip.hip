@@ -99,6 +99,7 @@ struct m17hip_ctx {
     int gather_fault = 0;             // tuning knob 30 (tests): 1 = this rank's compaction fails inside the gather, 2 = the root's staging allocation fails
     uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
     uint32_t front_first = 0;         // tuning knob 12: segments of K1 that must be complete before the first K5 starts (0 = its own only)
+    int redo_form = 0;                // tuning knob 20: the replay's redo beside K5, state only (0, default), or in front of K5 with the history stored (1)
     int dcd_form = -1;                // tuning knob 10: K3 as one wave per 32 channels (0), as the four-wave latency pipeline (1), or chosen per run (-1: the pipeline for runs queued by m17hip_demod_front)
     bool dcd_latency = false;         // what the launches of the run being queued use
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
@@ -1129,7 +1130,7 @@ static int launch_front_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, uint32
 
 // One launch of K2 over segment k of the run whose slabs the context names: the whole segment from K5's state (first segment), ahead of
 // K5 from K2's own state, or the redo of the channels K5 flagged in the previous segment.
-static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStream_t st, bool ahead, bool redo, uint32_t C, uint32_t flags)
+static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStream_t st, bool ahead, bool redo, uint32_t C, uint32_t flags, bool redo_stores = false)
 {
     const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
     Timed tm(c, KT_GATE, st);
@@ -1140,7 +1141,7 @@ static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStre
     G.chain_in = ahead ? c->gate_exp : nullptr; G.chain_out = c->gate_exp;
     G.only = redo ? c->dropped + (size_t)((k - 1u) & 1u) * c->maxC : nullptr;   // (flags by segment parity)
     G.bnd = redo ? c->bnd + (size_t)(k & 1u) * c->maxC : nullptr;   // (written by K5 of segment k - 1)
-    G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags | (redo ? 2u : 0u);
+    G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags | ((redo && !redo_stores) ? 2u : 0u);
     hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), GT_LDS_FLOATS * sizeof(float), st, G);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
@@ -1227,6 +1228,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     GUARD(c);
     int r;
     bool staged_run = false;
+    const bool from_front = c->front_pending;
     if (c->front_pending) {   // the front end is already on its way (m17hip_demod_front): this call must be the run it was queued for
         if (C != c->frontC || T != c->frontT || flags != c->front_flags) return M17HIP_ESTATE;
         c->front_pending = false;
@@ -1286,13 +1288,23 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipMemsetAsync(c->bnd, 0, 2 * (size_t)c->maxC * sizeof(Boundary), c->stream));
     }
     uint32_t* const drop_of[2] = {c->dropped, c->dropped + c->maxC};   // by segment parity
-    auto launch_gate = [&](uint32_t k, hipStream_t st, bool ahead, bool redo) -> int {
+    auto launch_gate = [&](uint32_t k, hipStream_t st, bool ahead, bool redo, bool redo_stores = false) -> int {
         if (k == 0 && c->gate0_queued) {   // m17hip_demod_front has queued this one on the replay stream, behind the prefix copies
             HIPCHK(c, hipStreamWaitEvent(st, ev_gate[0], 0));
             return M17HIP_OK;
         }
-        return launch_gate_seg(c, sp, k, st, ahead, redo, C, flags);
+        return launch_gate_seg(c, sp, k, st, ahead, redo, C, flags, redo_stores);
     };
+    // Redo policy (m17hip_tune key 20).  IN FRONT of K5: the redo stores the history of segment k for the channels that left the replay in
+    // k - 1 before K5(k) starts — sixteen channels per instruction instead of one wave each carrying the filter itself through segment k
+    // (3 dependent instructions per sample): fewer instructions, but 1-2 ms of replay latency on the K5 chain of every segment that follows
+    // a drop.  BESIDE K5: the redo re-derives the replay's end state only, the channels concerned serve themselves through segment k, K5
+    // never waits.  Measured (NOTES 4.11): wherever the chain of K5 launches is what a step lasts — a continued stream, one batch at a time —
+    // the redo beside K5 wins (24.3 against 27.3 ms, 28.6 against 30.5); several independent batches in flight, whose chains have slack
+    // and which are bound by the instruction total, are 1.4 % faster with the redo in front: the default is beside, a host that overlaps
+    // batches may ask for the other (bench.py does for its two-batch regime).
+    const bool redo_front = c->redo_form == 1;
+    (void)from_front;
     // one wave per channel, four waves per workgroup
     constexpr uint32_t wpb = 4;
     const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
@@ -1331,6 +1343,11 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
                 if ((r = launch_gate(0, c->stream, false, false))) return r;
                 HIPCHK(c, hipEventRecord(ev_redo[0], c->stream));
                 HIPCHK(c, hipStreamWaitEvent(c->side3, ev_redo[0], 0));
+            } else if (redo_front) {
+                HIPCHK(c, hipStreamWaitEvent(c->stream, ev_gate[k], 0));
+                if ((r = launch_gate(k, c->stream, false, true, true))) return r;   // (flagged channels only: from their boundary records, history stored)
+                HIPCHK(c, hipEventRecord(ev_redo[k], c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->side3, ev_redo[k], 0));
             } else {
                 HIPCHK(c, hipStreamWaitEvent(c->stream, ev_gate[k], 0));
                 if (k + 1 < nseg) {
@@ -1347,7 +1364,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         }
         Timed tm(c, KT_SEQ);
         SeqParams P = seq_params(k, t0, len);
-        P.dropped_in = k > 0 ? drop_of[(k - 1u) & 1u] : nullptr;
+        P.dropped_in = (k > 0 && !redo_front) ? drop_of[(k - 1u) & 1u] : nullptr;   // (redo in front: nobody starts a segment off the replay)
 #ifdef M17_TOOLS
         if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P);
         else if (c->wave_times) hipLaunchKernelGGL((demod_wave_kernel<4, false, true>), grid, block, lds, c->stream, P);
@@ -1840,6 +1857,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 10:  // K3 form: 0 = one wave per 32 channels (throughput), 1 = four-wave pipeline (latency), -1 (default) = the pipeline for the runs m17hip_demod_front queues
         if (value < -1 || value > 1) return M17HIP_EINVAL;
         c->dcd_form = (int)value;
+        return M17HIP_OK;
+    case 20:  // redo policy of the limit-filter replay: 0 (default) = beside K5, state only; 1 = in front of K5, history stored
+        if (value < 0 || value > 1) return M17HIP_EINVAL;
+        c->redo_form = (int)value;
         return M17HIP_OK;
     case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1, default), or in K5 (0)
         c->defer_decode = value != 0;

@@ -32,7 +32,7 @@ def _sorted(parts):
     return got[np.lexsort((got["seq"], got["channel"]))]
 
 
-@pytest.fixture(scope="module", params=[{}, {15: 0}, {3: 7001}, {3: 9600, 15: 0}, {10: 0}], ids=["default", "decode_in_k5", "seg7001", "seg9600_decode_in_k5", "k3_throughput_form"])
+@pytest.fixture(scope="module", params=[{}, {15: 0}, {3: 7001}, {3: 9600, 15: 0}, {10: 0, 20: 1}], ids=["default", "decode_in_k5", "seg7001", "seg9600_decode_in_k5", "k3_throughput_form_redo_in_front"])
 def ctx(request):
     c = m17hip.Context(64, 48000)
     for k, v in request.param.items():
