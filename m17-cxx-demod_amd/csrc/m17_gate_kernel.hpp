@@ -64,10 +64,16 @@ struct GateParams {
     uint32_t flags;
 };
 
-constexpr int GT_LPC = 4;             // lanes per channel (cooperative loads / stores; the recurrence runs on lane 0 of them)
+constexpr int GT_LPC = 4;             // lanes per channel (cooperative loads / stores; the recurrence runs on the first of them)
 constexpr int GT_CPW = 64 / GT_LPC;   // channels per wave
+// Lane l = channel l % 16 of the wave, helper l / 16 of that channel: the sixteen lanes that carry the recurrence are lanes 0..15 — ONE
+// quarter of the wave.  A packed instruction whose enabled lanes lie in one quarter is through the pipeline sooner (the dependent
+// chain of the filter: 7.3 ns per sample on sixteen contiguous lanes, 12.3 on sixteen lanes spread over the four quarters;
+// tools/serve_bench2.hip), and with rows of TICK + 4 words the sixteen rows start in sixteen different LDS bank groups for the
+// recurrence's 16-byte reads as well as for the staging (rows of TICK words: all sixteen in the same banks).
+constexpr int GT_ROW = TICK + 4;      // LDS row of a channel's tick (words)
 constexpr int GT_F4 = TICK / 4 / GT_LPC;  // float4 per lane per tick
-constexpr int GT_LDS_FLOATS = GT_CPW * TICK + GT_CPW * 148 + 298;   // 22.9 KB
+constexpr int GT_LDS_FLOATS = GT_CPW * GT_ROW + GT_CPW * 148 + 298;   // 23.2 KB
 
 // One pass over the segment P names for the sixteen channels of a wave.  Per lane: `valid` = the channel takes part (stores, exports its
 // end state); a lane that does not idles.  `from_chain` (wave-uniform) = the pass starts from the replay's own state, else from K5's:
@@ -82,12 +88,12 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state
     const uint64_t pos0 = P.pos0 + t0;
     // matched-filter samples of the current piece, replaced IN PLACE by h0 after each of them (the recurrence reads a sample, or the
     // block of samples ahead of it, before it stores the history value over it): one 12 KB array instead of two
-    float (&yl)[GT_CPW][TICK] = *reinterpret_cast<float (*)[GT_CPW][TICK]>(lds_base);
-    float (&hl)[GT_CPW][TICK] = yl;
-    float (&pl)[GT_CPW][148] = *reinterpret_cast<float (*)[GT_CPW][148]>(lds_base + GT_CPW * TICK);   // patched first outputs of the current run
-    float (&pw)[298] = *reinterpret_cast<float (*)[298]>(lds_base + GT_CPW * TICK + GT_CPW * 148);      // patch window: 149 snapshot + 148 run samples
+    float (&yl)[GT_CPW][GT_ROW] = *reinterpret_cast<float (*)[GT_CPW][GT_ROW]>(lds_base);
+    float (&hl)[GT_CPW][GT_ROW] = yl;
+    float (&pl)[GT_CPW][148] = *reinterpret_cast<float (*)[GT_CPW][148]>(lds_base + GT_CPW * GT_ROW);   // patched first outputs of the current run
+    float (&pw)[298] = *reinterpret_cast<float (*)[298]>(lds_base + GT_CPW * GT_ROW + GT_CPW * 148);      // patch window: 149 snapshot + 148 run samples
     const int lane = threadIdx.x;
-    const int g = lane / GT_LPC, r = lane % GT_LPC;
+    const int g = lane % GT_CPW, r = lane / GT_CPW;
     const bool invert = P.flags & 1u;
     // flags bit 1: a replay whose history values nobody will read (the channels K5 serves itself, m17_wave_kernel.hpp): only the
     // replay's end state is wanted, hbuf is left alone (K5 is writing those very rows)
@@ -238,8 +244,8 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state
         const unsigned long long pm = __ballot(need_patch);
         if (pm) {
             for (int gg = 0; gg < GT_CPW; ++gg) {
-                if (!((pm >> (GT_LPC * gg)) & 1ull)) continue;   // wave-uniform
-                const int src = GT_LPC * gg;
+                if (!((pm >> gg) & 1ull)) continue;   // wave-uniform
+                const int src = gg;
                 const uint32_t cc = (uint32_t)__shfl((int)c, src);
                 const int32_t rp = __shfl(run_pos, src);
                 const int32_t rs = (int32_t)t - rp;           // relative index of the run's first sample (>= -148)
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 {
     __builtin_amdgcn_s_setprio(3);  // K5 of the next segment waits for this kernel: issue ahead of whatever shares the SIMD
     const int lane = threadIdx.x;
-    uint32_t c = blockIdx.x * GT_CPW + lane / GT_LPC;
+    uint32_t c = blockIdx.x * GT_CPW + lane % GT_CPW;
     bool valid = c < P.C;
     if (!valid) c = P.C - 1;  // (a real row for its addresses; the lane idles)
     if (P.only) {

@@ -73,30 +73,59 @@ typedef float m17_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ Hist3 nf_serve_limit(const float* yr, float* hr, M17_LDS float* B, uint32_t from, uint32_t to, float h0, float h1, float h2)
 {
     const uint32_t l = threadIdx.x & 63u;
+    // Both rows through buffer descriptors that end at `to`: a load beyond it returns 0, a store beyond it is dropped — four loads and four
+    // stores per block on EVERY path, so that the wait for a block's samples can leave the previous block's stores in flight (with the
+    // bounds as branches the wait-count insertion could only wait for everything: a store round trip per 256 samples).
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc((void*)yr, 0, (int)(to * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t hdst = __builtin_amdgcn_make_buffer_rsrc((void*)hr, 0, (int)(to * 4u), 0x00020000);
     float nx[4];
     auto load = [&](uint32_t b) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t i = b + l + 64u * j; nx[j] = i < to ? yr[i] : 0.f; }
+        for (int j = 0; j < 4; ++j) nx[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ysrc, (int)((b + l + 64u * j) * 4u), 0, 0));
     };
     load(from);
-    float m2 = IirCoef::a2 * h1;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(0, hdst, 0x7FFF0000 + 256 * j, 0, 0);   // (four dropped stores: the first block's wait sees what every later one sees)
     for (uint32_t b = from; b < to; b += 256u) {
         const uint32_t n = min(256u, to - b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) B[l + 64u * j] = nx[j];
         wave_lds_sync();
-        if (b + 256u < to) load(b + 256u);
+        load(b + 256u);   // (beyond `to`: zeros, not used)
         if (l < 16u) {   // the recurrence is one value per sample for the whole wave: sixteen lanes (uniform16, m17_state.hpp)
+            // (eight samples per pass, the next pass's two LDS reads issued before the recurrence: a wave that serves itself is what its
+            // launch waits for, and a read per four samples waited for on the spot was most of the loop.  The packed multiply (a1 h, a2 h)
+            // takes h from the lower or upper half of the register pair the outputs are collected in: written as `{h, h} * {a1, a2}` the
+            // compiler uses whatever register follows h's as the unused half — a register of the global loads in flight, whose latency
+            // the wait-count insertion then puts into the chain once per block.)
+            const M17_LDS m17_v4f* B4 = reinterpret_cast<const M17_LDS m17_v4f*>(B);
+            M17_LDS m17_v4f* O4 = reinterpret_cast<M17_LDS m17_v4f*>(B);
+            const iir_v2f coef = {IirCoef::a1, IirCoef::a2};
+            float m2 = IirCoef::a2 * h1;
+            iir_v2f p0 = {h2, h2}, p1 = {h1, h0};   // the last four history values; p1.y = the newest
+            auto lo = [&](iir_v2f p) { iir_v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(p), "s"(coef)); return r; };
+            auto hi = [&](iir_v2f p) { iir_v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(p), "s"(coef)); return r; };
+            auto four = [&](const m17_v4f v) {
+                iir_v2f r;
+                r = hi(p1); p0.x = (fabsf(v.x) - r.x) - m2; m2 = r.y;
+                r = lo(p0); p0.y = (fabsf(v.y) - r.x) - m2; m2 = r.y;
+                r = hi(p0); p1.x = (fabsf(v.z) - r.x) - m2; m2 = r.y;
+                r = lo(p1); p1.y = (fabsf(v.w) - r.x) - m2; m2 = r.y;
+                return m17_v4f{p0.x, p0.y, p1.x, p1.y};
+            };
+            m17_v4f c0 = B4[0], c1 = B4[1];
             uint32_t i = 0;
-            for (; i + 4 <= n; i += 4) {
-                const m17_v4f v = *reinterpret_cast<const M17_LDS m17_v4f*>(B + i);
-                m17_v4f o;
-                o.x = iir_advance_pk(fabsf(v.x), h0, m2); h2 = h1; h1 = h0; h0 = o.x;
-                o.y = iir_advance_pk(fabsf(v.y), h0, m2); h2 = h1; h1 = h0; h0 = o.y;
-                o.z = iir_advance_pk(fabsf(v.z), h0, m2); h2 = h1; h1 = h0; h0 = o.z;
-                o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
-                *reinterpret_cast<M17_LDS m17_v4f*>(B + i) = o;
+            for (; i + 8 <= n; i += 8) {
+                const m17_v4f v0 = c0, v1 = c1;
+                c0 = B4[min(i / 4u + 2u, 62u)];
+                c1 = B4[min(i / 4u + 3u, 63u)];
+                __builtin_amdgcn_sched_barrier(0);
+                O4[i / 4u] = four(v0);
+                O4[i / 4u + 1u] = four(v1);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (i) { h0 = p1.y; h1 = p1.x; h2 = p0.y; }
             for (; i < n; ++i) {
                 const float hn = iir_advance_pk(fabsf(B[i]), h0, m2);
                 h2 = h1; h1 = h0; h0 = hn;
@@ -105,7 +134,7 @@ __device__ __forceinline__ Hist3 nf_serve_limit(const float* yr, float* hr, M17_
         }
         wave_lds_sync();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t i2 = l + 64u * j; if (i2 < n) hr[b + i2] = B[i2]; }
+        for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, B[l + 64u * j]), hdst, (int)((b + l + 64u * j) * 4u), 0, 0);
         wave_lds_sync();
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the history values are read back by this wave (other lanes, later loads)
@@ -907,11 +936,12 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             const uint32_t rp0 = s.ring_pos;
             const uint32_t kw = s.sync_count < 77 ? (uint32_t)(77 - s.sync_count) : 0u;   // samples in front of the window
             const uint32_t nw = n > kw ? n - kw : 0u;                                     // window samples in the chunk (<= 9)
-            const uint32_t k = kw + (uint32_t)wl;
+            // (sixteen lanes at least: a VALU instruction with fewer enabled lanes issues 2.7 x slower; the spare lanes redo the last sample)
+            const uint32_t k = kw + min((uint32_t)wl, nw ? nw - 1u : 0u);
             const int wd = (s.st == ST_STREAM_SYNC) ? 1 : 2;   // the word a *_SYNC state looks for
             bool hit = false, trg = false;
             float vk = 0.f;
-            if ((uint32_t)wl < nw) {
+            if (nw && wl < 16) {
                 float h0k, h1k, h2k;   // the limit filter's history after sample k
                 const int32_t off = (int32_t)(t + k) - hpf_base;
                 if (off >= 2 && off < 64) { hpf_ready(); h0k = hpf[off]; h1k = hpf[off - 1]; h2k = hpf[off - 2]; }
@@ -928,6 +958,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 vk = corr(wd);
                 trg = beyond(wd, vk) && vk != 0.f;   // SyncWord::operator() tests the RETURNED value: an exact 0 beyond a negative limit is no trigger
                 if (s.st == ST_STREAM_SYNC) { const float v3 = corr(3); hit = beyond(3, v3) && v3 > 0.1f; }   // EOT :424
+                if ((uint32_t)wl >= nw) { trg = false; hit = false; }
             }
             unsigned long long mask = __ballot(hit);
             const unsigned long long tmask = __ballot(trg);
