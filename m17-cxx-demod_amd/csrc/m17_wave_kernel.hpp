@@ -589,6 +589,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
         enum { BULK_NONE, BULK_INIT, BULK_QUIET, BULK_FEED, BULK_FRAME, BULK_SEARCH, BULK_SYNCWIN, BULK_LSF };
         int mode = BULK_NONE;
         uint32_t n = 0, o1 = 0;
+        uint32_t upd_off = 0xFFFFFFFFu;   // BULK_FRAME: offset of the index-0 sample inside the chunk on which a pending clock update is due
         bool completes = false;   // the chunk ends on the sample that completes the frame (BULK_FRAME) / leaves SYNC_WAIT (BULK_QUIET)
         {
             const uint32_t room = min(P.T - t, (uint32_t)WV_YCH);
@@ -640,7 +641,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     // (a frame chunk is bounded by neither the sample window nor the carrier-detect update points: it takes its symbol
                     //  samples from the channel's row and serves the update points that fall inside it on its way)
                     uint32_t lim_f = P.T - t;
-                    if (s.need_clock_reset | s.need_clock_update) lim_f = min(lim_f, 10u - idx0);
+                    // (a pending clock UPDATE — every frame of a locked stream starts with one, set on leaving SYNC_WAIT — is served inside
+                    //  the chunk, on the index-0 sample it is due on; a pending reset ends the chunk in front of that sample)
+                    if (s.need_clock_reset) lim_f = min(lim_f, 10u - idx0);
+                    else if (s.need_clock_update) upd_off = 10u - idx0;
                     if (diverged) lim_f = min(lim_f, 960u - s.count);   // (a wave that serves itself the limit filter does so from update point to update point: no sample may be passed over)
                     n = min(last + 1u, lim_f);
                     completes = n == last + 1u;
@@ -684,19 +688,44 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             // (lane l checks anti-phase samples l, l + 64, ...; the first one that moves it is the chunk's last sample: do_frame does nothing
             //  else on that sample — it is no symbol sample — so the move itself is committed with the chunk, and the next chunk starts
             //  from the new sample_index)
+            // The clock update that is due on the index-0 sample at offset u0 (:695-709; ClockRecovery::update(uint8_t) :54-67 on the count
+            // up to that sample): the anti-phase samples from u0 on predict from ITS estimate, with the count restarted there; the one that
+            // may lie in front of it predicts from the old one.  Served here if the chunk reaches u0 the way the sample-by-sample form would:
+            // no anti-phase move in front of it, no carrier-detect update point in front of it (its diagnostic record holds the clock
+            // state); otherwise the chunk ends in front of u0 as it used to and the update is served during the next chunk selection.
+            const float est_old = s.ck_sample_est, clk_old = s.ck_clock_est;
+            const uint32_t cnt_old = s.ck_count;
+            uint32_t u0 = upd_off;
+            if (u0 != 0xFFFFFFFFu) {
+                bool ok = u0 < n && 959u - s.count >= u0;
+                if (ok && a1 < u0) ok = (uint32_t)(uint8_t)clock_predict(est_old, clk_old, cnt_old + a1 + 1u) == S;
+                if (ok) {
+                    const ClockOut o = nf_clock_update_idx<KORDER>(cd, s.sync_sample_index, cnt_old + u0, korder);
+                    s.ck_sample_est = o.sample_est; s.ck_clock_est = o.clock_est; s.ck_sample_index = o.sample_index;
+                    s.need_clock_update = 0;
+                } else {
+                    if (u0 < n) { n = u0; completes = false; }
+                    u0 = 0xFFFFFFFFu;
+                }
+            }
+            const uint32_t a_eff = (u0 != 0xFFFFFFFFu && a1 < u0) ? a1 + 10u : a1;   // first anti-phase sample whose result outlives the update
+            auto predict_at = [&](uint32_t a) {   // ClockRecovery::update() :76-88 on the anti-phase sample at offset a
+                return (u0 != 0xFFFFFFFFu && a >= u0) ? clock_predict(s.ck_sample_est, s.ck_clock_est, a - u0 + 1u) : clock_predict(est_old, clk_old, cnt_old + a + 1u);
+            };
             int32_t S_moved = -1;
             for (uint32_t base = a1; base < n; base += 640u) {
                 const uint32_t a = base + 10u * wl;
-                const float v = core::clock_predict_arg(s.ck_sample_est, s.ck_clock_est, s.ck_count + a + 1u);
+                const bool post = u0 != 0xFFFFFFFFu && a >= u0;
+                const float v = core::clock_predict_arg(post ? (float)s.ck_sample_est : est_old, post ? (float)s.ck_clock_est : clk_old, post ? a - u0 + 1u : cnt_old + a + 1u);
                 bool bad = a < n && !core::clock_predict_equals(v, (int32_t)S);
                 if (__ballot(a < n && !core::clock_predict_near(v)))   // (an estimate far outside 0..10: the general form)
-                    bad = a < n && (uint32_t)(uint8_t)clock_predict(s.ck_sample_est, s.ck_clock_est, s.ck_count + a + 1u) != S;
+                    bad = a < n && (uint32_t)(uint8_t)predict_at(a) != S;
                 const unsigned long long mask = __ballot(bad);
                 if (mask != 0ull) {
                     const uint32_t af = base + 10u * (uint32_t)(__ffsll((long long)mask) - 1);
                     n = af + 1u;
                     completes = false;
-                    S_moved = clock_predict(s.ck_sample_est, s.ck_clock_est, s.ck_count + af + 1u);   // ClockRecovery::update() :76-88 on that sample
+                    S_moved = predict_at(af);
                     ++n_flip;
                     break;
                 }
@@ -752,7 +781,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 while (d + 1u < n) {   // an update point INSIDE the chunk: carrier on, trigger set (tail of operator() :742-752)
                     fold_to(min(m, d >= o1 ? (d - o1) / 10u + 1u : 0u));   // the symbols up to and including sample d
                     s.evm_S = Sv;
-                    if (a1 <= d) s.ck_sample_index = (int32_t)S;           // (the anti-phase updates up to here returned sample_index)
+                    if (a_eff <= d) s.ck_sample_index = (int32_t)S;        // (the anti-phase updates up to here returned sample_index)
                     s.count = 0;
                     fire_diag(t + d, sqrtf(Sv));
                     dcd_update_at(t + d);
@@ -766,7 +795,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 fold_to(m);
                 s.evm_S = Sv;
                 s.framer_idx += 2u * m;
-                if (a1 < n) s.ck_sample_index = (int32_t)S;   // the anti-phase updates of the chunk (if any) returned sample_index ...
+                if (a_eff < n) s.ck_sample_index = (int32_t)S;   // the anti-phase updates of the chunk (if any) returned sample_index ...
                 if (S_moved >= 0) { s.ck_sample_index = S_moved; s.sample_index = (uint32_t)(uint8_t)S_moved; }   // ... but for the last one, which moved it (:601-606)
                 const unsigned long long b2 = now();
                 tk_sym += b2 - b1;
@@ -787,7 +816,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                     s.run_pos = min(148, s.run_pos + (int32_t)n);
                 }
                 s.count = served ? n - 1u - d_last : s.count + n;
-                s.ck_count += n;
+                s.ck_count = u0 != 0xFFFFFFFFu ? n - u0 : cnt_old + n;
                 wave_lds_sync();
                 t += n;
                 te = t - 1u;
@@ -960,7 +989,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 if (s.st == ST_STREAM_SYNC) { const float v3 = corr(3); hit = beyond(3, v3) && v3 > 0.1f; }   // EOT :424
                 if ((uint32_t)wl >= nw) { trg = false; hit = false; }
             }
-            unsigned long long mask = __ballot(hit);
+            const unsigned long long hmask = __ballot(hit);
+            unsigned long long mask = hmask;
             const unsigned long long tmask = __ballot(trg);
             const uint32_t was_trig = s.sw_trig[wd];
             {   // + the first sample on which the trigger falls
@@ -992,11 +1022,54 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 t += f;
                 if (s.count == 960u) dcd_point_on(t - 1u);
                 ++n_bulk; n_bulk_samples += f;
-                tk_search += now() - b0;
-                continue;
             }
-            mode = BULK_NONE;  // the very next sample needs the single-sample path
+            // The sample on which the trigger falls (SyncWord::operator() :187-198: peak search over the stored samples) when it finds the
+            // word the state is looking for — the way every frame of a locked stream goes: here as well, and the SYNC_WAIT samples behind
+            // it (do_sync_wait :583-593) as a quiet chunk below.  A fall with the other polarity, an EOT hit, the count running out: the
+            // single-sample path.
+            bool fell = false, point = false;
+            if (fw < nw && !((hmask >> fw) & 1ull)) {
+                float peak = 0.f;
+                uint32_t timing = 0;
+                for (int j = 0; j < 10; ++j) {
+                    const float fj = swsm[wd * 10 + j];
+                    if (fabsf(fj) > fabsf(peak)) { peak = fj; timing = (uint32_t)j; }
+                }
+                const bool found = s.st == ST_PACKET_SYNC || !(peak > 0.f);   // updated() = peak > 0 ? 1 : -1; :440, :508, :553
+                if (found) {
+                    fell = true;
+                    ring[s.ring_pos] = ywin[t & (WV_WIN - 1)];   // Correlator::sample
+                    s.prev_pos = s.ring_pos;
+                    s.ring_pos = (s.ring_pos + 1u) % 80u;
+                    s.run_pos = min(148, s.run_pos + 1);
+                    s.count += 1u;
+                    s.ck_count += 1u;
+                    s.sync_count += 1;
+                    s.sw_trig[wd] = 0;
+                    s.sw_timing[wd] = timing;
+                    s.sw_updated[wd] = 0;
+                    s.missing_sync_count = 0;
+                    s.sync_word_type = s.st == ST_STREAM_SYNC ? 1u : (s.st == ST_PACKET_SYNC ? 2u : 3u);
+                    if (s.st == ST_STREAM_SYNC) s.eot_flag = 0;
+                    s.st = ST_SYNC_WAIT;
+                    wave_lds_sync();
+                    update_values(timing & 0xFFu);
+                    wave_lds_sync();
+                    t += 1u;
+                    ++n_bulk; n_bulk_samples += 1u;
+                    if (s.count == 960u) { dcd_point_on(t - 1u); point = true; }
+                }
+            }
             tk_search += now() - b0;
+            if (fell && !point && !(s.need_clock_reset | s.need_clock_update) && t < P.T) {
+                const uint32_t q = s.sync_count < 86 ? (uint32_t)(86 - s.sync_count) : 0u;
+                n = min(q + 1u, min(min(P.T - t, (uint32_t)WV_YCH), 960u - s.count));
+                completes = n == q + 1u;
+                mode = BULK_QUIET;   // (the generic chunk below)
+            } else {
+                if (f > 0u || fell) continue;
+                mode = BULK_NONE;  // the very next sample needs the single-sample path
+            }
         }
         if (mode == BULK_SEARCH) {
             // ---- UNLOCKED (do_unlocked :289-342) while no sync word is triggered: up to a whole chunk (480 samples) at once, 64 samples per
