@@ -1,16 +1,23 @@
 """Same-box A/B of library builds in the two-batch regime (bench.py's default: two independent batches launched and waited for together).
 Every build runs in its own process (M17HIP_LIB), the list is gone through `--rounds` times so that box drift shows.
     python tools/bisect_bench.py [--rounds 2] [--single] _exp/bis/libm17hip_d8d49ef.so m17-cxx-demod_amd/libm17hip.so ...
+M17_BISECT_TUNE=key=value[,key=value] applies m17hip_tune settings to every context of every build.
 --single adds the single-stream regime (two groups of 2048 channels, state carried, m17hip_demod_front) where the build has it."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def worker(single):
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     import torch
     sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import m17hip, oracle_lib as ol
     m17hip.Context._warned = True
+    tunes = [tuple(int(x) for x in kv.split('=')) for kv in os.environ.get('M17_BISECT_TUNE', '').split(',') if kv]
+    class Context(m17hip.Context):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            for key, val in tunes: self.tune(key, val)
+    m17hip.Context = Context
     C, T = 4096, 480000
     p = ol.gen_params(seed=20260101, kind=-1, n_frames=T // 1920 - 6, lead_in=3072, noise_sigma=600., tail_sigma=600., lead_sigma=40000.0, total=T)
     ctxs, streams = [], []
