@@ -315,6 +315,11 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  *        instructions in all: 1.4 % more throughput when several independent batches are in flight).
  * key 15: 1 (default) = the sequential kernel leaves the payload frames of running stream / BERT transmissions undecoded (LLRs to a
  *        store, the record reserved) and a lane-per-frame kernel decodes them after the run; 0 = every frame is decoded where it completes.
+ * key 17: 1 (default) = the running EVM of the diagnostic callback (RunningStandardDeviation: three dependent operations per payload symbol
+ *        that nothing in the demodulator reads) is folded OUTSIDE the sequential kernel: that kernel writes one 4-byte operation per symbol
+ *        (4 B x samples / 10 per channel of device memory), one lane per channel folds them in the reference's order as extra workgroups of
+ *        the limit-filter replay / the deferred decode, and m17_diag::evm and the diagnostic log carry the same values as with 0 = folded in
+ *        the sequential kernel, symbol by symbol.  Can be changed between runs.
  * key 16: 1 = m17hip_upload_i16, m17hip_upload_i16_device and m17hip_synth_i16 write the context's STAGING slab (as
  *        m17hip_upload_i16_async does, but complete when they return) and stage it for the next run; 0 (default) = the current slab.
  * key 30 (tests): fault injection for m17hip_gather_frames*: 1 = this rank's compaction fails inside the call, 2 = the root's staging

@@ -62,6 +62,8 @@ struct GateParams {
     uint64_t pos0;            // absolute index of sample 0 of this (segment of a) run
     uint64_t tick_row0;       // absolute tick stored in row 0 of the DCD table
     uint32_t flags;
+    uint32_t nblk;            // workgroups of the replay itself; the ones behind them fold deferred EVM operations (m17_state.hpp, evm_fold_pass)
+    EvParams ev;
 };
 
 constexpr int GT_LPC = 4;             // lanes per channel (cooperative loads / stores; the recurrence runs on the first of them)
@@ -375,6 +377,11 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state
 // (at most 128 VGPRs: a wave of it has to fit into what four K5 waves leave of a SIMD)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void limit_track_kernel(GateParams P)
 {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    if (blockIdx.x >= P.nblk) {   // (a launch that runs beside K5 takes an earlier segment's EVM operations along: 64 channels per block)
+        evm_fold_pass(P.ev, blockIdx.x - P.nblk, lds_dyn);
+        return;
+    }
     __builtin_amdgcn_s_setprio(3);  // K5 of the next segment waits for this kernel: issue ahead of whatever shares the SIMD
     const int lane = threadIdx.x;
     uint32_t c = blockIdx.x * GT_CPW + lane % GT_CPW;
@@ -386,7 +393,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     // (dynamic LDS, GT_LDS_FLOATS floats: with a static allocation the compiler sizes the register budget for the LDS-limited occupancy and
     //  ignores the waves-per-SIMD attribute above)
-    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     limit_track_pass(P, (P.flags & 2u) != 0, c, valid, P.chain_in != nullptr, P.only ? P.bnd : nullptr, lds_dyn);
 }
 

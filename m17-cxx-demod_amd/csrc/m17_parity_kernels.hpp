@@ -171,12 +171,17 @@ struct DeferParams {
     uint32_t diag_cap;
     const uint32_t* diag_count;   // [C]
     uint32_t C;
+    EvParams ev;                  // the run's deferred EVM (m17_state.hpp): folded by the blocks behind the first C of the launch (ops == nullptr: none)
 };
 constexpr int DEFER_HIST_WORDS = 101;                                   // 201 trellis steps (BERT), two per word
 constexpr int DEFER_LDS_BYTES = (46 + 8) * 64 * 4 + 4 * 488 * 2;        // LLR nibbles, output bytes, source maps: 17.7 KB
 __global__ __launch_bounds__(64) void decode_deferred_kernel(DeferParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (blockIdx.x >= P.C) {    // (a handful of blocks: the EVM fold runs beside the decode instead of in front of or behind it)
+        evm_fold_pass(P.ev, blockIdx.x - P.C, reinterpret_cast<float*>(lds));
+        return;
+    }
     DecodeLds L;
     L.llr = lds;                // [46][64] nibbles
     L.outb = lds + 46 * 64;     // [8][64]

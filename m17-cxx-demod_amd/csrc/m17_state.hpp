@@ -89,6 +89,7 @@ struct Cold {  // per-channel state touched a few times per frame (out-of-line h
     uint32_t seq;               // frame callbacks since reset
     uint32_t n_run;             // frame callbacks in the current run
     uint32_t n_diag_run;        // diagnostic callbacks in the current run (only counted while the diagnostic log is on)
+    uint32_t ev_cursor;         // deferred EVM: operations written to the channel's row of SeqParams::ev_ops since the run began
     Diag diag;
 };
 struct SeqState {
@@ -143,7 +144,119 @@ struct SeqParams {
     const core::Kalman2Gain* level_gain;   // [core::LEVEL_SCHED_N] gain schedule of the level filters under `kalman_order`
     Boundary* bnd_out;        // optional [C]: boundary records for the end of this segment (m17_gate_kernel.hpp reads them)
     uint32_t* defer;          // optional [C][rec_cap][46]: LLR frames (nibbles) whose decoding is deferred to decode_deferred_kernel (nullptr: none is)
+    float* ev_ops;            // optional [C][ev_pitch]: the running EVM is deferred to evm_fold_pass (below); nullptr: K5 folds it itself
+    uint32_t ev_pitch;
+    uint32_t* ev_cursor_out;  // [C] the channel's operation cursor at the end of this segment
 };
+
+// ---- the running EVM, deferred ------------------------------------------------------------------------------------------------------
+// RunningStandardDeviation<float,184>::capture (StandardDeviation.h:60-72; SymbolEvm.h:31-51) is S <- (S - S alpha) + err^2 alpha once per
+// payload symbol: three dependent instructions that nothing in the demodulator reads — the value goes into the diagnostic callback
+// (M17Demodulator.h:746-750) and nowhere else.  Folded inside K5 it is 550 of a frame's ~2600 instructions on a wave that carries ONE channel;
+// deferred, K5 writes the term of every symbol (and a mark where the callback wants the value / where evm.reset() falls) to the channel's
+// row of operations, and a kernel with one LANE per channel folds them in the reference's order — 64 channels per instruction — and
+// puts sqrt(S) where the marks say (the diagnostic log entry, the channel's m17_diag).  Operations: v >= 0 a term; EV_RESET evm.reset()
+// (:255); EV_EMIT the callback's value (no log entry); v <= -2: the callback's value, into log entry (-v) - 2.
+constexpr float EV_RESET = -1.0f, EV_EMIT = -1.5f, EV_NOP = -1.125f;   // (EV_NOP: inside the fold only)
+constexpr uint32_t EVM_PENDING = 0x7FC0E7A1u;   // m17_diag::evm until evm_deferred_kernel has been through the run (a quiet NaN)
+struct EvState { float S, last; uint32_t pos, pad; };   // per channel: RunningStandardDeviation::S, the last value a callback got (both carried from run to run), operations of the current run already folded
+__device__ __host__ inline uint32_t ev_row_floats(uint32_t T) { return (T / 10u + T / 960u + T / 384u + 64u + 3u) & ~3u; }   // terms + callbacks + resets of a run of T samples
+
+struct EvParams {
+    const float* ops;     // [C][pitch] (nullptr: nothing to fold)
+    uint32_t pitch;
+    EvState* es;          // [C]
+    Diag* diag_log;       // optional [C][diag_cap]
+    uint32_t diag_cap;
+    SeqState* state;      // cold.ev_cursor = operations of the run; cold.diag.evm = EVM_PENDING where the last callback waits for its value
+    uint32_t C;
+    const uint32_t* upto; // [C] fold the operations below this cursor (K5's at the end of a segment); nullptr: all of the run's, and settle m17_diag (the last pass of a run)
+};
+constexpr int EV_CPB = 16;                        // channels per workgroup (one wave) of a fold pass
+constexpr int EV_TILE_FLOATS = EV_CPB * 68;       // its LDS: 16 channels x 64 operations, rows of 68 words
+__host__ __device__ inline uint32_t ev_fold_blocks(uint32_t C) { return (C + EV_CPB - 1) / EV_CPB; }
+// One pass for the sixteen channels [16 blk, 16 blk + 16): the operations from where the previous pass stopped up to the cursor given.
+// Lane l < 16 folds channel 16 blk + l (sixteen lanes in one quarter of the wave: the dependent chain at its shortest, NOTES 4.12); all 64
+// lanes load — four lanes per row, 64 operations per row and tile — and the tile goes to the folding lanes through LDS, the next tile's
+// loads in flight meanwhile.  The passes of a run: segment k's operations as extra blocks of the limit-filter replay that runs beside K5
+// of segment k + 2 (m17_gate_kernel.hpp), the rest behind the last K5 beside the deferred decode (m17_parity_kernels.hpp) — nothing of it
+// on a stream of its own (NOTES 4.14) or in the chain of K5 launches.
+__device__ __forceinline__ void evm_fold_pass(const EvParams& E, uint32_t blk, float* tile)
+{
+    const uint32_t l = threadIdx.x & 63u, c0 = blk * EV_CPB;
+    const uint32_t c = c0 + l;                       // (l < 16) the channel this lane folds
+    const bool valid = l < (uint32_t)EV_CPB && c < E.C;
+    const uint32_t cc = min(c, E.C - 1u);
+    EvState e = E.es[cc];
+    const uint32_t from = valid ? min(e.pos, E.pitch) : 0u;
+    const uint32_t upto = valid ? min(E.upto ? E.upto[cc] : E.state[cc].cold.ev_cursor, E.pitch) : 0u;
+    const uint32_t n = upto > from ? upto - from : 0u;   // operations of this lane's row in this pass
+    uint32_t nmax = n;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, o));
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    // loading: lane l serves row l / 4, operations 4 i + l % 4 of the tile
+    const uint32_t lr = l >> 2, lq = l & 3u;
+    const float* lrow = E.ops + (size_t)min(c0 + lr, E.C - 1u) * E.pitch;
+    const uint32_t lfrom = (uint32_t)__shfl((int)from, (int)lr);
+    float v[16];
+    auto load_tile = [&](uint32_t k0) {
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) v[i] = lrow[min(lfrom + k0 + 4u * i + lq, E.pitch - 1u)];
+    };
+    auto lds_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    };
+    if (nmax) load_tile(0);
+    for (uint32_t k0 = 0; k0 < nmax; k0 += 64u) {
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) tile[lr * 68u + 4u * i + lq] = v[i];
+        lds_sync();
+        if (k0 + 64u < nmax) load_tile(k0 + 64u);
+        if (l < (uint32_t)EV_CPB) {
+            const uint32_t m = n > k0 ? min(64u, n - k0) : 0u;       // this row's operations in the tile; beyond them: no-ops
+            const uint32_t mmax = min(64u, nmax - k0);
+            const float4* t4 = reinterpret_cast<const float4*>(tile + l * 68u);
+            float4 cur = t4[0], nxt = t4[1];
+            for (uint32_t j0 = 0; j0 < mmax; j0 += 4u) {
+                const float4 g = cur;
+                cur = nxt;
+                nxt = t4[min(j0 / 4u + 2u, 15u)];
+                const float xs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x = j0 + i < m ? xs[i] : EV_NOP;
+                    const float w = (e.S - e.S * core::EVM_ALPHA) + x;
+                    if (__ballot(x < -1.25f) != 0ull && (x == EV_EMIT || x <= -2.f)) {   // (rare: a callback's value)
+                        e.last = sqrtf(e.S);
+                        if (x <= -2.f) {
+                            const uint32_t idx = (uint32_t)(-x) - 2u;
+                            if (E.diag_log && idx < E.diag_cap) E.diag_log[(size_t)cc * E.diag_cap + idx].evm = e.last;
+                        }
+                    }
+                    e.S = !(x < 0.f) ? w : (x == EV_RESET ? 0.f : e.S);   // a term (>= 0, or NaN: S is NaN from there on, as in the reference); evm.reset(); a mark / no-op
+                }
+            }
+        }
+        lds_sync();
+    }
+    if (valid) {
+        e.pos = E.upto ? upto : 0u;   // (the last pass of a run: the next run's operations start at 0)
+        E.es[c] = e;
+        if (!E.upto) {
+            uint32_t* w = reinterpret_cast<uint32_t*>(&E.state[c].cold.diag.evm);
+            if (*w == EVM_PENDING) *w = __float_as_uint(e.last);
+        }
+    }
+}
+// (on its own where the payload decode is not deferred; otherwise as the last blocks of decode_deferred_kernel's launch, m17_parity_kernels.hpp)
+__global__ __launch_bounds__(64) void evm_deferred_kernel(EvParams E)
+{
+    __shared__ float tile[EV_TILE_FLOATS];
+    evm_fold_pass(E, blockIdx.x, tile);
+}
 
 // LDS words for a wave of `ls` channels: ring, sync samples, llr, hist, outb, lsf columns; edges, src maps, lich map
 

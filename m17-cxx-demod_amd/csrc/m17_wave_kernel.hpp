@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     for (int k = wl; k < 8; k += 64) DL.lsf[k] = gs->lsf[k];
     wave_lds_sync();
     s.load(as_lds(hot_lds));
-    if (!(P.flags & 2u)) { cd->n_run = 0; cd->n_diag_run = 0; }  // (flag bit 1: a later segment of the same run keeps counting its records)
+    if (!(P.flags & 2u)) { cd->n_run = 0; cd->n_diag_run = 0; cd->ev_cursor = 0; }  // (flag bit 1: a later segment of the same run keeps counting its records)
     // Sample window: ybuf samples [t, avail) are in LDS; the next WV_PF samples are in flight in registers (pf) so that the
     // HBM/L2 latency of this channel's row is paid ~WV_PF samples ahead of its use instead of at the head of every step.
     float pf[WV_PF / 64];
@@ -427,6 +427,17 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     // carrier-on update point: tail of operator() (:742-752); te = relative index of the sample just processed
     // The diagnostic callback (M17Demodulator.h:681-685, 746-750): its arguments become the channel's m17_diag; with the
     // diagnostic log on, every invocation is also appended to the channel's log with the sample that fired it.
+    // The running EVM deferred (m17_state.hpp, evm_deferred_kernel): one operation appended to the channel's row
+    auto ev_op = [&](float v) {
+        const uint32_t cur = cd->ev_cursor;
+        if (cold_lane() == 0 && cur < P.ev_pitch) P.ev_ops[(size_t)c * P.ev_pitch + cur] = v;
+        cd->ev_cursor = cur + 1u;
+    };
+    // the mark of a carrier-on diagnostic callback: where evm_deferred_kernel puts the value (read BEFORE fire_diag counts the entry)
+    auto ev_mark = [&]() -> float {
+        const uint32_t nd = cd->n_diag_run;
+        return (P.diag_log && nd < P.diag_cap) ? -(float)(nd + 2u) : EV_EMIT;
+    };
     auto fire_diag = [&](uint32_t te, float evm_arg) {
         nf_fire_diag(cd, s.dcd_on, evm_arg, s.idev, s.offset, s.st != ST_UNLOCKED, s.ck_clock_est, s.sample_index,
                      s.sync_sample_index, s.ck_sample_index, s.viterbi_cost);
@@ -480,7 +491,8 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             nf_snapshot_hist(gs->hist, xr, te, cold_lane());
         }
         s.count = 0;
-        fire_diag(te, sqrtf(s.evm_S));
+        if (P.ev_ops) { ev_op(ev_mark()); fire_diag(te, __uint_as_float(EVM_PENDING)); }
+        else fire_diag(te, sqrtf(s.evm_S));
         dcd_update_at(te);
     };
 
@@ -565,7 +577,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                         for (int k = wl; k < 92; k += 64) DL.llr[k] = 0;  // framer.reset()
                         s.framer_idx = 0;
                         cd->dec_state = 0;                                 // decoder.reset()
-                        s.evm_S = 0.f;                                     // evm.reset()
+                        if (P.ev_ops) ev_op(EV_RESET); else s.evm_S = 0.f;  // evm.reset()
                         wave_lds_sync();
                     }
                     s.need_clock_reset = 1;
@@ -778,12 +790,21 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                 };
                 bool served = false;
                 uint32_t d_last = 0;
+                const bool evd = P.ev_ops != nullptr;   // the fold is evm_deferred_kernel's: the terms go to the channel's row, the callbacks leave marks
+                uint32_t nmk = 0, mk_k0 = 0, mk_k1 = 0;
+                float mk_v0 = 0.f, mk_v1 = 0.f;
                 while (d + 1u < n) {   // an update point INSIDE the chunk: carrier on, trigger set (tail of operator() :742-752)
-                    fold_to(min(m, d >= o1 ? (d - o1) / 10u + 1u : 0u));   // the symbols up to and including sample d
-                    s.evm_S = Sv;
+                    const uint32_t kend = min(m, d >= o1 ? (d - o1) / 10u + 1u : 0u);   // the symbols up to and including sample d
+                    if (evd) {
+                        if (nmk == 0) { mk_k0 = kend; mk_v0 = ev_mark(); } else { mk_k1 = kend; mk_v1 = ev_mark(); }
+                        ++nmk;
+                    } else {
+                        fold_to(kend);
+                        s.evm_S = Sv;
+                    }
                     if (a_eff <= d) s.ck_sample_index = (int32_t)S;        // (the anti-phase updates up to here returned sample_index)
                     s.count = 0;
-                    fire_diag(t + d, sqrtf(Sv));
+                    fire_diag(t + d, evd ? __uint_as_float(EVM_PENDING) : sqrtf(Sv));
                     dcd_update_at(t + d);
                     served = true; d_last = d;
                     d += 960u;
@@ -792,8 +813,24 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
                         m = (n > o1) ? (n - o1 + 9u) / 10u : 0u;   // (symbols sliced beyond it are sliced again when their turn comes)
                     }
                 }
-                fold_to(m);
-                s.evm_S = Sv;
+                if (evd) {
+                    const uint32_t cur = cd->ev_cursor, wls = (uint32_t)cold_lane();
+                    float* row = P.ev_ops + (size_t)c * P.ev_pitch;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const uint32_t k = wls + 64u * j;
+                        const uint32_t pos = cur + k + ((nmk > 0u && k >= mk_k0) ? 1u : 0u) + ((nmk > 1u && k >= mk_k1) ? 1u : 0u);
+                        if (k < m && pos < P.ev_pitch) row[pos] = ev[k];
+                    }
+                    if (wls == 0u) {
+                        if (nmk > 0u && cur + mk_k0 < P.ev_pitch) row[cur + mk_k0] = mk_v0;
+                        if (nmk > 1u && cur + mk_k1 + 1u < P.ev_pitch) row[cur + mk_k1 + 1u] = mk_v1;
+                    }
+                    cd->ev_cursor = cur + m + nmk;
+                } else {
+                    fold_to(m);
+                    s.evm_S = Sv;
+                }
                 s.framer_idx += 2u * m;
                 if (a_eff < n) s.ck_sample_index = (int32_t)S;   // the anti-phase updates of the chunk (if any) returned sample_index ...
                 if (S_moved >= 0) { s.ck_sample_index = S_moved; s.sample_index = (uint32_t)(uint8_t)S_moved; }   // ... but for the last one, which moved it (:601-606)
@@ -1292,8 +1329,11 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
             } else if (corr_index() == s.sample_index) {
                 float err;
                 const float sample = normalise(filtered, err);
-                s.evm_S = s.evm_S - s.evm_S * alpha;
-                s.evm_S = s.evm_S + (err * err) * alpha;
+                if (P.ev_ops) ev_op((err * err) * alpha);
+                else {
+                    s.evm_S = s.evm_S - s.evm_S * alpha;
+                    s.evm_S = s.evm_S + (err * err) * alpha;
+                }
                 llr16[s.framer_idx >> 1] = (uint16_t)slice_llr(sample, edges);  // llr<float,4> + M17Framer :42-53
                 s.framer_idx += 2;
                 if (s.framer_idx == 368u) {
@@ -1358,6 +1398,7 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     for (int k = wl; k < 92; k += 64) gs->llr[k] = DL.llr[k];
     for (int k = wl; k < 8; k += 64) gs->lsf[k] = DL.lsf[k];
     P.rec_count[c] = cd->n_run;
+    if (P.ev_cursor_out && wl == 0) P.ev_cursor_out[c] = cd->ev_cursor;
     if (P.diag_log && wl == 0) P.diag_count[c] = cd->n_diag_run;
     if constexpr (TIMED) if (wl == 0) {
         unsigned long long* slot = P.dbg + (size_t)c * DBG_SLOTS + ((P.flags >> 8) & 31u);

@@ -118,6 +118,12 @@ struct m17hip_ctx {
     uint32_t* defer_llr = nullptr;   // [maxC][rec_cap_alloc][46]: LLR frames (nibbles) K5 leaves for decode_deferred_kernel (tune 15)
     uint32_t* defer_hist = nullptr;  // [maxC][101][64]: that kernel's decision words
     bool defer_decode = true;
+    // the running EVM folded outside K5, one lane per channel (m17_state.hpp, evm_fold_pass; tune 17)
+    bool defer_evm = true;
+    float* ev_ops = nullptr;         // [maxC][ev_pitch] operations of the current run (lazily allocated)
+    uint32_t ev_pitch = 0;
+    uint32_t* ev_cur = nullptr;      // [2][maxC] K5's operation cursor at the end of a segment, by segment parity
+    EvState* ev_state = nullptr;     // [maxC]
     uint32_t seq_lds_bytes = 0; // tune 14: LDS bytes a workgroup of the sequential kernel asks for (0 = SEQ_LDS_BYTES_4 for four waves)
     float* llr_edges = nullptr;
     core::Kalman2Gain* level_gain = nullptr;   // [8 orders][LEVEL_SCHED_N] gain schedules of the level filters (core.h)
@@ -290,10 +296,19 @@ int ensure_scratch(m17hip_ctx* c, size_t bytes)
 }
 
 // ---- small device kernels owned by the host layer ----------------------------------------------------------------
-__global__ void seq_reset_kernel(SeqState* st, DcdState* ds, uint32_t C)
+// m17hip_tune key 17 changed: RunningStandardDeviation::S moves to where the new mode keeps it
+__global__ void ev_move_kernel(SeqState* st, EvState* es, uint32_t C, int to_deferred)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (to_deferred) { es[c].S = st[c].hot.evm_S; es[c].pos = 0; } else st[c].hot.evm_S = es[c].S;
+}
+
+__global__ void seq_reset_kernel(SeqState* st, DcdState* ds, EvState* es, uint32_t C)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    es[c] = EvState{1.0f, 0.f, 0u, 0u};   // RunningStandardDeviation::S{1.0}
     // zero-initialised object + the constructors' values
     uint32_t* w = reinterpret_cast<uint32_t*>(st + c);
     for (size_t k = 0; k < sizeof(SeqState) / 4; ++k) w[k] = 0;
@@ -637,6 +652,8 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->dcd_table, C * c->ticks_cap * 12 * sizeof(float));
     ALLOC(c->dcd_state, C * sizeof(DcdState));
     ALLOC(c->seq_state, C * sizeof(SeqState));
+    ALLOC(c->ev_state, C * sizeof(EvState));
+    ALLOC(c->ev_cur, 2 * C * sizeof(uint32_t));
     ALLOC(c->recs, C * c->rec_cap * sizeof(FrameRec));
     ALLOC(c->rec_count, C * sizeof(uint32_t));
     ALLOC(c->rec_offsets, (C + 1) * sizeof(uint64_t));
@@ -710,7 +727,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
             for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
                     c->overflow, c->tables, c->taps, c->llr_edges, c->level_gain, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist,
-                    c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->bnd};
+                    c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->bnd, c->ev_ops, c->ev_cur, c->ev_state};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete c;
@@ -1056,7 +1073,7 @@ int m17hip_demod_reset(m17hip_ctx* c)
         c->front_pending = false;
         c->gate0_queued = false;
     }
-    hipLaunchKernelGGL(seq_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->dcd_state, c->maxC);
+    hipLaunchKernelGGL(seq_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->dcd_state, c->ev_state, c->maxC);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(zero_prefix_kernel, dim3(c->maxC), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, c->maxC);
     HIPCHK(c, hipGetLastError());
@@ -1142,7 +1159,13 @@ static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStre
     G.only = redo ? c->dropped + (size_t)((k - 1u) & 1u) * c->maxC : nullptr;   // (flags by segment parity)
     G.bnd = redo ? c->bnd + (size_t)(k & 1u) * c->maxC : nullptr;   // (written by K5 of segment k - 1)
     G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags | ((redo && !redo_stores) ? 2u : 0u);
-    hipLaunchKernelGGL(limit_track_kernel, dim3((C + GT_CPW - 1) / GT_CPW), dim3(64), GT_LDS_FLOATS * sizeof(float), st, G);
+    G.nblk = (C + GT_CPW - 1) / GT_CPW;
+    uint32_t fold_blocks = 0;
+    if (ahead && k >= 2 && c->defer_evm && c->ev_ops) {   // (K5 of segment k - 2 is through: its EVM operations ride along, sixteen channels per block)
+        G.ev = EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, C, c->ev_cur + (size_t)((k - 2u) & 1u) * c->maxC};
+        fold_blocks = ev_fold_blocks(C);
+    }
+    hipLaunchKernelGGL(limit_track_kernel, dim3(G.nblk + fold_blocks), dim3(64), GT_LDS_FLOATS * sizeof(float), st, G);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
@@ -1277,6 +1300,10 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipMalloc((void**)&c->defer_llr, (size_t)c->maxC * c->rec_cap_alloc * 46 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void**)&c->defer_hist, (size_t)c->maxC * DEFER_HIST_WORDS * 64 * sizeof(uint32_t)));
     }
+    if (c->defer_evm && !c->ev_ops) {   // the operation rows of the deferred EVM: 4 B per symbol of the longest run
+        c->ev_pitch = ev_row_floats(c->maxT);
+        HIPCHK(c, hipMalloc((void**)&c->ev_ops, (size_t)c->maxC * c->ev_pitch * sizeof(float)));
+    }
     c->dbg_waves = (c->profile || c->wave_times) ? C : 0;
     // K2 launches: the whole first segment from K5's state; every later segment AHEAD of K5 from the replay's own end state (replay
     // stream); and the REDO: for the channels that left the replay in segment k - 1 (a forced dcd.unlock()), the replay's state at the
@@ -1324,6 +1351,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         P.level_gain = c->level_gain + (size_t)(c->kalman_order & 7u) * core::LEVEL_SCHED_N;
         P.diag_log = c->diag_cap ? c->diag_log : nullptr; P.diag_cap = c->diag_cap; P.diag_count = c->diag_count;
         P.defer = c->defer_decode ? c->defer_llr : nullptr;
+        if (c->defer_evm) { P.ev_ops = c->ev_ops; P.ev_pitch = c->ev_pitch; P.ev_cursor_out = c->ev_cur + (size_t)(k & 1u) * c->maxC; }
         P.bnd_out = c->bnd + (size_t)((k + 1u) & 1u) * c->maxC;
         P.dbg = (c->profile || c->wave_times) ? c->dbg : nullptr;
         return P;
@@ -1388,8 +1416,13 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         DeferParams D{};
         D.recs = c->recs; D.rec_cap = c->rec_cap; D.rec_count = c->rec_count; D.defer = c->defer_llr; D.hist = c->defer_hist; D.tables = c->tables;
         D.state = c->seq_state; D.diag_log = c->diag_cap ? c->diag_log : nullptr; D.diag_cap = c->diag_cap; D.diag_count = c->diag_count; D.C = C;
+        D.ev = EvParams{c->defer_evm ? c->ev_ops : nullptr, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, C, nullptr};
         Timed tm(c, KT_DEC);
-        hipLaunchKernelGGL(decode_deferred_kernel, dim3(C), dim3(64), DEFER_LDS_BYTES, c->stream, D);
+        hipLaunchKernelGGL(decode_deferred_kernel, dim3(C + (c->defer_evm ? ev_fold_blocks(C) : 0u)), dim3(64), DEFER_LDS_BYTES, c->stream, D);   // (+ the rest of the run's EVM fold)
+        HIPCHK(c, hipGetLastError());
+    } else if (c->defer_evm) {
+        hipLaunchKernelGGL(evm_deferred_kernel, dim3(ev_fold_blocks(C)), dim3(64), 0, c->stream,
+                           EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, C, nullptr});
         HIPCHK(c, hipGetLastError());
     }
     if (c->bert)   // payload consumer: PRBS9 statistics over this run's BERT records
@@ -1861,6 +1894,15 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 20:  // redo policy of the limit-filter replay: 0 (default) = beside K5, state only; 1 = in front of K5, history stored
         if (value < 0 || value > 1) return M17HIP_EINVAL;
         c->redo_form = (int)value;
+        return M17HIP_OK;
+    case 17:  // RunningStandardDeviation (the EVM of the diagnostic callback) folded outside K5, one lane per channel (1, default), or inside K5 (0)
+        if ((value != 0) != c->defer_evm) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->defer_evm = value != 0;
+            hipLaunchKernelGGL(ev_move_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->ev_state, c->maxC, c->defer_evm ? 1 : 0);
+            HIPCHK(c, hipGetLastError());
+            if (!c->defer_evm && c->ev_ops) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->ev_ops); c->ev_ops = nullptr; }
+        }
         return M17HIP_OK;
     case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1, default), or in K5 (0)
         c->defer_decode = value != 0;

@@ -23,7 +23,7 @@ def _oracle_records(x, invert=0):
     return flat, counts, diags
 
 
-@pytest.fixture(scope="module", params=[(1, -1, 0), (0, -1, 0), (1, 1, 1)], ids=["default", "decode_in_k5", "k3_latency_form_redo_in_front"])
+@pytest.fixture(scope="module", params=[(1, -1, 0, 1), (0, -1, 0, 0), (1, 1, 1, 1)], ids=["default", "decode_and_evm_in_k5", "k3_latency_form_redo_in_front"])
 def ctx(request):
     """Every test runs three times: with the payload frames of running transmissions decoded after the run, one lane per frame (the default),
     with every frame decoded by the sequential kernel's wave where it completes (m17hip_tune key 15 = 0), and with the carrier-detect
@@ -32,6 +32,7 @@ def ctx(request):
     c.tune(15, request.param[0])
     c.tune(10, request.param[1])
     c.tune(20, request.param[2])   # the replay's redo beside K5 (default) / in front of it with the history stored
+    c.tune(17, request.param[3])   # the running EVM folded outside K5 (default) / inside it
     yield c
     c.close()
 

@@ -32,7 +32,7 @@ def _sorted(parts):
     return got[np.lexsort((got["seq"], got["channel"]))]
 
 
-@pytest.fixture(scope="module", params=[{}, {15: 0}, {3: 7001}, {3: 9600, 15: 0}, {10: 0, 20: 1}], ids=["default", "decode_in_k5", "seg7001", "seg9600_decode_in_k5", "k3_throughput_form_redo_in_front"])
+@pytest.fixture(scope="module", params=[{}, {15: 0, 17: 0}, {3: 7001}, {3: 9600, 15: 0}, {10: 0, 20: 1, 17: 0}], ids=["default", "decode_and_evm_in_k5", "seg7001", "seg9600_decode_in_k5", "k3_throughput_form_redo_in_front_evm_in_k5"])
 def ctx(request):
     c = m17hip.Context(64, 48000)
     for k, v in request.param.items():
@@ -269,3 +269,19 @@ def test_pipelined_full_size_run_properties():
     got = _sorted(parts)
     assert got[got["channel"] < 8].tobytes() == exp.tobytes()
     a.close(); b.close()
+
+
+def test_the_evm_fold_can_move_between_runs_of_a_stream():
+    """m17hip_tune key 17 between the runs of one stream: RunningStandardDeviation's state moves with the mode (deferred fold <-> inside
+    the sequential kernel), the channels' m17_diag (evm included) ends up as the oracle's over the whole stream."""
+    Cn, T, n = 64, 24000, 6
+    x = _signals(Cn, n * T, seed=131, sigma=700.0)
+    exp, diags = _oracle(x)
+    c = m17hip.Context(Cn, T)
+    parts = []
+    for k, mode in enumerate((1, 0, 0, 1, 1, 0)):
+        c.tune(17, mode)
+        c.upload(x[:, k * T:(k + 1) * T]); c.run(); parts.append(c.frames().copy())
+    assert _sorted(parts).tobytes() == exp.tobytes()
+    _check_diag(c, Cn, diags)
+    c.close()

@@ -32,10 +32,10 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     recs, counts, diags = ol.demod_batch(x, invert=inv, cap=2 * (T // 1920 + 2) + 4, threads=os.cpu_count())
     cuts = sorted(int(v) for v in rng.integers(1, T, size=2))
     rseg = int(rng.integers(3000, 30000))
-    # (payload frames decoded after the run [m17hip_tune 15], segment length, run boundaries, staged + m17hip_demod_front)
+    # (payload frames decoded after the run [m17hip_tune 15], segment length, run boundaries, staged + m17hip_demod_front; the redo policy [20] and the EVM fold's place [17] alternate)
     for spec, seg, pieces, piped in ((1, 19200, None, 0), (1, rseg, None, 0), (0, rseg, None, 0), (1, 0, None, 0), (1, 19200, [0] + cuts + [T], 0),
                                      (1, 19200, [0] + cuts + [T], 1), (0, rseg, [0] + cuts + [T], 1), (1, 4800, [0] + cuts + [T], 1)):
-        ctx.tune(15, spec); ctx.tune(3, seg); ctx.tune(20, (seed + spec + piped) & 1); ctx.reset()
+        ctx.tune(15, spec); ctx.tune(3, seg); ctx.tune(20, (seed + spec + piped) & 1); ctx.tune(17, (seed + piped + (seg & 1)) & 1); ctx.reset()
         if pieces is None:
             ctx.upload(x); ctx.run(flags=inv); got = ctx.frames()
         elif not piped:   # the same stream as three runs (state, filter history and DCD sums carried between them)
