@@ -6,12 +6,13 @@ segments (a short first one, then equal ones), so a launch covers channels x sam
 Usage: make_traffic.py <dir with fetch_summary.md, write_summary.md> <channels> <samples> <launches per step> <out.json>"""
 import json, re, sys
 d, C, T, lps, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-def val(path, kern, ctr):
+def val(path, kerns, ctr):
     for l in open(path):
-        if l.startswith('- ') and kern in l:
+        if l.startswith('- ') and any(k in l for k in kerns):
             return float(re.search(ctr + r'=([0-9.e+]+)', l).group(1))
     return None
-K = {'fir_rrc150': 'fir_rrc150_', 'dcd': 'dcd_kernel', 'limit_track': 'limit_track_kernel', 'demod_seq': 'demod_wave_kernel'}
+# (the carrier-detect kernel in whichever form the profiled regime ran: one wave per 32 channels, or the four-wave latency form)
+K = {'fir_rrc150': ('fir_rrc150_',), 'dcd': ('dcd_kernel', 'dcd_pipe_kernel'), 'limit_track': ('limit_track_kernel',), 'demod_seq': ('demod_wave_kernel',)}
 j = {'channels': C, 'samples': T, 'launches_per_step': lps,
      'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh); per-dispatch averages in KB; '
                'FETCH_SIZE doubled per MI355X_MICROARCH.md; limit_track averages include the near-empty redo launches', 'kernels': {}}
