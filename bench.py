@@ -130,8 +130,6 @@ def main():
         if F > 1 and "20" not in tuned:   # several independent batches in flight: the replay's redo in front of K5 (include/m17hip.h, m17hip_tune key 20:
             c_.tune(20, 1)                #  fewer instructions at the price of latency on a chain that has slack in this regime; +1.4 %)
             policy20 = 1
-        if F == 1 and "10" not in tuned:  # one batch at a time: nothing else fills the chip while the carrier-detect kernel's chain runs — its latency form
-            c_.tune(10, 1)                #  (include/m17hip.h, m17hip_tune key 10; the library's default picks it only for runs queued by m17hip_demod_front)
         if F > 1:
             streams.append(torch.cuda.Stream(device=dev))
             c_.set_stream(streams[-1].cuda_stream)
@@ -415,8 +413,7 @@ def main():
     if args.one_at_a_time:
         if policy20 is not None:
             ctx.tune(20, 0)   # one batch at a time: the default policy (the chain of K5 launches is what this regime lasts)
-        if "10" not in tuned:
-            ctx.tune(10, 1)   # ... and the carrier-detect kernel in its latency form: with nothing else in flight its ten-launch chain is what a step waits for (29.3 -> 25.7 ms)
+        ctx.reset(); ctx.run(); ctx.frames_count()   # (untimed: the library picks the carrier-detect kernel's form from whether runs overlapped lately — the legs before this one did)
         ctx.reset()
         ctx.timing(True); ctx.timing_reset()
         torch.cuda.synchronize()
@@ -427,8 +424,6 @@ def main():
         seq_ms = (time.perf_counter() - ts) / args.one_at_a_time_steps * 1e3
         seq_kern = kernel_times([ctx], KNAMES[:4], args.one_at_a_time_steps)
         ctx.timing(False)
-        if "10" not in tuned:
-            ctx.tune(10, 1 if F == 1 else -1)
 
     if rank != 0:
         for m_ in comms:
@@ -543,8 +538,7 @@ def main():
                    "parallelism": f"channels sharded contiguously over {world} GPU(s), global channel ids", "gather": gather_kind,
                    "steps_in_flight": F, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "hw_queue_advice": int(ctx.lib.m17hip_advice(ctx.h)), "prewarm_steps": args.prewarm, "batches": "pipelined" if args.stagger else "launched and waited for in groups",
                    "gathered_set_ordered_and_unique": gathered_ok, "tune": tuned or None,
-                   "redo_policy_two_batch_regime": ("m17hip_tune key 20 = 1 (redo in front of K5: throughput policy for batches in flight)" if policy20 else "default"),
-                   "dcd_form_one_batch_at_a_time": (None if "10" in tuned else "m17hip_tune key 10 = 1 (latency form of the carrier-detect kernel) for the one-at-a-time pass the roofline object comes from" + (" and the timed region" if F == 1 else "")),},
+                   "redo_policy_two_batch_regime": ("m17hip_tune key 20 = 1 (redo in front of K5: throughput policy for batches in flight)" if policy20 else "default"),},
         "single_stream": single,
         "value_with_h2d": h2d["value_with_h2d"] if h2d else None, "h2d": h2d,
         "roofline": roofline, "cpu_baseline": cpu, "config2": config2,

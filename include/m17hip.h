@@ -307,7 +307,9 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * key 9: diagnostic log, value = diagnostic callbacks of room per channel and run (m17hip_diag_log_fetch; default 0 = off).
  * key 10: form of the carrier-detect kernel K3: 0 = one wave per 32 channels (least wave slots: batch throughput), 1 = four-wave pipeline per
  *        32 channels (1.8x shorter chain, four times the wave slots: stream latency), -1 (default) = the pipeline for runs whose front end
- *        was queued by m17hip_demod_front (a continued stream waits for K3's chain), the one-wave form otherwise.  Same table either way.
+ *        was queued by m17hip_demod_front (a continued stream waits for K3's chain) and for runs of a process that has not overlapped runs
+ *        of different contexts on this device lately (one batch at a time: 29 -> 26 ms per 4096 x 480 000), the one-wave form while it does.
+ *        Same table either way.
  * key 20: what happens after a forced dcd.unlock() took a channel off the limit-filter replay: 0 (default) = the replay's state is re-derived
  *        beside the sequential kernel and the channel computes its own filter history through the next segment (the sequential kernel never
  *        waits: best wherever its chain of launches is what a step lasts — a continued stream, one batch at a time); 1 = the replay of the next

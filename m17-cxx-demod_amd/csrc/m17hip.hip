@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -102,6 +103,8 @@ struct m17hip_ctx {
     int redo_form = 0;                // tuning knob 20: the replay's redo beside K5, state only (0, default), or in front of K5 with the history stored (1)
     int dcd_form = -1;                // tuning knob 10: K3 as one wave per 32 channels (0), as the four-wave latency pipeline (1), or chosen per run (-1: the pipeline for runs queued by m17hip_demod_front)
     bool dcd_latency = false;         // what the launches of the run being queued use
+    uint64_t seen_overlap = 0;        // (run registry below) the overlap count this context's previous run saw
+    hipEvent_t last_end = nullptr;    // ev_end of the run queued last
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     uint32_t seg0_len = 0;            // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others; measured neutral)
     float* dcd_table = nullptr;
@@ -274,6 +277,27 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
 };
 #define GUARD(ctx) DeviceGuard guard_(ctx); if (!guard_.ok) return M17HIP_EHIP
+
+// ---- is this context the only one with a run in flight? ------------------------------------------------------------------------------
+// The form of the carrier-detect kernel (m17hip_tune key 10 = -1) depends on it: with nothing else in flight on the device a step waits for
+// that kernel's ten-launch chain and the four-wave latency form is 12 % faster; with other batches in flight the one-wave form is (the chip is
+// full, the extra wave slots cost more than the chain saves).  A context cannot see the caller's intentions, only what happened: a run that is
+// queued while another context's latest run has not finished counts as an overlap, and a context whose previous run was followed by one
+// (its own launch or somebody's since) takes the process for one that overlaps batches.
+struct RunRegistry { std::mutex mu; std::vector<m17hip_ctx*> ctxs; uint64_t overlaps = 0; };
+RunRegistry g_runs;
+bool runs_overlap(m17hip_ctx* c)   // at the launch of a run of c
+{
+    std::lock_guard<std::mutex> lk(g_runs.mu);
+    bool other = false;
+    for (m17hip_ctx* o : g_runs.ctxs)
+        if (o != c && o->device == c->device && o->last_end && hipEventQuery(o->last_end) == hipErrorNotReady) other = true;
+    (void)hipGetLastError();
+    if (other) ++g_runs.overlaps;
+    const bool overlapped = other || g_runs.overlaps != c->seen_overlap;
+    c->seen_overlap = g_runs.overlaps;
+    return overlapped;
+}
 void drain_timing(m17hip_ctx* c)
 {
     for (auto& t : c->pending) {
@@ -702,6 +726,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     if (hipFuncSetAttribute((const void*)decode_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (92 + 122 + 16) * 64 * 4) != hipSuccess)
         return fail(M17HIP_EHIP);
     if (hipMemset(c->overflow, 0, 16) != hipSuccess) return fail(M17HIP_EHIP);
+    { std::lock_guard<std::mutex> lk(g_runs.mu); c->seen_overlap = g_runs.overlaps; g_runs.ctxs.push_back(c); }   // (a new context has seen no overlap yet)
     *out = c;
     const int r = m17hip_demod_reset(c);
     if (r != M17HIP_OK) { *out = nullptr; return fail(r); }
@@ -711,6 +736,11 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
 void m17hip_ctx_destroy(m17hip_ctx* c)
 {
     if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(g_runs.mu);
+        for (size_t i = 0; i < g_runs.ctxs.size(); ++i)
+            if (g_runs.ctxs[i] == c) { g_runs.ctxs.erase(g_runs.ctxs.begin() + (long)i); break; }
+    }
     DeviceGuard guard_(c);
     drain_timing(c);
     for (auto e : c->pool) hipEventDestroy(e);
@@ -1209,7 +1239,7 @@ static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, b
     int r = ensure_seg_events(c, c->slot, sp.nseg);
     if (r) return r;
     const uint32_t ahead = c->front_ahead ? c->front_ahead : sp.nseg;
-    c->dcd_latency = c->dcd_form < 0 ? from_front : c->dcd_form == 1;
+    c->dcd_latency = c->dcd_form < 0 ? (from_front || !runs_overlap(c)) : c->dcd_form == 1;
     c->front_segs = std::min(ahead, sp.nseg);
     for (uint32_t k = 0; k < c->front_segs; ++k)
         if ((r = launch_front_seg(c, sp, k, C, flags))) return r;
@@ -1291,7 +1321,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
         HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork, 0));
-        c->dcd_latency = c->dcd_form == 1;
+        c->dcd_latency = c->dcd_form < 0 ? !runs_overlap(c) : c->dcd_form == 1;
         c->front_segs = std::min(ahead, nseg);
         for (uint32_t k = 0; k < c->front_segs; ++k)
             if ((r = launch_front_seg(c, sp, k, C, flags))) return r;
@@ -1433,6 +1463,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
                            (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count, c->channel_base);
     }
     HIPCHK(c, hipEventRecord(c->ev_end[q], c->stream));
+    c->last_end = c->ev_end[q];
     c->slot_used[q] = true;
     c->pos += T;
     c->inplace_after_run = false;
