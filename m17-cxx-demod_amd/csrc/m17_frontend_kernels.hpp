@@ -586,37 +586,40 @@ __global__ __launch_bounds__(256) void dcd_pipe_kernel(const int16_t* __restrict
 // The correlator's limit filter for the per-operator entry point (m17hip_correlator, BASELINE config 2) as a pipeline of roles,
 // (the pattern of round 2's K3 pipeline, NOTES.md): limit_kernel above runs one LANE per channel with 4-byte loads 64 rows apart (uncoalesced)
 // and carries output arithmetic and stores on the wave that carries the recurrence — 70 ms for 1024 x 480 000 samples.  Here a
-// workgroup = 64 channels x tiles of 64 samples, five waves:
-//   P0, P1  16-byte coalesced loads of the matched-filter rows (32 rows each), three tiles in flight        -> ytile[2][64][68]
-//   R       h0 = |y| - a1 h1 - a2 h2 for its lane's channel, nothing else (the dependent chain)             -> htile[2][64][4 + 68]
-//   O0, O1  limit = b0 h0 + b1 h1 + b2 h2 from the trajectory, time-parallel, 16-byte coalesced stores (32 rows each)
-// Bit-identical to limit_kernel (same core:: functions).  Preconditions (else the host launches limit_kernel): T a multiple of 64.
+// workgroup = SIXTEEN channels x tiles of 256 samples, five waves:
+//   P0, P1  16-byte coalesced loads of the matched-filter rows (a whole 1 KB row segment per instruction, 8 rows each), three tiles in flight -> ytile[2][16][260]
+//   R       h0 = |y| - a1 h1 - a2 h2 for its lane's channel, nothing else (the dependent chain), on lanes 0..15: ONE quarter of the
+//           wave, where the chain with a packed multiply is at its shortest (7.3 ns per sample against 12.3 on 64 lanes, NOTES 4.12); the
+//           reads run two blocks of four ahead, the multiply takes h from the register pair the outputs are collected in   -> htile[2][16][4 + 260]
+//   O0, O1  limit = b0 h0 + b1 h1 + b2 h2 from the trajectory, time-parallel, 16-byte coalesced stores (8 rows each)
+// (Round 3's form had 64 channels per workgroup, the recurrence on 64 lanes: 17.6 ns per sample, 8.5 ms for 480 000.)
+// Bit-identical to limit_kernel (same IEEE products and sums).  Preconditions (else the host launches limit_kernel): T a multiple of 256.
 // =====================================================================================================
-constexpr int LP_TILE = 64;
-constexpr int LP_YP = LP_TILE + 4;        // ytile row pitch (floats): 16-byte rows, conflict-free 16-byte column reads
+constexpr int LP_CH = 16;                 // channels per workgroup
+constexpr int LP_TILE = 256;
+constexpr int LP_YP = LP_TILE + 4;        // ytile row pitch (floats): sixteen rows start in sixteen different bank groups
 constexpr int LP_HP = 4 + LP_TILE + 4;    // htile row pitch: 4 floats of the previous tile in front
 constexpr int LP_PF = 3;
 
 __global__ __launch_bounds__(320, 1) void limit_pipe_kernel(const float* __restrict__ y, size_t ypitch, float* __restrict__ limit, uint32_t C, uint32_t T)
 {
-    __shared__ __attribute__((aligned(16))) float ytile[2][64][LP_YP];
-    __shared__ __attribute__((aligned(16))) float htile[2][64][LP_HP];
+    __shared__ __attribute__((aligned(16))) float ytile[2][LP_CH][LP_YP];
+    __shared__ __attribute__((aligned(16))) float htile[2][LP_CH][LP_HP];
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0, 1 = P0, P1; 2 = R; 3, 4 = O0, O1
     const int lane = threadIdx.x & 63;
-    const uint32_t c0 = blockIdx.x * 64u;
+    const uint32_t c0 = blockIdx.x * (uint32_t)LP_CH;
     const uint32_t NT = T / LP_TILE;
     const uint32_t NI = (NT + 2u + LP_PF - 1u) / LP_PF * LP_PF;
     auto row_of = [&](uint32_t r) -> uint32_t { return min(c0 + r, C - 1u); };   // rows beyond the last channel shadow it
+    typedef float v4f __attribute__((ext_vector_type(4)));
     if (role <= 1) {
-        // lane = (row within a group of 4, float4 column): 16 lanes x 16 bytes = one 256-byte row segment
-        const uint32_t rsub = (uint32_t)lane >> 4, col = (uint32_t)lane & 15u;
+        // lane = float4 column of the tile: 64 lanes x 16 bytes = the whole 1 KB row segment; eight rows per producer
         // three tiles in flight.  (Native vector type on purpose: an array of eight HIP float4 STRUCTS is not promoted to
         // registers by this compiler and lands in scratch memory.)
-        typedef float v4f __attribute__((ext_vector_type(4)));
         v4f pf[LP_PF][8];
         const float* ybase[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) ybase[q] = y + (size_t)row_of(32u * (uint32_t)role + 4u * (uint32_t)q + rsub) * ypitch + YPRE + 4u * col;
+        for (int q = 0; q < 8; ++q) ybase[q] = y + (size_t)row_of(8u * (uint32_t)role + (uint32_t)q) * ypitch + YPRE + 4u * (uint32_t)lane;
         auto issue = [&](uint32_t tile, int slot) {
             const uint32_t t0 = min(tile, NT - 1u) * LP_TILE;
 #pragma unroll
@@ -635,45 +638,55 @@ __global__ __launch_bounds__(320, 1) void limit_pipe_kernel(const float* __restr
                 if (i < NT) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
-                        *reinterpret_cast<v4f*>(&ytile[i & 1u][32u * (uint32_t)role + 4u * (uint32_t)q + rsub][4u * col]) = v[q];
+                        *reinterpret_cast<v4f*>(&ytile[i & 1u][8u * (uint32_t)role + (uint32_t)q][4u * (uint32_t)lane]) = v[q];
                 }
                 dp_handover();
             }
         }
     } else if (role == 2) {
-        float h1 = 0.f, h2 = 0.f;            // the filter starts from zero history
-        float4 tail = make_float4(0.f, 0.f, 0.f, 0.f);
+        // the filter starts from zero history; p1 = (h[-2], h[-1]), m2 = a2 h[-2]: the pair the newest outputs sit in (see nf_serve_limit, m17_wave_kernel.hpp)
+        iir_v2f p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
+        float m2 = 0.f;
+        const iir_v2f coef = {IirCoef::a1, IirCoef::a2};
+        auto lo = [&](iir_v2f p) { iir_v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(p), "s"(coef)); return r; };
+        auto hi = [&](iir_v2f p) { iir_v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(p), "s"(coef)); return r; };
+        auto four = [&](const v4f v) {   // h0 = (|y| - a1 h1) - a2 h2, the two products of a history value from one packed multiply
+            iir_v2f r;
+            r = hi(p1); p0.x = (fabsf(v.x) - r.x) - m2; m2 = r.y;
+            r = lo(p0); p0.y = (fabsf(v.y) - r.x) - m2; m2 = r.y;
+            r = hi(p0); p1.x = (fabsf(v.z) - r.x) - m2; m2 = r.y;
+            r = lo(p1); p1.y = (fabsf(v.w) - r.x) - m2; m2 = r.y;
+            return v4f{p0.x, p0.y, p1.x, p1.y};
+        };
+        v4f tail = {0.f, 0.f, 0.f, 0.f};
         for (uint32_t i = 0; i < NI; ++i) {
-            if (i >= 1u && i <= NT) {
+            if (i >= 1u && i <= NT && lane < LP_CH) {
                 const uint32_t b = (i - 1u) & 1u;
-                const float* yrow = &ytile[b][lane][0];
-                float* hrow = &htile[b][lane][0];
-                *reinterpret_cast<float4*>(hrow) = tail;   // the last four values of the previous tile, for the output stage
-                float m2 = IirCoef::a2 * h2;
-#pragma unroll
-                for (int q = 0; q < LP_TILE / 4; ++q) {
-                    const float4 v = *reinterpret_cast<const float4*>(yrow + 4 * q);
-                    float4 o;
-                    // h0 = |y| - a1*h1 - a2*h2: m2 = a2*h2 is formed one sample ahead, off the dependent chain
-                    o.x = (fabsf(v.x) - IirCoef::a1 * h1) - m2; m2 = IirCoef::a2 * h1; h1 = o.x;
-                    o.y = (fabsf(v.y) - IirCoef::a1 * h1) - m2; m2 = IirCoef::a2 * h1; h1 = o.y;
-                    o.z = (fabsf(v.z) - IirCoef::a1 * h1) - m2; m2 = IirCoef::a2 * h1; h1 = o.z;
-                    o.w = (fabsf(v.w) - IirCoef::a1 * h1) - m2; m2 = IirCoef::a2 * h1; h1 = o.w;
-                    *reinterpret_cast<float4*>(hrow + 4 + 4 * q) = o;
-                    tail = o;
+                const v4f* yrow = reinterpret_cast<const v4f*>(&ytile[b][lane][0]);
+                v4f* hrow = reinterpret_cast<v4f*>(&htile[b][lane][0]);
+                hrow[0] = tail;   // the last four values of the previous tile, for the output stage
+                v4f c0v = yrow[0], c1v = yrow[1];
+#pragma unroll 4
+                for (int q = 0; q < LP_TILE / 4; q += 2) {
+                    const v4f v0 = c0v, v1 = c1v;
+                    c0v = yrow[min(q + 2, LP_TILE / 4 - 2)];
+                    c1v = yrow[min(q + 3, LP_TILE / 4 - 1)];
+                    __builtin_amdgcn_sched_barrier(0);
+                    hrow[1 + q] = four(v0);
+                    tail = four(v1);
+                    hrow[2 + q] = tail;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                h2 = tail.z;   // (h1 = tail.w is current; h2 is re-derived for the next tile's first m2)
             }
             dp_handover();
         }
     } else {
-        const uint32_t rsub = (uint32_t)lane >> 4, col = (uint32_t)lane & 15u;
         for (uint32_t i = 0; i < NI; ++i) {
             if (i >= 2u && i < NT + 2u) {
-                const uint32_t tile = i - 2u, b = tile & 1u;
+                const uint32_t tile = i - 2u, b = tile & 1u, col = (uint32_t)lane;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const uint32_t r = 32u * (uint32_t)(role - 3) + 4u * (uint32_t)q + rsub;
+                    const uint32_t r = 8u * (uint32_t)(role - 3) + (uint32_t)q;
                     const float* hrow = &htile[b][r][0];
                     const float4 p = *reinterpret_cast<const float4*>(hrow + 4u * col);        // h[k0-4 .. k0-1]
                     const float4 h = *reinterpret_cast<const float4*>(hrow + 4u + 4u * col);   // h[k0 .. k0+3]

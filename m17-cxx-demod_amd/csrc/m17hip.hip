@@ -973,7 +973,7 @@ int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, 
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
         if (T % LP_TILE == 0 && T >= 4 * LP_TILE && (((size_t)C * T) & 3) == 0)
-            hipLaunchKernelGGL(limit_pipe_kernel, dim3((C + 63) / 64), dim3(320), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
+            hipLaunchKernelGGL(limit_pipe_kernel, dim3((C + LP_CH - 1) / LP_CH), dim3(320), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
         else
             hipLaunchKernelGGL(limit_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
         HIPCHK(c, hipGetLastError());
