@@ -9,6 +9,7 @@ frame records to rank 0 (m17hip_gather_frames_device; the torch all_gather of m1
 be had).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8                       # starts its 8 ranks itself (one process per GPU, 127.0.0.1 rendezvous); --dry-launch shows them
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
     python bench.py --config 2        # BASELINE configs[1]: 1024 channels, FIR + correlator outputs materialised (26 B/sample)
 
@@ -57,6 +58,89 @@ def usable_cpus():
     return use, n, quota
 
 
+def visible_gpus():
+    """GPUs a rank of this job would see, counted in a throw-away child process so that THIS process never touches the HIP runtime
+    (it goes on to start the ranks).  None when the count cannot be had (no torch, time-out): the ranks then fail by themselves."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def rank_commands(n, argv, port):
+    """The N (argv, environment additions) pairs `bench.py --gpus N` starts when it was not started by a launcher itself:
+    one process per GPU, rendezvous on 127.0.0.1 — what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py ...` sets for its workers."""
+    out = []
+    for r in range(n):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "GROUP_RANK": "0",
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "M17_BENCH_LAUNCHED": "1"}
+        out.append(([sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"], env))
+    return out
+
+
+def launch_ranks(args, argv):
+    """`python3 bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks as child processes BEFORE
+    anything in this process imports torch or touches the GPU, relay rank 0's JSON line as the LAST (and only) line of stdout, everything
+    else any rank prints goes to stderr.  Exit code = the worst child's; a failing rank takes the others down (they would wait in a
+    collective for ever) — never a retry, never a smaller world.  Fewer visible GPUs than N: one line on stderr, exit code 2."""
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmds = rank_commands(n, argv, port)
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": [{"rank": r, "argv": c, "env": e} for r, (c, e) in enumerate(cmds)]}))
+        return 0
+    have = visible_gpus()
+    if have is not None and have < n:
+        print(f"bench.py: --gpus {n} but {have} GPU(s) visible to this process: not measuring a smaller world", file=sys.stderr)
+        return 2
+    procs = []
+    for r, (c, e) in enumerate(cmds):
+        procs.append(subprocess.Popen(c, env={**os.environ, **e}, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1))
+    line0 = []
+
+    def pump(r, pr):   # rank 0: keep the result line back until every rank is done; anything else -> stderr, tagged
+        for ln in pr.stdout:
+            s_ = ln.rstrip("\n")
+            if r == 0 and s_.startswith("{") and '"metric"' in s_:
+                line0.append(s_)
+            else:
+                print(f"[rank {r}] {s_}", file=sys.stderr, flush=True)
+
+    threads = [threading.Thread(target=pump, args=(r, pr), daemon=True) for r, pr in enumerate(procs)]
+    for t in threads:
+        t.start()
+    worst, alive, stopped = 0, set(range(n)), set()
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and r not in stopped:   # (a rank stopped from here reports the signal: not its own failure)
+                worst = max(worst, code if code > 0 else 128 - code)
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for q in alive:      # exactly the processes started above
+                    procs[q].terminate()
+                    stopped.add(q)
+        time.sleep(0.2)
+    for t in threads:
+        t.join(timeout=5)
+    if worst == 0 and len(line0) != 1:
+        print(f"bench.py: rank 0 printed {len(line0)} result lines", file=sys.stderr)
+        worst = 1
+    if worst == 0:
+        print(line0[0], flush=True)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,8 +167,13 @@ def main():
                     "durations the roofline object is computed from (the regime in which HIP events and rocprofv3 agree)")
     ap.add_argument("--one-at-a-time-steps", type=int, default=2)
     ap.add_argument("--stream-groups", type=int, default=2, help="contexts the channels of the single-stream regime are split into (independent chains)")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no launcher: print the N command lines / environments bench.py would start, and exit")
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 code path (process group, communicators, gather per step) with WORLD_SIZE = 1")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # no launcher around us: be the launcher (before torch / the GPU are touched)
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if args.dry_launch:
+        sys.exit("--dry-launch: only with --gpus N > 1 and WORLD_SIZE unset")
     # the streams of a context (main, K1, K3, K2-ahead, copy) and of different contexts must not share a hardware queue: a kernel queued
     # behind another stream's event wait in the same queue waits with it (the runtime's default is 4 queues)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -95,9 +184,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:   # a launcher that started another number of ranks than the command line names: refuse, do not measure that
+        sys.exit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants GPU {local_rank} but {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_gather     # the N > 1 code path (with --force-gather also for a world of one rank)
