@@ -4,7 +4,33 @@
 
 #include "m17_common.hpp"
 
+#include <type_traits>
+
 namespace m17 {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <bool INVERT>
+__device__ __forceinline__ v2f dcd_scale2(int a, int b)   // core::scale_i16 on two samples at once
+{
+    if (INVERT) { a = (int)(int16_t)(-a); b = (int)(int16_t)(-b); }
+    const v2f rcp = {1.0f / 41067.0f, 1.0f / 41067.0f};
+    const v2f k = {41067.0f, 41067.0f};
+    const v2f fs = {(float)a, (float)b};
+    const v2f q = fs * rcp;
+    const v2f r = __builtin_elementwise_fma(-q, k, fs);
+    return __builtin_elementwise_fma(r, rcp, q);
+}
+
+// hand-over between the roles of the pipeline kernels: LDS only.  (__syncthreads() would also fence GLOBAL memory, i.e. wait for the producer's prefetches
+// of the blocks to come — vmcnt(0) at every barrier — and expose a full HBM round trip per block.)  Every role executes the
+// same number of these, each in its own loop: the hardware counts arrivals per workgroup, not program counters.
+__device__ __forceinline__ void dp_handover()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // =====================================================================================================
 // K1  fir_rrc150_kernel  — reference a1 + a2: apps/m17-demod.cpp:486-489, FirFilter.h:28-43.
@@ -121,6 +147,191 @@ __global__ __launch_bounds__(FIR_THREADS, MINW) void fir_rrc150_rolled_kernel(co
             for (int q = 0; q < 4; ++q)
                 if (t + q < T) yr[t + q] = win[4 * k + q];
         }
+    }
+}
+
+// =====================================================================================================
+// K1, skewed-pair form (round 5)  fir_rrc150_skew_kernel — the same a1 + a2, the same products and the same additions in the same
+// order, with every VALU instruction of the tap loop a FULL packed operation and no register moves:
+//
+//   * a lane owns SIXTEEN consecutive outputs as eight accumulator pairs (2q, 2q + 1).  Output o at tap i reads sample o - i, so the
+//     even output of a pair at tap u and the odd one at tap u + 1 read the SAME sample: one v_pk_mul_f32 forms
+//     (tap_u * w, tap_{u+1} * w) from ONE window register (broadcast through op_sel) and an aligned pair of taps, one v_pk_add_f32
+//     adds them to the pair.  The odd output runs one tap ahead of the even one; each output still receives its products
+//     i = 0, 1, 2, ... in order (tap_{-1} = tap_149 = 0 pad the two ends: a signed zero added to a sum that is never -0).
+//   * step s = 0..149 serves all eight pairs with the tap pair (tap_{s-1}, tap_s); pair q reads lane-relative window element
+//     e = 153 + 2q - s.  Every element is used by the eight pairs over fifteen consecutive steps, so the window is a RING of 32
+//     registers (slot = e mod 32, two elements per ds_read_b64, issued twelve steps before their first use) and the loop is
+//     rolled over bodies of 32 steps with static register numbers: 150 = 22 + 4 x 32, the first pass enters its body at position 10.
+//   * LDS window with two spare words per sixteen samples (a lane's base is 18 x lane words: its 8-byte reads fall into distinct
+//     banks for sixteen lanes); 16-byte coalesced loads of the int16 input, one conversion per sample (INVERT is a template
+//     parameter), outputs stored from the accumulator registers (64 contiguous bytes per lane).
+//   * BOUNDED GRID: a workgroup loops over (channel, tile) items, tile fastest, the input of its next item in flight during the tap
+//     loop — a launch of a few workgroups per CU leaves its dispatch pipe at once instead of holding it until the last of 50 000
+//     workgroups has found a place (NOTES 4.14: whatever shares a pipe with such a grid waits for whole launches).
+//   VALU per 16 outputs of a lane: 2400 packed + ~90 = 156 per output (rolled R = 15 form above: 181).
+// =====================================================================================================
+template <int E, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (E < N) {
+        f(std::integral_constant<int, E>{});
+        static_for<E + 1, N>(f);
+    }
+}
+
+constexpr int FS_R = 16;                              // outputs per lane
+constexpr int FS_THREADS = 256;
+constexpr int FS_TILE = FS_R * FS_THREADS;            // 4096 outputs per item
+constexpr int FS_WOFF = 152;                          // window samples in front of the tile (= XPRE: 16-byte aligned rows)
+constexpr int FS_WIN = FS_TILE + FS_WOFF;             // 4248 staged samples = 531 chunks of eight
+constexpr int FS_PADF = 18;                           // words in front of the window: the ring's last loads reach below element 0
+constexpr int FS_LDS_FLOATS = FS_PADF + ((FS_WIN + 15) / 16) * 18;   // 4806 floats = 19 224 bytes (<= the 20 KB a CU has beside four K5 workgroups)
+constexpr int FS_STEPS = 150, FS_BODY = 32, FS_ENTRY = 10, FS_NBODY = 5;   // steps; body length = ring size; 150 = (32 - 10) + 4 x 32
+static_assert(FS_BODY - FS_ENTRY + (FS_NBODY - 1) * FS_BODY == FS_STEPS, "step count");
+constexpr int FS_TAB = 64;                            // floats per body in the tap table: 32 for even positions, 32 for odd ones
+
+// word offset of lane-relative element e inside a lane's window (two spare words per sixteen samples); e may be negative
+constexpr int fs_off(int e) { return e + 2 * ((e - (e < 0 ? 15 : 0)) / 16); }
+
+// Host side: the tap table of the kernel.  Body bi, position p serves step s = 32 (bi - 1) + 22 + p with the pair (T2(s), T2(s + 1)),
+// T2(s) = tap_{s-1} (zero outside taps 0..148); even positions read the pair at [p, p + 1] of the first half, odd ones at
+// [p - 1, p] of the second half (the same sequence shifted by one), so that every pair is an aligned scalar register pair.
+inline void fs_build_tap_table(float* tab /* FS_NBODY * FS_TAB */)
+{
+    auto T2 = [](int s) { return (s >= 1 && s <= 149) ? rrc_tap(s - 1) : 0.0f; };
+    for (int bi = 0; bi < FS_NBODY; ++bi)
+        for (int k = 0; k < 32; ++k) {
+            const int s = 32 * (bi - 1) + (FS_BODY - FS_ENTRY) + k;
+            tab[bi * FS_TAB + k] = T2(s);
+            tab[bi * FS_TAB + 32 + k] = T2(s + 1);
+        }
+}
+
+// (tap_a * w, tap_b * w) for w = the low (HALF = 0) or high (HALF = 1) element of a window register pair: one packed multiply, the window
+// element broadcast through op_sel, the taps an aligned scalar register pair
+template <int HALF>
+__device__ __forceinline__ v2f fs_tap_pair_times(v2f taps, v2f wpair)
+{
+    // (written as `taps * v2f{w, w}` the compiler selects the same instruction, but then schedules the whole body freely: 128 VGPRs and
+    //  spills against 106 with the statements below, and 2-4 % slower on the chip)
+    v2f r;
+    if constexpr (HALF) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "s"(taps), "v"(wpair));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "s"(taps), "v"(wpair));
+    return r;
+}
+
+template <bool INVERT>
+__global__ __launch_bounds__(FS_THREADS, 4) void fir_rrc150_skew_kernel(const int16_t* __restrict__ x, size_t xpitch, float* __restrict__ y, size_t ypitch,
+                                                                       uint32_t T, const float* __restrict__ tab, uint32_t tiles, uint32_t items)
+{
+    __shared__ __attribute__((aligned(16))) float win[FS_LDS_FLOATS];
+    const int tid = threadIdx.x;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    constexpr int NCH = (FS_WIN + 7) / 8;             // 531 chunks of eight samples
+    constexpr int CPT = (NCH + FS_THREADS - 1) / FS_THREADS;   // 3 per thread (the third for 19 threads only)
+    v4i pre[CPT];
+    // the int16 input of an item: chunk k <-> window samples 8k .. 8k + 7 <-> times t0 - 152 + 8k ...; beyond the slab's end: zero
+    auto fetch = [&](uint32_t item) {
+        const uint32_t c = item / tiles, tile = item - c * tiles;
+        const int16_t* xr = x + (size_t)c * xpitch + XPRE;
+        const int64_t w0 = (int64_t)tile * FS_TILE - FS_WOFF;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int k = tid + q * FS_THREADS;
+            const int64_t t = w0 + 8 * k;
+            v4i v = {0, 0, 0, 0};
+            if (k < NCH) {
+                if (t + 8 <= (int64_t)T) v = *reinterpret_cast<const v4i*>(xr + t);
+                else {                                // the slab ends inside this chunk (once per channel at most): sample by sample
+                    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+                    for (int h = 0; h < 8; ++h)
+                        if (t + h < (int64_t)T) w[h >> 1] |= (uint32_t)(uint16_t)xr[t + h] << (16 * (h & 1));
+                    v = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+                }
+            }
+            pre[q] = v;
+        }
+    };
+    auto stage = [&] {
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int k = tid + q * FS_THREADS;
+            if (k < NCH) {
+                float* dst = win + FS_PADF + 8 * k + 2 * (k >> 1);   // sample j = 8k at word j + 2 (j >> 4)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int w = pre[q][h];
+                    const v2f f = dcd_scale2<INVERT>((int)(int16_t)(w & 0xFFFF), w >> 16);
+                    *reinterpret_cast<v2f*>(dst + 2 * h) = f;
+                }
+            }
+        }
+    };
+    uint32_t item = blockIdx.x;
+    if (item < items) fetch(item);
+    const float* lbase = win + FS_PADF + 18 * tid;    // lane-relative element e at lbase[fs_off(e)]
+    for (; item < items; item += gridDim.x) {
+        const uint32_t c = item / tiles, tile = item - c * tiles;
+        stage();
+        dp_handover();                                // (LDS only: no wait for the stores of the item before)
+        if (item + gridDim.x < items) fetch(item + gridDim.x);   // in flight during the tap loop
+        v2f acc[8], ring[16];
+        v2f late = {0.0f, 0.0f};                      // pair 7's product of the step before (added one step late: +0 first, harmless)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = v2f{0.0f, 0.0f};
+        // the ring before step 0: the pairs that positions in front of the entry point would have loaded (elements 142 .. 167)
+        static_for<0, 13>([&](auto kc) {
+            constexpr int e = 142 + 2 * decltype(kc)::value;
+            ring[(e & 31) >> 1] = *reinterpret_cast<const v2f*>(lbase + fs_off(e));
+        });
+        const float* lb = lbase + 36;                 // body b reads from lbase - 36 b: b = -1 first
+#pragma unroll 1
+        for (int bi = 0; bi < FS_NBODY; ++bi) {
+            const float* tb = tab + bi * FS_TAB;      // wave-uniform: scalar loads
+            auto half = [&](auto lo_c, auto hi_c) {
+                static_for<decltype(lo_c)::value, decltype(hi_c)::value>([&](auto pc) {
+                    constexpr int p = decltype(pc)::value;
+                    // step s = 32 b + 22 + p; pair q reads element e = 153 + 2q - s = 131 - 32 b + 2q - p: slot (131 + 2q - p) mod 32
+                    if constexpr ((p & 1) == 0) {     // the pair of elements first needed twelve steps from now
+                        constexpr int e = 118 - p;    // (minus 32 b: folded into lb)
+                        ring[(e & 31) >> 1] = *reinterpret_cast<const v2f*>(lb + fs_off(e));
+                    }
+                    const v2f tp = (p & 1) ? *reinterpret_cast<const v2f*>(tb + 32 + p - 1) : *reinterpret_cast<const v2f*>(tb + p);
+                    v2f pr[8];                        // the eight products first, then the eight additions: no dependent neighbours
+                    static_for<0, 8>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        constexpr int slot = (131 + 2 * q - p) & 31;
+                        pr[q] = fs_tap_pair_times<slot & 1>(tp, ring[slot >> 1]);
+                    });
+                    // (the compiler counts an asm statement as no wait state at all and pads a reader of ANY asm result that follows a run of
+                    //  them with an s_nop: pair 7's addition of the step before goes first — its product is eight real instructions old)
+                    acc[7] = acc[7] + late;
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) acc[q] = acc[q] + pr[q];
+                    late = pr[7];
+                });
+            };
+            if (bi > 0) half(std::integral_constant<int, 0>{}, std::integral_constant<int, FS_ENTRY>{});
+            half(std::integral_constant<int, FS_ENTRY>{}, std::integral_constant<int, FS_BODY>{});
+            lb -= 36;
+        }
+        acc[7] = acc[7] + late;
+        // outputs 16 tid .. 16 tid + 15 of the tile, from the registers
+        const uint32_t t = tile * FS_TILE + 16u * (uint32_t)tid;
+        float* yo = y + (size_t)c * ypitch + YPRE + t;
+        if (t + 16 <= T) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(yo + 4 * g) = make_float4(acc[2 * g].x, acc[2 * g].y, acc[2 * g + 1].x, acc[2 * g + 1].y);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (t + 2 * q < T) yo[2 * q] = acc[q].x;
+                if (t + 2 * q + 1 < T) yo[2 * q + 1] = acc[q].y;
+            }
+        }
+        dp_handover();                                // every wave is through with the window before the next item is staged
     }
 }
 
@@ -245,7 +456,6 @@ __device__ __forceinline__ float scale_sample_mul(int s, bool invert)
     return (float)((double)s * (1.0 / 41067.0));
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int DCD_BLK = 32;        // samples per block: conversion granule and straight-line length of the recurrence
 constexpr int DCD_CPW = 32;        // channels per wave
 constexpr int DCD_PITCH = DCD_BLK + 4;  // LDS row pitch in floats
@@ -404,28 +614,6 @@ constexpr int DP_BLK = 32;               // samples per pipeline stage
 constexpr int DP_CPB = 32;               // channels per workgroup
 constexpr int DP_DPITCH = DP_BLK + 4;    // delta row pitch in floats (conflict-free 16-byte reads)
 constexpr int DP_PF = 3;                 // blocks of input the producer keeps in flight
-
-template <bool INVERT>
-__device__ __forceinline__ v2f dcd_scale2(int a, int b)   // core::scale_i16 on two samples at once
-{
-    if (INVERT) { a = (int)(int16_t)(-a); b = (int)(int16_t)(-b); }
-    const v2f rcp = {1.0f / 41067.0f, 1.0f / 41067.0f};
-    const v2f k = {41067.0f, 41067.0f};
-    const v2f fs = {(float)a, (float)b};
-    const v2f q = fs * rcp;
-    const v2f r = __builtin_elementwise_fma(-q, k, fs);
-    return __builtin_elementwise_fma(r, rcp, q);
-}
-
-// hand-over between the roles of the pipeline kernels: LDS only.  (__syncthreads() would also fence GLOBAL memory, i.e. wait for the producer's prefetches
-// of the blocks to come — vmcnt(0) at every barrier — and expose a full HBM round trip per block.)  Every role executes the
-// same number of these, each in its own loop: the hardware counts arrivals per workgroup, not program counters.
-__device__ __forceinline__ void dp_handover()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 
 // preconditions (the host launches dcd_kernel otherwise): T and pos0 are multiples of DP_BLK, T >= 4 blocks, so every block
 // is whole and tick boundaries (192 = 6 x 32 samples) are block boundaries

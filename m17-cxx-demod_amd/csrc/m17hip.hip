@@ -118,6 +118,10 @@ struct m17hip_ctx {
     uint64_t compact_cap = 0;
     DecodeTables* tables = nullptr;
     float* taps = nullptr;
+    float* taps_skew = nullptr;      // tap table of fir_rrc150_skew_kernel (fs_build_tap_table)
+    int fir_form = 1;                // K1: 1 = skewed-pair form on a bounded grid (default), 0 = the rolled R = 15 form, one workgroup per tile (tools build: key 11)
+    uint32_t fir_grid = 0;           // workgroups of the bounded grid (0 = default: FIR_GRID_PER_CU per CU)
+    uint32_t n_cu = 256;
     uint32_t* defer_llr = nullptr;   // [maxC][rec_cap_alloc][46]: LLR frames (nibbles) K5 leaves for decode_deferred_kernel (tune 15)
     uint32_t* defer_hist = nullptr;  // [maxC][101][64]: that kernel's decision words
     bool defer_decode = true;
@@ -589,11 +593,25 @@ __global__ void compact_kernel(const FrameRec* recs, uint32_t rec_cap, const uin
 
 // t0: first sample of the slab to process (segment of a run); the kernels see the slab from there on
 constexpr size_t SEQ_LDS_BYTES_4 = 34816;   // see the K5 launch
+constexpr uint32_t FIR_GRID_PER_CU = 5;   // workgroups of the bounded K1 grid per CU: what a CU holds of them when it has nothing else to do
 int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0)
 {
     Timed tm(c, KT_FIR, st);
-    dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C);
-    hipLaunchKernelGGL((fir_rrc150_rolled_kernel<FIR_R, 4>), grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
+    if (c->fir_form == 0) {
+        dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C);
+        hipLaunchKernelGGL((fir_rrc150_rolled_kernel<FIR_R, 4>), grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
+    } else {
+        const uint32_t tiles = (T + FS_TILE - 1) / FS_TILE;
+        const uint64_t items64 = (uint64_t)tiles * C;
+        if (items64 > 0xFFFFFFFFull) return M17HIP_EINVAL;
+        const uint32_t items = (uint32_t)items64;
+        const uint32_t cap = c->fir_grid ? c->fir_grid : FIR_GRID_PER_CU * c->n_cu;
+        const dim3 grid(std::min(items, cap));
+        if (flags & 1u)
+            hipLaunchKernelGGL(fir_rrc150_skew_kernel<true>, grid, dim3(FS_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, c->taps_skew, tiles, items);
+        else
+            hipLaunchKernelGGL(fir_rrc150_skew_kernel<false>, grid, dim3(FS_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, c->taps_skew, tiles, items);
+    }
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
@@ -684,6 +702,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->overflow, 4 * sizeof(uint32_t));   // [0] record overflow, [1] channels that left the limit-filter replay (m17hip_replay_drops)
     ALLOC(c->tables, sizeof(DecodeTables));
     ALLOC(c->taps, 160 * sizeof(float));
+    ALLOC(c->taps_skew, FS_NBODY * FS_TAB * sizeof(float));
     ALLOC(c->llr_edges, 64 * sizeof(float));
     ALLOC(c->level_gain, 8 * (size_t)core::LEVEL_SCHED_N * sizeof(core::Kalman2Gain));
     ALLOC(c->dbg, (C + 1) * DBG_SLOTS * sizeof(unsigned long long));   // (tools build: per-wave counters of K5)
@@ -699,6 +718,12 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
         float edges[64] = {0};
         build_llr_edges(edges);
         if (hipMemcpy(c->taps, taps, sizeof(taps), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
+        float skew[FS_NBODY * FS_TAB];
+        fs_build_tap_table(skew);
+        if (hipMemcpy(c->taps_skew, skew, sizeof(skew), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) return fail(M17HIP_EHIP);
+        c->n_cu = (uint32_t)ncu;
         if (hipMemcpy(c->llr_edges, edges, sizeof(edges), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
         std::vector<core::Kalman2Gain> sched(8 * (size_t)core::LEVEL_SCHED_N);
         for (uint32_t o = 0; o < 8; ++o)   // (false = the covariance has not reached its fixed point inside the table: the scheduled update would be wrong)
@@ -756,7 +781,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
         for (auto* v : {&c->ev_fir_[q], &c->ev_dcd_[q], &c->ev_gate_[q], &c->ev_redo_[q], &c->ev_seq_[q]})
             for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->llr_edges, c->level_gain, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist,
+                    c->overflow, c->tables, c->taps, c->taps_skew, c->llr_edges, c->level_gain, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist,
                     c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->bnd, c->ev_ops, c->ev_cur, c->ev_state};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -1949,6 +1974,14 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         return M17HIP_OK;
     case 16:  // the in-place producers (m17hip_upload_i16, m17hip_upload_i16_device, m17hip_synth_i16) write the STAGING slab instead
         c->stage_inputs = value != 0;
+        return M17HIP_OK;
+    case 11:  // K1 form: 1 (default) = skewed pairs on a bounded grid, 0 = rolled R = 15 form with one workgroup per tile (round 4's; kept for same-box A/B until the round ends)
+        if (value < 0 || value > 1) return M17HIP_EINVAL;
+        c->fir_form = (int)value;
+        return M17HIP_OK;
+    case 13:  // workgroups of K1's bounded grid (0 = default)
+        if (value < 0 || value > (1 << 20)) return M17HIP_EINVAL;
+        c->fir_grid = (uint32_t)value;
         return M17HIP_OK;
 #ifdef M17_TOOLS
     // ---- measurement / experiment knobs: only in the tools build (make -C csrc tools -> libm17hip_tools.so), used by tools/*.py ------

@@ -21,7 +21,17 @@ def worker(single):
     C, T = 4096, 480000
     p = ol.gen_params(seed=20260101, kind=-1, n_frames=T // 1920 - 6, lead_in=3072, noise_sigma=600., tail_sigma=600., lead_sigma=40000.0, total=T)
     ctxs, streams = [], []
+    nph = int(os.environ.get('M17_BISECT_PLACEHOLDERS', '0'))   # streams created (and never used) in front of every context: shifts which streams share a dispatch pipe (NOTES 4.14)
+    placeholders = []
+    def hip_stream():   # a REAL new HIP stream (torch.cuda.Stream() hands out streams of a pool it creates all at once)
+        import ctypes
+        path = [l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l][0]
+        h = ctypes.c_void_p()
+        rc = ctypes.CDLL(path).hipStreamCreateWithFlags(ctypes.byref(h), 1)
+        assert rc == 0, rc
+        return h
     for f in range(2):
+        placeholders += [hip_stream() for _ in range(nph)]
         c = m17hip.Context(C, T); streams.append(torch.cuda.Stream()); c.set_stream(streams[-1].cuda_stream); c.synth(p, C, T); ctxs.append(c)
     def groups(n):
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -40,6 +50,7 @@ def worker(single):
         gs, ss = [], []
         try:
             for g in range(G):
+                placeholders += [hip_stream() for _ in range(nph)]
                 c = m17hip.Context(Cg, T); ss.append(torch.cuda.Stream()); c.set_stream(ss[-1].cuda_stream)
                 c.synth(p, Cg, T, chan0=g * Cg); c.tune(16, 1); c.synth(p, Cg, T, chan0=g * Cg); c.tune(16, 0)
                 c.reset(); c.run(); gs.append(c)
