@@ -585,9 +585,8 @@ def main():
         c2 = m17hip.Context(C2, T, device=local_rank)
         c2.synth(p, C2, T, chan0=0)
 
-        def step2():
-            c2.fir(fetch=False)
-            c2.correlator_device()
+        def step2():   # m17hip_fir_correlator: the matched filter, the limit filter and the correlations of a run in ONE call, pipelined in time
+            c2.fir_correlator(fetch=False)
 
         step2()
         c2.timing(True); c2.timing_reset()
@@ -693,9 +692,8 @@ def bench_front(args, ctx, ol, x, C, T, rank, world, dev, sync, ncpu, ncpu_affin
     import torch
     import torch.distributed as dist
 
-    def step():
-        ctx.fir(fetch=False)                      # K1: scaling + BaseFirFilter<float,150>, result stays on the device
-        ctx.correlator_device()                   # Correlator::sample (limit) + correlate x 4 words, results stay on the device
+    def step():   # K1 (scaling + BaseFirFilter<float,150>), Correlator::sample (limit) and correlate x 4 words, pipelined in time; results stay on the device
+        ctx.fir_correlator(fetch=False)
 
     for _ in range(args.warmup):
         step()

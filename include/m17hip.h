@@ -125,6 +125,12 @@ int m17hip_fir_rrc150(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint
  * (preamble, LSF, packet, EOT — M17Demodulator.h:154-157) for every sample of the FIR output left on the
  * device by m17hip_fir_rrc150 (Correlator.h:43-64, IirFilter.h:26-42).  limit: [C][T]; corr: [4][C][T]. */
 int m17hip_correlator(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, float* limit_host, float* corr_host);
+/* K1 + K2 in one call (BASELINE configs[1]: "FIR + Correlator only"): the matched filter, the limit filter and the four correlations over
+ * the uploaded slab, pipelined in time — the limit filter is one dependent chain per channel over the whole run and is what the call
+ * lasts; the matched filter of the next piece and the correlations of this one run beside it.  Results are identical to
+ * m17hip_fir_rrc150 followed by m17hip_correlator (FirFilter.h:28-43, Correlator.h:38-64, IirFilter.h:26-42).
+ * y: [C][T], limit: [C][T], corr: [4][C][T]; any of the host pointers may be NULL (the result stays on the device). */
+int m17hip_fir_correlator(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint32_t flags, float* y_host, float* limit_host, float* corr_host);
 /* K3: NSlidingDFT<float,48000,120,2> + DataCarrierDetect accumulation (SlidingDFT.h:118-132,
  * DataCarrierDetect.h:53-58) over the uploaded slab.  For every 192-sample tick k the table holds the
  * sequential sums of norm(X0) (bin 0) and norm(X1) (bin 1) for segments that started 1..5 ticks ago (index a%5,

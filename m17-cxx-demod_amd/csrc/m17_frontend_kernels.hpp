@@ -340,12 +340,13 @@ __global__ __launch_bounds__(FS_THREADS, 4) void fir_rrc150_skew_kernel(const in
 // sync words for every sample: corr[w][c][t] = sum_{i=0}^{7} word[i] * y[t - 70 + 10 i] (oldest symbol
 // first, fp32, mul then add).  Time-parallel, elementwise; the 8 taps are shared by the four words.
 // =====================================================================================================
+// samples [t0, t0 + T) of rows of Ttot samples (a piece in time of the whole pass: m17hip_fir_correlator)
 __global__ __launch_bounds__(256) void correlate_kernel(const float* __restrict__ y, size_t ypitch, float* __restrict__ corr,
-                                                        uint32_t C, uint32_t T)
+                                                        uint32_t C, uint32_t T, uint32_t t0, uint32_t Ttot)
 {
     const uint32_t c = blockIdx.y;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
+    const uint32_t t = t0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= t0 + T) return;
     const float* yr = y + (size_t)c * ypitch + YPRE;
     float s[8];
 #pragma unroll
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void correlate_kernel(const float* __restrict_
             const float p = (float)SYNC_WORDS[w][i] * s[i];
             r = r + p;
         }
-        corr[((size_t)w * C + c) * T + t] = r;
+        corr[((size_t)w * C + c) * Ttot + t] = r;
     }
 }
 
@@ -789,7 +790,10 @@ constexpr int LP_YP = LP_TILE + 4;        // ytile row pitch (floats): sixteen r
 constexpr int LP_HP = 4 + LP_TILE + 4;    // htile row pitch: 4 floats of the previous tile in front
 constexpr int LP_PF = 3;
 
-__global__ __launch_bounds__(320, 1) void limit_pipe_kernel(const float* __restrict__ y, size_t ypitch, float* __restrict__ limit, uint32_t C, uint32_t T)
+// `T` samples from y (row pitch ypitch) to limit (row pitch lpitch); state (may be null = zero history / not kept): the last four history values of a
+// channel, h[-4 .. -1], so that a run can be cut into pieces in time (m17hip_fir_correlator pipelines the matched filter with this chain)
+__global__ __launch_bounds__(320, 1) void limit_pipe_kernel(const float* __restrict__ y, size_t ypitch, float* __restrict__ limit, size_t lpitch, uint32_t C, uint32_t T,
+                                                            const float* __restrict__ state_in, float* __restrict__ state_out)
 {
     __shared__ __attribute__((aligned(16))) float ytile[2][LP_CH][LP_YP];
     __shared__ __attribute__((aligned(16))) float htile[2][LP_CH][LP_HP];
@@ -834,10 +838,20 @@ __global__ __launch_bounds__(320, 1) void limit_pipe_kernel(const float* __restr
     } else if (role == 2) {
         // the filter starts from zero history; p1 = (h[-2], h[-1]), m2 = a2 h[-2]: the pair the newest outputs sit in (see nf_serve_limit, m17_wave_kernel.hpp)
         iir_v2f p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
-        float m2 = 0.f;
         const iir_v2f coef = {IirCoef::a1, IirCoef::a2};
-        auto lo = [&](iir_v2f p) { iir_v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(p), "s"(coef)); return r; };
-        auto hi = [&](iir_v2f p) { iir_v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(p), "s"(coef)); return r; };
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        v4f_ tail = {0.f, 0.f, 0.f, 0.f};
+        if (state_in && lane < LP_CH) {
+            tail = *reinterpret_cast<const v4f_*>(state_in + 4 * (size_t)row_of((uint32_t)lane));
+            p1 = iir_v2f{tail.z, tail.w};
+        }
+        float m2 = IirCoef::a2 * p1.x;                // a2 h[-2]: the product the sample before the first one left behind
+        __builtin_amdgcn_s_setprio(3);                // the chain's instructions first, whatever shares the SIMD (the matched filter's packed operations, four cycles each)
+        // (a1 h, a2 h) for h = the low / high element of a pair whose BOTH elements are live: the compiler selects v_pk_mul_f32 with op_sel on
+        // that pair.  (As an asm statement the multiply drew an s_nop in front of its reader — the compiler takes an asm result for a forwarding
+        // hazard — one more issue slot in a four-instruction dependent chain.)
+        auto lo = [&](iir_v2f p) { return iir_v2f{p.x, p.x} * coef; };
+        auto hi = [&](iir_v2f p) { return iir_v2f{p.y, p.y} * coef; };
         auto four = [&](const v4f v) {   // h0 = (|y| - a1 h1) - a2 h2, the two products of a history value from one packed multiply
             iir_v2f r;
             r = hi(p1); p0.x = (fabsf(v.x) - r.x) - m2; m2 = r.y;
@@ -846,7 +860,6 @@ __global__ __launch_bounds__(320, 1) void limit_pipe_kernel(const float* __restr
             r = lo(p1); p1.y = (fabsf(v.w) - r.x) - m2; m2 = r.y;
             return v4f{p0.x, p0.y, p1.x, p1.y};
         };
-        v4f tail = {0.f, 0.f, 0.f, 0.f};
         for (uint32_t i = 0; i < NI; ++i) {
             if (i >= 1u && i <= NT && lane < LP_CH) {
                 const uint32_t b = (i - 1u) & 1u;
@@ -868,6 +881,7 @@ __global__ __launch_bounds__(320, 1) void limit_pipe_kernel(const float* __restr
             }
             dp_handover();
         }
+        if (state_out && lane < LP_CH && c0 + (uint32_t)lane < C) *reinterpret_cast<v4f_*>(state_out + 4 * (size_t)(c0 + (uint32_t)lane)) = tail;
     } else {
         for (uint32_t i = 0; i < NI; ++i) {
             if (i >= 2u && i < NT + 2u) {
@@ -883,7 +897,7 @@ __global__ __launch_bounds__(320, 1) void limit_pipe_kernel(const float* __restr
                     o.y = iir_output(h.y, h.x, p.w);
                     o.z = iir_output(h.z, h.y, h.x);
                     o.w = iir_output(h.w, h.z, h.y);
-                    if (c0 + r < C) *reinterpret_cast<float4*>(limit + (size_t)(c0 + r) * T + (size_t)tile * LP_TILE + 4u * col) = o;
+                    if (c0 + r < C) *reinterpret_cast<float4*>(limit + (size_t)(c0 + r) * lpitch + (size_t)tile * LP_TILE + 4u * col) = o;
                 }
             }
             dp_handover();

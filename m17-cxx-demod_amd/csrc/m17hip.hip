@@ -55,6 +55,7 @@ struct m17hip_ctx {
     float* yalt = nullptr;
     float* halt = nullptr;
     float* dcd_alt = nullptr;
+    bool foreign_streams[4] = {false, false, false, false};   // tools build, keys 40-43: side / side2 / side3 / copy belong to the experiment, not to the context
     hipStream_t copy = nullptr;       // host -> device copies of staged input only
     hipEvent_t ev_copy = nullptr;     // the staged copy has left its source buffer
     hipEvent_t ev_in_ready = nullptr; // the staged slab and its carried 152-sample prefix are complete
@@ -97,7 +98,7 @@ struct m17hip_ctx {
     uint32_t* diag_count = nullptr;   // [maxC]
     uint32_t diag_cap = 0;
     uint32_t kalman_order = 3;        // evaluation order of the Kalman updates (m17hip_set_kalman_order)
-    int gather_fault = 0;             // tuning knob 30 (tests): 1 = this rank's compaction fails inside the gather, 2 = the root's staging allocation fails
+    int gather_fault = 0;             // tuning knob 30 (tests): 1 = this rank's compaction fails inside the gather, 2 = the root's staging allocation fails, 3 = its word of exchange 2 is not written
     uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
     uint32_t front_first = 0;         // tuning knob 12: segments of K1 that must be complete before the first K5 starts (0 = its own only)
     int redo_form = 0;                // tuning knob 20: the replay's redo beside K5, state only (0, default), or in front of K5 with the history stored (1)
@@ -175,6 +176,17 @@ namespace {
     } while (0)
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// Give device memory back and forget the pointer.  hipFree fails only for a pointer the runtime does not know (or a dead device): the
+// pointer is dropped either way — never reused, never freed twice — and the code is kept where a context is at hand.
+template <typename T>
+void free_dev(T*& p, int* last_hip = nullptr)
+{
+    if (!p) return;
+    const hipError_t e = hipFree((void*)p);
+    if (e != hipSuccess && last_hip) *last_hip = (int)e;
+    p = nullptr;
+}
 
 // ---- constant tables ------------------------------------------------------------------------------------------
 const uint8_t DC_SEQ[46] = {0xd6, 0xb5, 0xe2, 0x30, 0x82, 0xFF, 0x84, 0x62, 0xba, 0x4e, 0x96, 0x90, 0xd8, 0x98, 0xdd, 0x5d,
@@ -317,7 +329,7 @@ void drain_timing(m17hip_ctx* c)
 int ensure_scratch(m17hip_ctx* c, size_t bytes)
 {
     if (bytes <= c->scratch_bytes) return M17HIP_OK;
-    if (c->scratch) { hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    free_dev(c->scratch, &c->last_hip); c->scratch_bytes = 0;
     HIPCHK(c, hipMalloc(&c->scratch, bytes));
     c->scratch_bytes = bytes;
     return M17HIP_OK;
@@ -771,10 +783,10 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     for (auto e : c->pool) hipEventDestroy(e);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
-    if (c->side) hipStreamDestroy(c->side);
-    if (c->side2) hipStreamDestroy(c->side2);
-    if (c->side3) hipStreamDestroy(c->side3);
-    if (c->copy) hipStreamDestroy(c->copy);
+    if (c->side && !c->foreign_streams[0]) hipStreamDestroy(c->side);
+    if (c->side2 && !c->foreign_streams[1]) hipStreamDestroy(c->side2);
+    if (c->side3 && !c->foreign_streams[2]) hipStreamDestroy(c->side3);
+    if (c->copy && !c->foreign_streams[3]) hipStreamDestroy(c->copy);
     for (hipEvent_t e : {c->ev_copy, c->ev_in_ready, c->ev_end[0], c->ev_end[1], c->ev_mark, c->ev_tail})
         if (e) hipEventDestroy(e);
     for (int q = 0; q < 2; ++q)
@@ -784,7 +796,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
                     c->overflow, c->tables, c->taps, c->taps_skew, c->llr_edges, c->level_gain, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist,
                     c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->bnd, c->ev_ops, c->ev_cur, c->ev_state};
     for (void* p : ptrs)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);   // (the context is going away: nothing to report to)
     delete c;
 }
 
@@ -922,7 +934,7 @@ int m17hip_synth_i16(m17hip_ctx* c, const m17_synth_params* params, uint32_t C, 
     if (r) return r;
     // the symbol staging lives in its own allocation: the per-operator scratch may be in use by work queued on the main stream
     if (sym_bytes + (size_t)C * 4 > c->synth_bytes) {
-        if (c->synth_scratch) { HIPCHK(c, hipDeviceSynchronize()); hipFree(c->synth_scratch); c->synth_scratch = nullptr; c->synth_bytes = 0; }
+        if (c->synth_scratch) { HIPCHK(c, hipDeviceSynchronize()); free_dev(c->synth_scratch, &c->last_hip); c->synth_bytes = 0; }
         HIPCHK(c, hipMalloc(&c->synth_scratch, sym_bytes + (size_t)C * 4));
         c->synth_bytes = sym_bytes + (size_t)C * 4;
     }
@@ -994,11 +1006,11 @@ int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, 
         Timed tm(c, KT_CORR);
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        hipLaunchKernelGGL(correlate_kernel, dim3((T + 255) / 256, C), dim3(256), 0, c->side, c->ybuf, c->ypitch, corr, C, T);
+        hipLaunchKernelGGL(correlate_kernel, dim3((T + 255) / 256, C), dim3(256), 0, c->side, c->ybuf, c->ypitch, corr, C, T, 0u, T);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
         if (T % LP_TILE == 0 && T >= 4 * LP_TILE && (((size_t)C * T) & 3) == 0)
-            hipLaunchKernelGGL(limit_pipe_kernel, dim3((C + LP_CH - 1) / LP_CH), dim3(320), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
+            hipLaunchKernelGGL(limit_pipe_kernel, dim3((C + LP_CH - 1) / LP_CH), dim3(320), 0, c->stream, c->ybuf, c->ypitch, limit, (size_t)T, C, T, (const float*)nullptr, (float*)nullptr);
         else
             hipLaunchKernelGGL(limit_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
         HIPCHK(c, hipGetLastError());
@@ -1275,6 +1287,61 @@ static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, b
 
 }  // namespace
 
+// BASELINE configs[1] as ONE call: matched filter, limit filter and the four correlations of `samples` samples per channel, pipelined in time.
+// The limit filter is one dependent chain per channel over the whole run (12 ns per sample) and is what the call lasts; the matched filter
+// (K1) of piece k + 1 and the correlations of piece k run beside the chain's piece k on two side streams, the chain's state (four history
+// values per channel) carried from piece to piece.  Results identical to m17hip_fir_rrc150 followed by m17hip_correlator.
+int m17hip_fir_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, float* y_host, float* limit_host, float* corr_host)
+{
+    if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT || (flags & ~M17HIP_FLAG_INVERT)) return M17HIP_EINVAL;
+    GUARD(c);
+    if (c->front_pending) return M17HIP_ESTATE;
+    if (!c->uploaded) return M17HIP_ESTATE;
+    const size_t n = (size_t)C * T;
+    int r = ensure_scratch(c, 5 * n * sizeof(float) + (size_t)C * 4 * sizeof(float));
+    if (r) return r;
+    float* limit = (float*)c->scratch;
+    float* corr = limit + n;
+    float* lstate = corr + 4 * n;
+    // pieces of whole 256-sample tiles (the limit pipeline's granule), about a tenth of the run each; anything else: one piece, the plain kernels
+    const bool tiled = T % LP_TILE == 0 && T >= 8 * LP_TILE && (n & 3) == 0;
+    const uint32_t piece = tiled ? std::max<uint32_t>((uint32_t)round_up((T + 9) / 10, LP_TILE), 4 * LP_TILE) : T;
+    uint32_t npieces = (T + piece - 1) / piece;
+    if (tiled && npieces > 1 && T - (npieces - 1) * piece < 4 * LP_TILE) --npieces;   // (a last piece of fewer than four tiles joins the one before it)
+    if ((r = ensure_seg_events(c, c->slot, npieces))) return r;
+    auto& ev_fir = c->ev_fir_[c->slot];
+    // (Tried: the chain on compute units of its own — hipExtStreamCreateWithCUMask, a quarter of the chip — with the two throughput kernels on
+    //  the rest: the chain's pieces 0.79 -> 0.74 ms, the call 8.2 -> 9.0 ms.  What stretches the chain beside them is not its SIMD: NOTES 5.4.)
+    const hipStream_t st_chain = c->stream, st_fir = c->side2, st_corr = c->side;
+    const uint32_t chain_wgs = (C + LP_CH - 1) / LP_CH;
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    for (hipStream_t st : {st_chain, st_fir, st_corr})
+        if (st != c->stream) HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
+    if (tiled) HIPCHK(c, hipMemsetAsync(lstate, 0, (size_t)C * 4 * sizeof(float), st_chain));
+    for (uint32_t k = 0; k < npieces; ++k) {
+        const uint32_t t0 = k * piece, len = k + 1 < npieces ? piece : T - t0;
+        if ((r = launch_fir(c, C, len, flags, st_fir, t0))) return r;
+        HIPCHK(c, hipEventRecord(ev_fir[k], st_fir));
+        HIPCHK(c, hipStreamWaitEvent(st_corr, ev_fir[k], 0));
+        HIPCHK(c, hipStreamWaitEvent(st_chain, ev_fir[k], 0));
+        Timed tm(c, KT_CORR, st_chain);
+        hipLaunchKernelGGL(correlate_kernel, dim3((len + 255) / 256, C), dim3(256), 0, st_corr, c->ybuf, c->ypitch, corr, C, len, t0, T);
+        if (tiled)
+            hipLaunchKernelGGL(limit_pipe_kernel, dim3(chain_wgs), dim3(320), 0, st_chain, c->ybuf + t0, c->ypitch, limit + t0, (size_t)T, C, len,
+                               (const float*)lstate, lstate);
+        else
+            hipLaunchKernelGGL(limit_kernel, dim3((C + 63) / 64), dim3(64), 0, st_chain, c->ybuf, c->ypitch, limit, C, T);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(c->ev_join, st_corr));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (y_host) HIPCHK(c, hipMemcpy2DAsync(y_host, (size_t)T * sizeof(float), c->ybuf + YPRE, c->ypitch * sizeof(float), (size_t)T * sizeof(float), C, hipMemcpyDeviceToHost, c->stream));
+    if (limit_host) HIPCHK(c, hipMemcpyAsync(limit_host, limit, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (corr_host) HIPCHK(c, hipMemcpyAsync(corr_host, corr, 4 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M17HIP_OK;
+}
+
 int m17hip_demod_front(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
 {
     if (!c || C == 0 || T == 0 || C > c->maxC || T > c->maxT || (flags & ~M17HIP_FLAG_INVERT)) return M17HIP_EINVAL;
@@ -1549,8 +1616,7 @@ int m17hip_frames_fetch(m17hip_ctx* c, m17_frame_rec* recs_host, uint64_t capaci
     // wanted anyway), so a second pass is never needed
     const uint64_t want = std::max<uint64_t>(std::min<uint64_t>(capacity, (uint64_t)c->lastC * c->rec_cap), 1024);
     if (want > c->compact_cap) {
-        if (c->compact) hipFree(c->compact);
-        c->compact = nullptr; c->compact_cap = 0;
+        free_dev(c->compact, &c->last_hip); c->compact_cap = 0;
         HIPCHK(c, hipMalloc((void**)&c->compact, (size_t)want * sizeof(FrameRec)));
         c->compact_cap = want;
     }
@@ -1742,8 +1808,8 @@ void m17hip_comm_destroy(m17hip_comm* m)
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     hipSetDevice(m->device);
-    if (m->counts_dev) hipFree(m->counts_dev);
-    if (m->gathered) hipFree(m->gathered);
+    free_dev(m->counts_dev);
+    free_dev(m->gathered);
     if (m->comm) rccl().CommDestroy(m->comm);
     if (prev >= 0) hipSetDevice(prev);
     delete m;
@@ -1751,12 +1817,15 @@ void m17hip_comm_destroy(m17hip_comm* m)
 
 // Every rank makes the same sequence of collective calls whatever goes wrong locally: a failure travels as a status inside the words
 // that are exchanged anyway, and all ranks return together (a rank that left early would leave its peers waiting inside RCCL).
-//   exchange 1 (all-gather, two words per rank):  [0] = record count (48 bits) | call serial (8 bits) | status (8 bits: -code)
+//   exchange 1 (all-gather, two words per rank):  [0] = record count (40 bits) | call serial (16 bits) | status (8 bits: -code)
 //                                                 [1] = the ROOT's staging capacity in records (0 from the other ranks)
 //       the serial makes a stale word recognisable: a rank whose own word could not be written to the device (its HIP calls fail)
-//       still joins the all-gather, and what its peers then read in its slot is the word of the PREVIOUS call
+//       still joins the all-gather, and what its peers then read in its slot is a word of an EARLIER exchange
 //   exchange 2 (all-gather, one word per rank) only if the gathered set does not fit the root's staging: the root grows it and says
-//       whether that worked (the others say "ok"); every rank knows from exchange 1 that this exchange is due
+//       whether that worked (the others say "ok"); every rank knows from exchange 1 that this exchange is due.  Its words carry a
+//       phase tag in the status byte's place (0xA5: no status of exchange 1 looks like it, and read as one it is an error) and the
+//       serial again; EVERY rank looks at EVERY slot — a slot without the tag and this call's serial is a word that could not be
+//       written, whoever's it is — so that all ranks leave together or go on together
 //   exchange 3: grouped ncclSend / ncclRecv of the exact record sets, rank after rank = global (channel, seq) order
 static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* counts_host,
                               uint64_t* total_out, bool dest_is_device)
@@ -1775,8 +1844,7 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
         // the dense buffer must hold ALL of this rank's records before anything is sent from it, whatever the first pass said
         // (an overflowed run reports EOVERFLOW before the truncation is looked at)
         if ((r == M17HIP_OK || r == M17HIP_ETRUNC || r == M17HIP_EOVERFLOW) && mine > c->compact_cap) {
-            if (c->compact) hipFree(c->compact);
-            c->compact = nullptr; c->compact_cap = 0;
+            free_dev(c->compact, &c->last_hip); c->compact_cap = 0;
             const uint64_t want = std::max<uint64_t>(mine + mine / 8, 1024);
             const hipError_t e = hipMalloc((void**)&c->compact, (size_t)want * sizeof(FrameRec));
             if (e != hipSuccess) r = hip_code(e);
@@ -1791,8 +1859,11 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
         else { m->gathered = nullptr; m->gathered_cap = 0; }
     }
     // 2. exchange 1
-    const uint64_t serial = (uint64_t)(++m->serial & 0xFFu);
-    uint64_t word[2] = {(mine & 0x0000FFFFFFFFFFFFull) | (serial << 48) | ((uint64_t)(uint8_t)(-local) << 56), is_root ? m->gathered_cap : 0ull};
+    const uint64_t serial = (uint64_t)(++m->serial & 0xFFFFu);
+    constexpr uint64_t COUNT_MASK = (1ull << 40) - 1;
+    if (mine > COUNT_MASK && !local) { local = M17HIP_EINVAL; mine = 0; }   // (2^40 records: not a real case, but the word has no room for more)
+    uint64_t word[2] = {(mine & COUNT_MASK) | (serial << 40) | ((uint64_t)(uint8_t)(-local) << 56),
+                        is_root ? (c->gather_fault == 3 ? 0ull : m->gathered_cap) : 0ull};   // (fault 3: the root claims no room, so that exchange 2 takes place)
     std::vector<uint64_t> words(2 * (size_t)m->nranks, 0);
     {
         hipError_t e = hipMemcpyAsync(m->counts_dev + 2 * m->rank, word, 16, hipMemcpyHostToDevice, c->stream);
@@ -1809,8 +1880,8 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
     for (int k = 0; k < m->nranks; ++k) {
         const uint64_t w = words[2 * (size_t)k];
         int code = -(int)(w >> 56);
-        if (((w >> 48) & 0xFFu) != serial) code = M17HIP_ECOMM;   // a stale word: that rank could not deliver this call's
-        counts[k] = code ? 0 : (w & 0x0000FFFFFFFFFFFFull);
+        if (((w >> 40) & 0xFFFFu) != serial) code = M17HIP_ECOMM;   // a stale word: that rank could not deliver this call's
+        counts[k] = code ? 0 : (w & COUNT_MASK);
         total += counts[k];
         if (code && !remote) remote = code;
     }
@@ -1822,21 +1893,27 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
     if (total > words[2 * (size_t)root + 1]) {
         int rc = M17HIP_OK;
         if (is_root) {
-            if (m->gathered) hipFree(m->gathered);
-            m->gathered = nullptr; m->gathered_cap = 0;
+            free_dev(m->gathered, &c->last_hip); m->gathered_cap = 0;
             const uint64_t want = std::max<uint64_t>(total + total / 8, 1024);
             const hipError_t e = c->gather_fault == 2 ? hipErrorOutOfMemory : hipMalloc((void**)&m->gathered, (size_t)want * sizeof(FrameRec));
             if (e != hipSuccess) rc = hip_code(e); else m->gathered_cap = want;
         }
-        const uint64_t st = (uint64_t)(uint8_t)(-rc);
-        hipError_t e = hipMemcpyAsync(m->counts_dev + 2 * m->rank, &st, 8, hipMemcpyHostToDevice, c->stream);
+        constexpr uint64_t PHASE2 = 0xA5ull << 56;
+        const uint64_t st = PHASE2 | (serial << 40) | (uint64_t)(uint8_t)(-rc);
+        const hipError_t ew = c->gather_fault == 3 ? hipErrorUnknown : hipMemcpyAsync(m->counts_dev + 2 * m->rank, &st, 8, hipMemcpyHostToDevice, c->stream);
+        if (ew != hipSuccess && !rc) rc = hip_code(ew);          // (our slot keeps a word of exchange 1: no tag — every rank sees that)
         const ncclResult_t q = R.AllGather(m->counts_dev + 2 * m->rank, m->counts_dev, 2, ncclUint64, m->comm, c->stream);
         if (q != ncclSuccess) { m->last_rccl = (int)q; return M17HIP_ECOMM; }
-        if (e == hipSuccess) e = hipMemcpyAsync(words.data(), m->counts_dev, words.size() * 8, hipMemcpyDeviceToHost, c->stream);
+        hipError_t e = hipMemcpyAsync(words.data(), m->counts_dev, words.size() * 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return hip_code(e);
+        if (e != hipSuccess) return hip_code(e);   // (this rank cannot read what was agreed on: as in exchange 1)
+        bool all_ok = true;
+        for (int k = 0; k < m->nranks; ++k) {
+            const uint64_t w = words[2 * (size_t)k];
+            if ((w & (0xFFull << 56)) != PHASE2 || ((w >> 40) & 0xFFFFu) != serial || (w & 0xFFu)) all_ok = false;
+        }
         if (rc) return rc;
-        if (words[2 * (size_t)root] & 0xFFu) return M17HIP_ECOMM;   // the root has no room for the gathered set: nobody sends
+        if (!all_ok) return M17HIP_ECOMM;   // the root has no room for the gathered set, or some rank's word did not arrive: nobody sends
     }
     // 4. the records travel to the root with their exact sizes, rank after rank = global channel order
     if (is_root) {
@@ -1912,8 +1989,7 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 7: {  // packet reassembly (m17hip_packets_fetch): room for `value` completed packets per run, 0 = off
         if (value < 0 || value > (1 << 24)) return M17HIP_EINVAL;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->pkt_recs) hipFree(c->pkt_recs);
-        c->pkt_recs = nullptr; c->pkt_cap = 0; c->pkt_fed = false;
+        free_dev(c->pkt_recs, &c->last_hip); c->pkt_cap = 0; c->pkt_fed = false;
         if (value == 0) return M17HIP_OK;
         if (!c->pkt_state) {
             HIPCHK(c, hipMalloc(&c->pkt_state, (size_t)c->maxC * sizeof(PacketState)));
@@ -1934,8 +2010,7 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 9: {  // diagnostic log: room for `value` diagnostic callbacks per channel and run, 0 = off (m17hip_diag_log_fetch)
         if (value < 0 || value > (1 << 20)) return M17HIP_EINVAL;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->diag_log) hipFree(c->diag_log);
-        c->diag_log = nullptr; c->diag_cap = 0;
+        free_dev(c->diag_log, &c->last_hip); c->diag_cap = 0;
         if (value == 0) return M17HIP_OK;
         if (!c->diag_count) HIPCHK(c, hipMalloc((void**)&c->diag_count, (size_t)c->maxC * 4));
         HIPCHK(c, hipMemset(c->diag_count, 0, (size_t)c->maxC * 4));
@@ -1957,19 +2032,19 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
             c->defer_evm = value != 0;
             hipLaunchKernelGGL(ev_move_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->ev_state, c->maxC, c->defer_evm ? 1 : 0);
             HIPCHK(c, hipGetLastError());
-            if (!c->defer_evm && c->ev_ops) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->ev_ops); c->ev_ops = nullptr; }
+            if (!c->defer_evm && c->ev_ops) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_dev(c->ev_ops, &c->last_hip); }
         }
         return M17HIP_OK;
     case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1, default), or in K5 (0)
         c->defer_decode = value != 0;
         if (!c->defer_decode && c->defer_llr) {   // give the stores back (a run in flight may still use them: wait for it)
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            hipFree(c->defer_llr); hipFree(c->defer_hist);
-            c->defer_llr = nullptr; c->defer_hist = nullptr;
+            free_dev(c->defer_llr, &c->last_hip); free_dev(c->defer_hist, &c->last_hip);
         }
         return M17HIP_OK;
-    case 30:  // fault injection for m17hip_gather_frames (tests): 0 = none, 1 = this rank's compaction fails, 2 = the root's staging allocation fails
-        if (value < 0 || value > 2) return M17HIP_EINVAL;
+    case 30:  // fault injection for m17hip_gather_frames (tests): 0 = none, 1 = this rank's compaction fails, 2 = the root's staging allocation fails,
+              // 3 = this rank's word of exchange 2 cannot be written (its slot keeps the word of exchange 1)
+        if (value < 0 || value > 3) return M17HIP_EINVAL;
         c->gather_fault = (int)value;
         return M17HIP_OK;
     case 16:  // the in-place producers (m17hip_upload_i16, m17hip_upload_i16_device, m17hip_synth_i16) write the STAGING slab instead
@@ -2011,6 +2086,15 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         if (value < 0 || value > 1000) return M17HIP_EINVAL;
         c->front_k1_after = (uint32_t)value;
         return M17HIP_OK;
+    case 40: case 41: case 42: case 43: {   // pipe-layout experiments (tools/pipe_layout.py): the K3 / K1 / replay / copy stream replaced by the caller's (value = hipStream_t)
+        hipStream_t* slot[4] = {&c->side, &c->side2, &c->side3, &c->copy};
+        const int r = key - 40;
+        HIPCHK(c, hipDeviceSynchronize());
+        if (*slot[r] && !c->foreign_streams[r]) hipStreamDestroy(*slot[r]);
+        *slot[r] = (hipStream_t)(uintptr_t)value;
+        c->foreign_streams[r] = true;
+        return M17HIP_OK;
+    }
     case 25:  // 1 (default) = m17hip_demod_front also queues the replay of the staged run's first segment (beside the current run's deferred decode)
         if (value != 0 && value != 1) return M17HIP_EINVAL;
         c->gate0_early = (int)value;

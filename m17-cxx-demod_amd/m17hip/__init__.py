@@ -34,7 +34,7 @@ VITERBI_SHAPES = {0: (488, 240), 1: (296, 144), 2: (420, 206), 3: (402, 197)}
 
 EXPORTS = [
     "m17hip_strerror", "m17hip_last_hip_error", "m17hip_version", "m17hip_ctx_create", "m17hip_ctx_destroy", "m17hip_set_stream",
-    "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_upload_i16_async", "m17hip_synth_i16", "m17hip_download_i16", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_dcd", "m17hip_viterbi",
+    "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_upload_i16_async", "m17hip_synth_i16", "m17hip_download_i16", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_fir_correlator", "m17hip_dcd", "m17hip_viterbi",
     "m17hip_slice_llr", "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_packets_fetch", "m17hip_packets_feed", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
     "m17hip_set_kalman_order", "m17hip_kalman_trace", "m17hip_set_channel_base", "m17hip_upload_wait", "m17hip_comm_get_id", "m17hip_comm_create",
@@ -190,6 +190,17 @@ class Context:
         corr = np.empty((4, self.C, self.T), dtype=np.float32)
         self._chk(self.lib.m17hip_correlator(self.h, C.c_uint32(self.C), C.c_uint32(self.T), _ptr(limit), _ptr(corr)))
         return limit, corr
+
+    def fir_correlator(self, flags=0, fetch=True):
+        """configs[1] as one call: matched filter + limit filter + the four correlations, pipelined in time (m17hip_fir_correlator)."""
+        if not fetch:
+            self._chk(self.lib.m17hip_fir_correlator(self.h, C.c_uint32(self.C), C.c_uint32(self.T), C.c_uint32(flags), None, None, None))
+            return None
+        y = np.empty((self.C, self.T), dtype=np.float32)
+        limit = np.empty((self.C, self.T), dtype=np.float32)
+        corr = np.empty((4, self.C, self.T), dtype=np.float32)
+        self._chk(self.lib.m17hip_fir_correlator(self.h, C.c_uint32(self.C), C.c_uint32(self.T), C.c_uint32(flags), _ptr(y), _ptr(limit), _ptr(corr)))
+        return y, limit, corr
 
     def correlator_device(self):
         """Same computation, results left in device memory (benchmarks)."""

@@ -248,9 +248,12 @@ def test_rccl_gather_single_rank():
     assert c.lib.m17hip_gather_frames(c.h, comm2.h, 0, big.ctypes.data_as(C.c_void_p), C.c_uint64(big.size), None, C.byref(tot)) == -3   # ENOMEM on the root
     c.tune(30, 1)
     assert c.lib.m17hip_gather_frames(c.h, comm2.h, 0, big.ctypes.data_as(C.c_void_p), C.c_uint64(big.size), None, C.byref(tot)) == -2   # this rank's records: EHIP
+    c.tune(30, 3)   # exchange 2 takes place and this rank's word of it cannot be written: its slot keeps the word of exchange 1 — no phase tag — and every rank leaves
+    assert c.lib.m17hip_gather_frames(c.h, comm2.h, 0, big.ctypes.data_as(C.c_void_p), C.c_uint64(big.size), None, C.byref(tot)) == -2
     c.tune(30, 0)
-    again, counts = c.gather_frames(comm2, root=0)
-    assert again.tobytes() == recs.tobytes()
+    for _ in range(3):   # (serials go on; the staging buffer grown under fault 3 is in use)
+        again, counts = c.gather_frames(comm2, root=0)
+        assert again.tobytes() == recs.tobytes()
     comm2.close()
     comm.close(); c.close()
 

@@ -112,6 +112,29 @@ def test_fir_ragged_tiles_short_runs_extreme_inputs(Cn, T):
     ctx.close()
 
 
+@pytest.mark.parametrize("Cn,T", [(21, 256 * 200), (16, 256 * 9), (70, 256 * 8), (33, 48000), (5, 256 * 41 + 64), (1, 300)])
+def test_fir_correlator_in_one_call_equals_the_two_operators_and_the_oracle(Cn, T):
+    """m17hip_fir_correlator (configs[1] as one call, the limit chain cut into pieces in time with its history carried, the matched filter and
+    the correlations pipelined beside it) against m17hip_fir_rrc150 + m17hip_correlator and against the oracle, bit for bit: lengths that
+    are cut into ten pieces, into two, and lengths that are not whole 256-sample tiles (one piece, plain kernels); INVERT too."""
+    p = ol.gen_params(seed=1900 + Cn, kind=-1, n_frames=max(1, T // 1920 - 2), lead_in=500, noise_sigma=800.0, tail_sigma=800.0, lead_sigma=30000.0, total=T)
+    x = ol.generate_batch(p, Cn, T, threads=8)
+    x[0, min(300, T // 2):] = 0                      # channel 0: exact zeros after a burst -> the limit filter decays through the subnormal range, across pieces
+    ctx = m17hip.Context(Cn, T)
+    ctx.upload(x)
+    for flags in (0, m17hip.FLAG_INVERT):
+        y, limit, corr = ctx.fir_correlator(flags=flags)
+        y2 = ctx.fir(flags=flags)
+        limit2, corr2 = ctx.correlator()
+        assert np.array_equal(y, y2) and np.array_equal(limit, limit2) and np.array_equal(corr, corr2), (Cn, T, flags)
+        if flags == 0:
+            for c in range(Cn):
+                ye = ol.fir_i16(x[c])
+                le, ce = ol.correlator(ye)
+                assert np.array_equal(y[c], ye) and np.array_equal(limit[c], le) and np.array_equal(corr[:, c, :], ce), (Cn, T, c)
+    ctx.close()
+
+
 def test_config2_at_its_stated_size_1024_channels_by_480000_samples():
     """BASELINE configs[1] AT SIZE: 1024 channels x 480 000 samples (10 s), FIR + correlator outputs materialised on the device (the
     5 x C x T float staging is 9.8 GB).  The matched-filter output and the limit of ALL channels come back (2 x 1.97 GB) and 16
@@ -137,6 +160,12 @@ def test_config2_at_its_stated_size_1024_channels_by_480000_samples():
         assert np.array_equal(y[c], ye) and np.array_equal(limit[c], le), c
         assert np.array_equal(ys[i], ye) and np.array_equal(ls[i], le) and np.array_equal(cs[:, i, :], ce), c
     assert np.isfinite(y).all() and np.isfinite(limit).all() and (np.abs(y).max(axis=1) > 1.0).all()
+    # the same at size through the ONE-CALL form (what bench.py's config2 leg times): all rows of y and limit equal the two-operator results
+    yf = np.empty((Cn, T), dtype=np.float32); lf = np.empty((Cn, T), dtype=np.float32)
+    ctx._chk(ctx.lib.m17hip_fir_correlator(ctx.h, C.c_uint32(Cn), C.c_uint32(T), C.c_uint32(0), yf.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p), None))
+    assert np.array_equal(yf, y) and np.array_equal(lf, limit)
+    ysf, lsf, csf = small.fir_correlator()
+    assert np.array_equal(ysf, ys) and np.array_equal(lsf, ls) and np.array_equal(csf, cs)
     small.close(); ctx.close()
 
 
