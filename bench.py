@@ -209,7 +209,6 @@ def main():
                       tail_sigma=args.sigma, lead_sigma=40000.0, total=T)
     F = max(1, args.in_flight) if args.config == 3 else 1
     ctxs, streams, tuned = [], [], {}
-    policy20 = None
     for f in range(F):   # F independent batches of C channels, each with its own device slabs and streams
         c_ = m17hip.Context(C, T, device=local_rank)
         c_.set_channel_base(rank * C)     # records carry GLOBAL channel ids: the gathered set is the record set of one big run
@@ -217,9 +216,6 @@ def main():
             k_, v_ = kv.split("=")
             c_.tune(int(k_), int(v_))
             tuned[k_] = int(v_)
-        if F > 1 and "20" not in tuned:   # several independent batches in flight: the replay's redo in front of K5 (include/m17hip.h, m17hip_tune key 20:
-            c_.tune(20, 1)                #  fewer instructions at the price of latency on a chain that has slack in this regime; +1.4 %)
-            policy20 = 1
         if F > 1:
             streams.append(torch.cuda.Stream(device=dev))
             c_.set_stream(streams[-1].cuda_stream)
@@ -501,9 +497,7 @@ def main():
     #      `roofline` object is computed from.
     seq_kern = seq_ms = None
     if args.one_at_a_time:
-        if policy20 is not None:
-            ctx.tune(20, 0)   # one batch at a time: the default policy (the chain of K5 launches is what this regime lasts)
-        ctx.reset(); ctx.run(); ctx.frames_count()   # (untimed: the library picks the carrier-detect kernel's form from whether runs overlapped lately — the legs before this one did)
+        ctx.reset(); ctx.run(); ctx.frames_count()   # (untimed: the library picks the carrier-detect kernel's form and the redo policy from whether runs overlapped lately — the legs before this one did)
         ctx.reset()
         ctx.timing(True); ctx.timing_reset()
         torch.cuda.synchronize()
@@ -551,6 +545,26 @@ def main():
                 "chain_frac": round(CHAIN_BYTES * C * T * args.steps / dt / 1e9 / HBM_PEAK_GBS, 6),
                 "timed_region_kernel_ms": {k: round(v["ms_per_step"], 4) for k, v in kern.items()},
                 "timed_region_note": "HIP-event brackets of launches that share the chip with another batch's kernels include the time a launch waits for free CUs"}
+    # ---- the BINDING roofline: fp32 VALU.  SURVEY §8(d): the exact-order matched filter is 149 multiplies + 149 additions per sample, no FMA allowed:
+    #      298 flop per sample against the non-FMA fp32 vector peak (157.3 / 2 = 78.6 Tflop/s).  Instruction counts and clocks come from the committed PMC
+    #      pass (profiles/valu.json <- tools/profile_round.sh + tools/make_valu.py); `issue_util` = VALU instructions of a step x 4 cycles (a packed
+    #      operation's issue time; an unpacked one takes 2: NOTES 5.1) / (SIMDs x cycles of the step at the clock measured in the mix).
+    valu = {"flop_per_sample": 298, "achieved_tflops": round(value * 1e6 / world * 298 / 1e12, 3), "peak_nonfma_tflops": 78.6,
+            "frac": round(value * 1e6 / world * 298 / 1e12 / 78.6, 4), "valu_insts_per_step": None, "issue_util": None}
+    vpath = os.path.join(ROOT, "profiles", "valu.json")
+    if os.path.exists(vpath):
+        vj = json.load(open(vpath))
+        if vj.get("channels") == C and vj.get("samples") == T:
+            mix = vj.get("clock_in_mix") if isinstance(vj.get("clock_in_mix"), dict) else {}
+            clk_mhz = mix.get("busy_mean_mhz") or 2100.0
+            n_simd = 4 * int(torch.cuda.get_device_properties(dev).multi_processor_count)
+            cycles = dt / args.steps * clk_mhz * 1e6
+            valu.update({"valu_insts_per_step": int(vj["valu_insts_per_step"]), "issue_util": round(vj["valu_insts_per_step"] * 4 / (n_simd * cycles), 4),
+                         "clock_mhz_in_mix": round(clk_mhz, 1), "simds": n_simd,
+                         "valu_insts_per_step_by_kernel": {k: int(v["valu_insts_per_step"]) for k, v in vj["kernels"].items()},
+                         "clock_ghz_alone_by_kernel": {k: round(v["clock_ghz_alone"], 3) for k, v in vj["kernels"].items()},
+                         "source": "profiles/valu.json (rocprofv3 PMC passes of tools/profile_round.sh: SQ_INSTS_VALU, GRBM_GUI_ACTIVE; tools/clock_probe.hip beside the two-batch regime)"})
+    roofline["valu"] = valu
     if single:
         roofline["single_stream_chain_achieved_GBs"] = round(CHAIN_BYTES * single["value"] * 1e6 / world / 1e9, 2)
         roofline["single_stream_chain_frac"] = round(CHAIN_BYTES * single["value"] * 1e6 / world / 1e9 / HBM_PEAK_GBS, 6)
@@ -627,7 +641,7 @@ def main():
                    "parallelism": f"channels sharded contiguously over {world} GPU(s), global channel ids", "gather": gather_kind,
                    "steps_in_flight": F, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "hw_queue_advice": int(ctx.lib.m17hip_advice(ctx.h)), "prewarm_steps": args.prewarm, "batches": "pipelined" if args.stagger else "launched and waited for in groups",
                    "gathered_set_ordered_and_unique": gathered_ok, "tune": tuned or None,
-                   "redo_policy_two_batch_regime": ("m17hip_tune key 20 = 1 (redo in front of K5: throughput policy for batches in flight)" if policy20 else "default"),},
+                   "redo_policy": "library default (m17hip_tune key 20 = -1: chosen per run from what the process does, as K3's form is)"},
         "single_stream": single,
         "value_with_h2d": h2d["value_with_h2d"] if h2d else None, "h2d": h2d,
         "roofline": roofline, "cpu_baseline": cpu, "config2": config2,

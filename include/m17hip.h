@@ -315,12 +315,19 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  *        32 channels (1.8x shorter chain, four times the wave slots: stream latency), -1 (default) = the pipeline for runs whose front end
  *        was queued by m17hip_demod_front (a continued stream waits for K3's chain) and for runs of a process that has not overlapped runs
  *        of different contexts on this device lately (one batch at a time: 29 -> 26 ms per 4096 x 480 000), the one-wave form while it does.
- *        Same table either way.
- * key 20: what happens after a forced dcd.unlock() took a channel off the limit-filter replay: 0 (default) = the replay's state is re-derived
+ *        Same table either way.  NOTE: -1 consults PROCESS-WIDE state (a registry of the process's contexts on the device and their last
+ *        end-of-run events): the form, and with it a run's latency, depends on what other contexts of the process did lately — never a
+ *        result.  A host that needs the same latency whatever else the process runs pins 0 or 1.
+ * key 11: matched-filter kernel K1: 1 (default) = skewed accumulator pairs on a bounded grid (round 5), 0 = round 4's rolled form with one
+ *        workgroup per tile (kept for same-box comparisons; identical output).  key 13: workgroups of the bounded grid, 0 (default) = five
+ *        per compute unit.
+ * key 20: what happens after a forced dcd.unlock() took a channel off the limit-filter replay: 0 = the replay's state is re-derived
  *        beside the sequential kernel and the channel computes its own filter history through the next segment (the sequential kernel never
  *        waits: best wherever its chain of launches is what a step lasts — a continued stream, one batch at a time); 1 = the replay of the next
  *        segment is redone for those channels, history stored, IN FRONT of the sequential kernel (1-2 ms of replay latency on that chain, fewer
- *        instructions in all: 1.4 % more throughput when several independent batches are in flight).
+ *        instructions in all: 1.4 % more throughput when several independent batches are in flight); -1 (default) = chosen per run from the
+ *        same process-wide observation as key 10 = -1: in front while runs of several contexts of the process overlap, beside otherwise and for
+ *        every run queued through m17hip_demod_front.
  * key 15: 1 (default) = the sequential kernel leaves the payload frames of running stream / BERT transmissions undecoded (LLRs to a
  *        store, the record reserved) and a lane-per-frame kernel decodes them after the run; 0 = every frame is decoded where it completes.
  * key 17: 1 (default) = the running EVM of the diagnostic callback (RunningStandardDeviation: three dependent operations per payload symbol
@@ -331,7 +338,8 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * key 16: 1 = m17hip_upload_i16, m17hip_upload_i16_device and m17hip_synth_i16 write the context's STAGING slab (as
  *        m17hip_upload_i16_async does, but complete when they return) and stage it for the next run; 0 (default) = the current slab.
  * key 30 (tests): fault injection for m17hip_gather_frames*: 1 = this rank's compaction fails inside the call, 2 = the root's staging
- *        allocation fails; 0 = none.  Every rank still makes all its collective calls and returns the failure.
+ *        allocation fails, 3 = the root claims no room and this rank's word of the second exchange cannot be written; 0 = none.  Every rank
+ *        still makes all its collective calls and returns the failure.
  * The measurement build of the library (make -C m17-cxx-demod_amd/csrc tools -> libm17hip_tools.so, -DM17_TOOLS; tools/ only) adds
  * key 1 / key 19 (section timers / per-wave working times of the sequential kernel -> m17hip_debug_counters) and the schedule
  * experiments 4, 5, 12, 14, 21, 25 (csrc/m17hip.hip, m17hip_tune). */

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd SQLite result (`*_results.db`) into a per-kernel table:
 calls, total/avg/min/max duration and, when the run collected --pmc counters, the per-dispatch
-average of every counter.  Usage: rocpd_summary.py results.db [out.md]"""
+average of every counter over its hardware instances (`=value xN`: N instances per dispatch, total = value x N).  Usage: rocpd_summary.py results.db [out.md]"""
 import sqlite3
 import sys
 from collections import defaultdict
@@ -40,7 +40,8 @@ def main():
         lines.append("PMC counters (average per dispatch):")
         for k, cs in pmc.items():
             short = k.split("(")[0]
-            lines.append(f"- {short}: " + ", ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(cs.items())))
+            ncalls = len(stats[k])   # (a counter has one row per hardware instance and dispatch: `xN` = instances, total per dispatch = average x N)
+            lines.append(f"- {short}: " + ", ".join(f"{c}={sum(v)/len(v):.4g}x{len(v)//max(1, ncalls)}" for c, v in sorted(cs.items())))
     out = "\n".join(lines)
     print(out)
     if len(sys.argv) > 2:
