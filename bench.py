@@ -342,9 +342,12 @@ def main():
         c_.timing_reset()
     sync()
     t0 = time.perf_counter()
+    wall0 = time.time()
     total_frames = run_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
+    if rank == 0:   # (wall-clock bracket of the timed region on stderr: tools/clock_probe.hip's series is aligned with it)
+        print(f"timed region: epoch {wall0:.3f} .. {wall0 + dt:.3f}", file=sys.stderr)
     def max_over_ranks(v):
         if not multi:
             return v
@@ -641,7 +644,7 @@ def main():
                    "parallelism": f"channels sharded contiguously over {world} GPU(s), global channel ids", "gather": gather_kind,
                    "steps_in_flight": F, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "hw_queue_advice": int(ctx.lib.m17hip_advice(ctx.h)), "prewarm_steps": args.prewarm, "batches": "pipelined" if args.stagger else "launched and waited for in groups",
                    "gathered_set_ordered_and_unique": gathered_ok, "tune": tuned or None,
-                   "redo_policy": "library default (m17hip_tune key 20 = -1: chosen per run from what the process does, as K3's form is)"},
+                   "redo_policy": "library default (m17hip_tune key 20 = 0: beside K5)"},
         "single_stream": single,
         "value_with_h2d": h2d["value_with_h2d"] if h2d else None, "h2d": h2d,
         "roofline": roofline, "cpu_baseline": cpu, "config2": config2,

@@ -321,13 +321,13 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * key 11: matched-filter kernel K1: 1 (default) = skewed accumulator pairs on a bounded grid (round 5), 0 = round 4's rolled form with one
  *        workgroup per tile (kept for same-box comparisons; identical output).  key 13: workgroups of the bounded grid, 0 (default) = five
  *        per compute unit.
- * key 20: what happens after a forced dcd.unlock() took a channel off the limit-filter replay: 0 = the replay's state is re-derived
+ * key 20: what happens after a forced dcd.unlock() took a channel off the limit-filter replay: 0 (default) = the replay's state is re-derived
  *        beside the sequential kernel and the channel computes its own filter history through the next segment (the sequential kernel never
  *        waits: best wherever its chain of launches is what a step lasts — a continued stream, one batch at a time); 1 = the replay of the next
  *        segment is redone for those channels, history stored, IN FRONT of the sequential kernel (1-2 ms of replay latency on that chain, fewer
- *        instructions in all: 1.4 % more throughput when several independent batches are in flight); -1 (default) = chosen per run from the
- *        same process-wide observation as key 10 = -1: in front while runs of several contexts of the process overlap, beside otherwise and for
- *        every run queued through m17hip_demod_front.
+ *        instructions in all).  With round 4's matched filter 1 was 1.4 % faster when several independent batches were in flight; with
+ *        round 5's it is slower in every regime (two batches 22.6 against 21.4 ms per 4096 x 480 000, a continued stream 28.0 against 24.7,
+ *        one batch at a time 28.9 against 26.3: NOTES 5.5) and stays only as the other side of that comparison.
  * key 15: 1 (default) = the sequential kernel leaves the payload frames of running stream / BERT transmissions undecoded (LLRs to a
  *        store, the record reserved) and a lane-per-frame kernel decodes them after the run; 0 = every frame is decoded where it completes.
  * key 17: 1 (default) = the running EVM of the diagnostic callback (RunningStandardDeviation: three dependent operations per payload symbol

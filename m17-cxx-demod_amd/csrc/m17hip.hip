@@ -101,8 +101,7 @@ struct m17hip_ctx {
     int gather_fault = 0;             // tuning knob 30 (tests): 1 = this rank's compaction fails inside the gather, 2 = the root's staging allocation fails, 3 = its word of exchange 2 is not written
     uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
     uint32_t front_first = 0;         // tuning knob 12: segments of K1 that must be complete before the first K5 starts (0 = its own only)
-    int redo_form = -1;               // tuning knob 20: the replay's redo beside K5, state only (0), in front of K5 with the history stored (1), or chosen per run (-1, default: in front while the process overlaps batches)
-    bool run_overlapped = false;      // the run being queued was launched while another context's run was in flight lately (run registry below)
+    int redo_form = 0;                // tuning knob 20: the replay's redo beside K5, state only (0, default), or in front of K5 with the history stored (1)
     int dcd_form = -1;                // tuning knob 10: K3 as one wave per 32 channels (0), as the four-wave latency pipeline (1), or chosen per run (-1: the pipeline for runs queued by m17hip_demod_front)
     bool dcd_latency = false;         // what the launches of the run being queued use
     uint64_t seen_overlap = 0;        // (run registry below) the overlap count this context's previous run saw
@@ -1280,8 +1279,7 @@ static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, b
     int r = ensure_seg_events(c, c->slot, sp.nseg);
     if (r) return r;
     const uint32_t ahead = c->front_ahead ? c->front_ahead : sp.nseg;
-    c->run_overlapped = !from_front && runs_overlap(c);   // (a continued stream waits for its own chains whatever else is in flight)
-    c->dcd_latency = c->dcd_form < 0 ? !c->run_overlapped : c->dcd_form == 1;
+    c->dcd_latency = c->dcd_form < 0 ? (from_front || !runs_overlap(c)) : c->dcd_form == 1;
     c->front_segs = std::min(ahead, sp.nseg);
     for (uint32_t k = 0; k < c->front_segs; ++k)
         if ((r = launch_front_seg(c, sp, k, C, flags))) return r;
@@ -1418,8 +1416,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
         HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork, 0));
-        c->run_overlapped = runs_overlap(c);
-        c->dcd_latency = c->dcd_form < 0 ? !c->run_overlapped : c->dcd_form == 1;
+        c->dcd_latency = c->dcd_form < 0 ? !runs_overlap(c) : c->dcd_form == 1;
         c->front_segs = std::min(ahead, nseg);
         for (uint32_t k = 0; k < c->front_segs; ++k)
             if ((r = launch_front_seg(c, sp, k, C, flags))) return r;
@@ -1454,11 +1451,10 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     // k - 1 before K5(k) starts — sixteen channels per instruction instead of one wave each carrying the filter itself through segment k
     // (3 dependent instructions per sample): fewer instructions, but 1-2 ms of replay latency on the K5 chain of every segment that follows
     // a drop.  BESIDE K5: the redo re-derives the replay's end state only, the channels concerned serve themselves through segment k, K5
-    // never waits.  Measured (NOTES 4.11): wherever the chain of K5 launches is what a step lasts — a continued stream, one batch at a time —
-    // the redo beside K5 wins (24.3 against 27.3 ms, 28.6 against 30.5); several independent batches in flight, whose chains have slack
-    // and which are bound by the instruction total, are 1.4 % faster with the redo in front: the default is beside, a host that overlaps
-    // batches may ask for the other (bench.py does for its two-batch regime).
-    const bool redo_front = c->redo_form < 0 ? c->run_overlapped : c->redo_form == 1;
+    // never waits.  Measured: wherever the chain of K5 launches is what a step lasts — a continued stream, one batch at a time — the redo
+    // beside K5 wins (24.7 against 28.0 ms, 26.3 against 28.9); with round 4's matched filter several independent batches in flight were
+    // 1.4 % faster with the redo in front (NOTES 4.11), with round 5's they are 5 % slower (22.6 against 21.4: NOTES 5.5).  Default: beside.
+    const bool redo_front = c->redo_form == 1;
     // one wave per channel, four waves per workgroup
     constexpr uint32_t wpb = 4;
     const dim3 grid((C + wpb - 1) / wpb), block(64 * wpb);
@@ -2027,9 +2023,8 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         if (value < -1 || value > 1) return M17HIP_EINVAL;
         c->dcd_form = (int)value;
         return M17HIP_OK;
-    case 20:  // redo policy of the limit-filter replay: 0 = beside K5, state only; 1 = in front of K5, history stored; -1 (default) = per run: in front
-              // while runs of several contexts of the process overlap (the same observation that picks K3's form, key 10)
-        if (value < -1 || value > 1) return M17HIP_EINVAL;
+    case 20:  // redo policy of the limit-filter replay: 0 (default) = beside K5, state only; 1 = in front of K5, history stored
+        if (value < 0 || value > 1) return M17HIP_EINVAL;
         c->redo_form = (int)value;
         return M17HIP_OK;
     case 17:  // RunningStandardDeviation (the EVM of the diagnostic callback) folded outside K5, one lane per channel (1, default), or inside K5 (0)

@@ -204,7 +204,7 @@ def test_performance_knobs_do_not_change_results():
         c.reset(); c.run()
         assert c.frames().tobytes() == exp.tobytes(), settings
         for k in settings:
-            c.tune(k, {3: 48000, 15: 1, 10: -1, 20: -1, 17: 1, 11: 1, 13: 0}[k])   # back to the defaults
+            c.tune(k, {3: 48000, 15: 1, 10: -1, 20: 0, 17: 1, 11: 1, 13: 0}[k])   # back to the defaults
     import ctypes as C_
     for key in (0, 1, 2, 4, 5, 12, 14, 19, 21, 22, 25):
         assert c.lib.m17hip_tune(c.h, key, C_.c_int64(1)) == -1, key

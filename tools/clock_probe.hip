@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <vector>
 __global__ void probe(unsigned long long* out, int n, unsigned long long wall_step)
 {
@@ -24,6 +25,8 @@ int main(int argc, char** argv)
     const int n = (int)(seconds * 1e8 / step);
     unsigned long long* d;
     if (hipMalloc(&d, (size_t)n * 16) != hipSuccess) return 1;
+    timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+    printf("# host epoch at launch %.3f\n", ts.tv_sec + ts.tv_nsec * 1e-9);
     hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, d, n, step);
     if (hipDeviceSynchronize() != hipSuccess) return 2;
     std::vector<unsigned long long> h((size_t)n * 2);

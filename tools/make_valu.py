@@ -47,11 +47,17 @@ try:
 except Exception as e:   # noqa: BLE001
     j['k1_alone_whole_run'] = str(e)
 try:   # the two-batch regime of the default command with the probe beside it: the busy stretch = windows below 99 % of the idle clock
-    pts = [tuple(float(x) for x in l.split()) for l in open(f'{d}/clock_probe_default.tsv') if l[0] != '#' and len(l.split()) == 2]
-    top = max(c for _, c in pts)
-    busy = [c for _, c in pts if c < 0.97 * top]
-    j['clock_in_mix'] = {'idle_or_light_mhz': top, 'busy_windows': len(busy), 'busy_mean_mhz': sum(busy) / len(busy) if busy else None,
-                         'busy_min_mhz': min(busy) if busy else None, 'source': 'tools/clock_probe.hip beside `bench.py --steps 200` (two batches in flight), 10 ms windows'}
+    lines = open(f'{d}/clock_probe_default.tsv').read().splitlines()
+    e0 = float(re.search(r'epoch at launch ([0-9.]+)', lines[0]).group(1))
+    pts = [tuple(float(x) for x in l.split()) for l in lines if l and l[0] != '#' and len(l.split()) == 2]
+    m = re.search(r'timed region: epoch ([0-9.]+) \.\. ([0-9.]+)', open(f'{d}/clock_probe_default.err').read())
+    a, b = float(m.group(1)) - e0, float(m.group(2)) - e0          # the timed region on the probe's time axis (s)
+    busy = [c for t, c in pts if a + 0.05 <= t / 1e3 <= b - 0.05]
+    idle = [c for t, c in pts if t / 1e3 < a - 3.0]
+    j['clock_in_mix'] = {'idle_mhz': sum(idle) / len(idle) if idle else None, 'busy_windows': len(busy), 'busy_mean_mhz': sum(busy) / len(busy) if busy else None,
+                         'busy_min_mhz': min(busy) if busy else None, 'busy_max_mhz': max(busy) if busy else None,
+                         'source': 'tools/clock_probe.hip (one wave of another process: s_memtime against the 100 MHz wall clock, 10 ms windows) beside the timed region '
+                                   'of `bench.py --steps 200` (two batches in flight)'}
 except Exception as e:   # noqa: BLE001
     j['clock_in_mix'] = str(e)
 json.dump(j, open(out, 'w'), indent=1)

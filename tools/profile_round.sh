@@ -23,8 +23,8 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BU
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace -d $OUT/clk_k1 -o clk_k1 -- python3 $R/tools/k1_only.py > $OUT/clk_k1.log 2>&1
 # ... and in the real mix (no profiler): one wave of another process records shader cycles against the 100 MHz wall clock (tools/clock_probe.hip)
 # while the default command's two-batch regime runs (200 timed steps = 4 s)
-( sleep 12; $R/tools/clock_probe 8 > $OUT/clock_probe_default.tsv 2>&1 ) &
-python3 $R/bench.py --steps 200 --warmup 5 --prewarm 100 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0 --config2-steps 0 --single-stream 0 --one-at-a-time 0 > $OUT/clock_probe_default.log 2>&1
+$R/tools/clock_probe 40 > $OUT/clock_probe_default.tsv 2>&1 &
+python3 $R/bench.py --steps 200 --warmup 5 --prewarm 100 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0 --config2-steps 0 --single-stream 0 --one-at-a-time 0 > $OUT/clock_probe_default.log 2> $OUT/clock_probe_default.err
 wait
 # the default command (two batches in flight, then the single-stream regime), for the record
 rocprofv3 --kernel-trace --stats -d $OUT/trace_default -o trace_default -- python3 $R/bench.py --steps 4 --warmup 1 --prewarm 4 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0 --config2-steps 0 > $OUT/trace_default.log 2>&1
