@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--one-at-a-time-steps", type=int, default=2)
     ap.add_argument("--stream-groups", type=int, default=2, help="contexts the channels of the single-stream regime are split into (independent chains)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no launcher: print the N command lines / environments bench.py would start, and exit")
+    ap.add_argument("--bursty-steps", type=int, default=6, help="N = 1: steps of the bursty leg (the same 4096 x 480 000, every channel ONE transmission of a fifth of the run, "
+                    "loud noise for the rest: the carrier detect is off 80 % of the time) reported as `bursty`; 0 = skip")
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 code path (process group, communicators, gather per step) with WORLD_SIZE = 1")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # no launcher around us: be the launcher (before torch / the GPU are touched)
@@ -512,6 +514,37 @@ def main():
         seq_kern = kernel_times([ctx], KNAMES[:4], args.one_at_a_time_steps)
         ctx.timing(False)
 
+    # ---- bursty input (N = 1, outside the timed regions): what the chain does when the reference's carrier detect is OFF most of the time.
+    #      The reference runs neither the matched filter nor the correlator while it is (M17Demodulator.h:675-689) and gets ~10 x cheaper there;
+    #      here K1 and K3 still see every sample (the gate that would let K1 skip is the TRUE one, forced unlocks included, which
+    #      only K5 knows), K2 and K5 do not.  Same regime as `value` (the batches in flight, fresh demodulators every step); bit-exactness on it checked.
+    bursty = None
+    if not multi and args.bursty_steps > 0:
+        nb = max(1, int(0.2 * T / 1920) - 2)
+        pb = ol.gen_params(seed=20260102, kind=-1, n_frames=nb, lead_in=3072, noise_sigma=args.sigma, tail_sigma=20000.0, lead_sigma=40000.0, total=T)
+        for c_ in ctxs:
+            c_.synth(pb, C, T, chan0=rank * C)
+        run_steps(2 * F)
+        sync()
+        tb = time.perf_counter()
+        nfr = run_steps(args.bursty_steps)
+        sync()
+        dtb = (time.perf_counter() - tb) / args.bursty_steps
+        bpar = None
+        if args.parity_channels > 0:
+            k = min(16, C)
+            xb = ctxs[(args.bursty_steps - 1) % F].download()[:k]
+            got = ctxs[(args.bursty_steps - 1) % F].frames()
+            got = got[got["channel"] < k]
+            er, ec, _ = ol.demod_batch(xb, cap=2 * (T // 1920 + 2) + 4, threads=min(k, ncpu))
+            bpar = bool(got.tobytes() == np.concatenate([er[c, : ec[c]] for c in range(k)]).tobytes())
+        bursty = {"value": round(C * T / dtb / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtb * 1e3, 3), "steps": args.bursty_steps,
+                  "ratio_to_always_on": round((C * T / dtb / 1e6) / (C * T * args.steps / dt / 1e6), 3), "frames_decoded_per_step": int(nfr),
+                  "what": "every channel one transmission of %d frames (a fifth of the run) behind a loud lead-in, loud noise (sigma 20000) for the rest; "
+                          "%d batches in flight as for `value`" % (nb, F), "parity_vs_oracle_first_channels": bpar}
+        for c_ in ctxs:   # (the legs below run on the always-on input again)
+            c_.synth(p, C, T, chan0=rank * C)
+
     if rank != 0:
         for m_ in comms:
             m_.close()
@@ -647,7 +680,7 @@ def main():
                    "redo_policy": "library default (m17hip_tune key 20 = 0: beside K5)"},
         "single_stream": single,
         "value_with_h2d": h2d["value_with_h2d"] if h2d else None, "h2d": h2d,
-        "roofline": roofline, "cpu_baseline": cpu, "config2": config2,
+        "roofline": roofline, "cpu_baseline": cpu, "config2": config2, "bursty": bursty,
     }
     for m_ in comms:
         m_.close()

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=16
 # ONE step strictly after the other (--in-flight 1, no single-stream leg, no extra one-at-a-time pass): every launch in the trace is in
 # the regime bench.py's `roofline` object is computed from, so the kernel_trace_stats average and the line's kernel_ms_per_launch agree
-ARGS="--in-flight 1 --single-stream 0 --one-at-a-time 0 --steps 4 --warmup 1 --prewarm 0 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0 --config2-steps 0"
+ARGS="--in-flight 1 --single-stream 0 --one-at-a-time 0 --steps 4 --warmup 1 --prewarm 0 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0 --config2-steps 0 --bursty-steps 0"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
@@ -24,10 +24,10 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BU
 # ... and in the real mix (no profiler): one wave of another process records shader cycles against the 100 MHz wall clock (tools/clock_probe.hip)
 # while the default command's two-batch regime runs (200 timed steps = 4 s)
 $R/tools/clock_probe 40 > $OUT/clock_probe_default.tsv 2>&1 &
-python3 $R/bench.py --steps 200 --warmup 5 --prewarm 100 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0 --config2-steps 0 --single-stream 0 --one-at-a-time 0 > $OUT/clock_probe_default.log 2> $OUT/clock_probe_default.err
+python3 $R/bench.py --steps 200 --warmup 5 --prewarm 100 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0 --config2-steps 0 --bursty-steps 0 --single-stream 0 --one-at-a-time 0 > $OUT/clock_probe_default.log 2> $OUT/clock_probe_default.err
 wait
 # the default command (two batches in flight, then the single-stream regime), for the record
-rocprofv3 --kernel-trace --stats -d $OUT/trace_default -o trace_default -- python3 $R/bench.py --steps 4 --warmup 1 --prewarm 4 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0 --config2-steps 0 > $OUT/trace_default.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace_default -o trace_default -- python3 $R/bench.py --steps 4 --warmup 1 --prewarm 4 --cpu-seconds 0 --parity-channels 0 --h2d-steps 0 --config2-steps 0 --bursty-steps 0 > $OUT/trace_default.log 2>&1
 # BASELINE configs[1] (the `config2` object of the default line): FIR + correlator, 1024 x 480 000
 rocprofv3 --kernel-trace --stats -d $OUT/trace_config2 -o trace_config2 -- python3 $R/bench.py --config 2 --steps 3 --warmup 1 --cpu-seconds 0 --parity-channels 0 > $OUT/trace_config2.log 2>&1
 for p in trace fetch write sq clk clk_k1 trace_default trace_config2; do
