@@ -32,6 +32,7 @@ __device__ __forceinline__ void dp_handover()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+#ifdef M17_TOOLS   // round 4's K1, kept in the measurement build only (same-box comparisons against the skewed-pair form below)
 // =====================================================================================================
 // K1  fir_rrc150_kernel  — reference a1 + a2: apps/m17-demod.cpp:486-489, FirFilter.h:28-43.
 //
@@ -150,9 +151,12 @@ __global__ __launch_bounds__(FIR_THREADS, MINW) void fir_rrc150_rolled_kernel(co
     }
 }
 
+#endif  // M17_TOOLS
+
 // =====================================================================================================
-// K1, skewed-pair form (round 5)  fir_rrc150_skew_kernel — the same a1 + a2, the same products and the same additions in the same
-// order, with every VALU instruction of the tap loop a FULL packed operation and no register moves:
+// K1  fir_rrc150_skew_kernel — reference a1 + a2: apps/m17-demod.cpp:486-489 (scaling), FirFilter.h:28-43 (y[t] = sum_{i=0}^{148} taps[i] x[t-i],
+// accumulated sequentially i = 0..148 in fp32, multiply and add rounded separately; tap 149 is 0.0 and contributes a signed zero only).
+// Skewed accumulator pairs (round 5): the same products and the same additions in the same order as the reference's loop, with every VALU instruction of the tap loop a FULL packed operation and no register moves:
 //
 //   * a lane owns SIXTEEN consecutive outputs as eight accumulator pairs (2q, 2q + 1).  Output o at tap i reads sample o - i, so the
 //     even output of a pair at tap u and the odd one at tap u + 1 read the SAME sample: one v_pk_mul_f32 forms

@@ -120,7 +120,7 @@ struct m17hip_ctx {
     DecodeTables* tables = nullptr;
     float* taps = nullptr;
     float* taps_skew = nullptr;      // tap table of fir_rrc150_skew_kernel (fs_build_tap_table)
-    int fir_form = 1;                // K1: 1 = skewed-pair form on a bounded grid (default), 0 = the rolled R = 15 form, one workgroup per tile (tools build: key 11)
+    int fir_form = 1;                // (tools build, key 11) K1: 1 = skewed-pair form on a bounded grid, 0 = round 4's rolled R = 15 form, one workgroup per tile
     uint32_t fir_grid = 0;           // workgroups of the bounded grid (0 = default: FIR_GRID_PER_CU per CU)
     uint32_t n_cu = 256;
     uint32_t* defer_llr = nullptr;   // [maxC][rec_cap_alloc][46]: LLR frames (nibbles) K5 leaves for decode_deferred_kernel (tune 15)
@@ -612,10 +612,13 @@ constexpr uint32_t FIR_GRID_PER_CU = 5;   // workgroups of the bounded K1 grid p
 int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0)
 {
     Timed tm(c, KT_FIR, st);
-    if (c->fir_form == 0) {
+#ifdef M17_TOOLS
+    if (c->fir_form == 0) {   // round 4's kernel: the measurement build keeps it for same-box comparisons (tools/k1_forms.py, the clk_k1 pass of tools/profile_round.sh)
         dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C);
         hipLaunchKernelGGL((fir_rrc150_rolled_kernel<FIR_R, 4>), grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
-    } else {
+    } else
+#endif
+    {
         const uint32_t tiles = (T + FS_TILE - 1) / FS_TILE;
         const uint64_t items64 = (uint64_t)tiles * C;
         if (items64 > 0xFFFFFFFFull) return M17HIP_EINVAL;
@@ -2051,15 +2054,15 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 16:  // the in-place producers (m17hip_upload_i16, m17hip_upload_i16_device, m17hip_synth_i16) write the STAGING slab instead
         c->stage_inputs = value != 0;
         return M17HIP_OK;
-    case 11:  // K1 form: 1 (default) = skewed pairs on a bounded grid, 0 = rolled R = 15 form with one workgroup per tile (round 4's; kept for same-box A/B until the round ends)
-        if (value < 0 || value > 1) return M17HIP_EINVAL;
-        c->fir_form = (int)value;
-        return M17HIP_OK;
     case 13:  // workgroups of K1's bounded grid (0 = default)
         if (value < 0 || value > (1 << 20)) return M17HIP_EINVAL;
         c->fir_grid = (uint32_t)value;
         return M17HIP_OK;
 #ifdef M17_TOOLS
+    case 11:  // K1 form: 1 (default) = skewed pairs on a bounded grid, 0 = round 4's rolled R = 15 form with one workgroup per tile
+        if (value < 0 || value > 1) return M17HIP_EINVAL;
+        c->fir_form = (int)value;
+        return M17HIP_OK;
     // ---- measurement / experiment knobs: only in the tools build (make -C csrc tools -> libm17hip_tools.so), used by tools/*.py ------
     case 1:  // section timers and counters of the sequential kernel (PROF instantiation; one segment per run) -> m17hip_debug_counters
         c->profile = value != 0;

@@ -2,6 +2,7 @@
 several sizes (key 13), whole run and as ten segments; outputs compared bit for bit between the forms.
     python tools/k1_forms.py [lib.so ...]        (every library in its own process when several are given)"""
 import os, subprocess, sys, time
+import _toolslib  # noqa: F401  (key 11 = round 4's kernel exists in the measurement build only)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def worker():
@@ -44,7 +45,7 @@ def worker():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == '--worker':
         worker(); sys.exit(0)
-    libs = sys.argv[1:] or [os.path.join(ROOT, 'm17-cxx-demod_amd', 'libm17hip.so')]
+    libs = sys.argv[1:] or [os.path.join(ROOT, 'm17-cxx-demod_amd', 'libm17hip_tools.so')]
     for lib in libs:
         print('==', lib, flush=True)
         env = dict(os.environ, M17HIP_LIB=os.path.abspath(lib))

@@ -1,6 +1,8 @@
 """K1 alone, ten launches over 4096 x 480 000 samples per form (round 4's rolled kernel: m17hip_tune key 11 = 0; the skewed-pair kernel), for the
 PMC pass that measures the clock the chip holds under it (GRBM_GUI_ACTIVE / duration): tools/profile_round.sh."""
 import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _toolslib  # noqa: F401  (key 11 = round 4's kernel exists in the measurement build only)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: F401

@@ -20,7 +20,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SA
 # the clock the chip holds: GRBM_GUI_ACTIVE (cycles the GPU was active during a dispatch) / the dispatch's duration, with the VALU-busy counter
 # beside it — per kernel of the chain (dispatches are serialised under counter collection: each kernel ALONE), and for K1 alone in both forms
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace -d $OUT/clk -o clk -- python3 $R/bench.py $ARGS > $OUT/clk.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace -d $OUT/clk_k1 -o clk_k1 -- python3 $R/tools/k1_only.py > $OUT/clk_k1.log 2>&1
+M17HIP_LIB=$R/m17-cxx-demod_amd/libm17hip_tools.so rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace -d $OUT/clk_k1 -o clk_k1 -- python3 $R/tools/k1_only.py > $OUT/clk_k1.log 2>&1
 # ... and in the real mix (no profiler): one wave of another process records shader cycles against the 100 MHz wall clock (tools/clock_probe.hip)
 # while the default command's two-batch regime runs (200 timed steps = 4 s)
 $R/tools/clock_probe 40 > $OUT/clock_probe_default.tsv 2>&1 &
