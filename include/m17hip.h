@@ -333,6 +333,9 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  *        (4 B x samples / 10 per channel of device memory), one lane per channel folds them in the reference's order as extra workgroups of
  *        the limit-filter replay / the deferred decode, and m17_diag::evm and the diagnostic log carry the same values as with 0 = folded in
  *        the sequential kernel, symbol by symbol.  Can be changed between runs.
+ * key 18 (tests): floats per channel row of deferred EVM operations (key 17), 0 (default) = what a run of max_samples can produce; with a
+ *        smaller row a channel outruns it, the operations beyond are dropped and m17hip_diag_fetch / m17hip_diag_log_fetch return
+ *        M17HIP_EOVERFLOW (every diagnostic field but `evm` is still right; the frame records are not affected).
  * key 16: 1 = m17hip_upload_i16, m17hip_upload_i16_device and m17hip_synth_i16 write the context's STAGING slab (as
  *        m17hip_upload_i16_async does, but complete when they return) and stage it for the next run; 0 (default) = the current slab.
  * key 30 (tests): fault injection for m17hip_gather_frames*: 1 = this rank's compaction fails inside the call, 2 = the root's staging

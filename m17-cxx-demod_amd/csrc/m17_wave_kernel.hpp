@@ -1398,7 +1398,10 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     for (int k = wl; k < 92; k += 64) gs->llr[k] = DL.llr[k];
     for (int k = wl; k < 8; k += 64) gs->lsf[k] = DL.lsf[k];
     P.rec_count[c] = cd->n_run;
-    if (P.ev_cursor_out && wl == 0) P.ev_cursor_out[c] = cd->ev_cursor;
+    if (P.ev_cursor_out && wl == 0) {
+        P.ev_cursor_out[c] = cd->ev_cursor;
+        if (cd->ev_cursor > P.ev_pitch) atomicOr(P.overflow + 2, 1u);   // operations were dropped: the EVM of this run's diagnostics is not to be trusted (m17hip_diag_fetch says so)
+    }
     if (P.diag_log && wl == 0) P.diag_count[c] = cd->n_diag_run;
     if constexpr (TIMED) if (wl == 0) {
         unsigned long long* slot = P.dbg + (size_t)c * DBG_SLOTS + ((P.flags >> 8) & 31u);

@@ -130,6 +130,7 @@ struct m17hip_ctx {
     bool defer_evm = true;
     float* ev_ops = nullptr;         // [maxC][ev_pitch] operations of the current run (lazily allocated)
     uint32_t ev_pitch = 0;
+    uint32_t ev_pitch_override = 0;  // tuning knob 18 (tests): floats per operation row instead of ev_row_floats(maxT)
     uint32_t* ev_cur = nullptr;      // [2][maxC] K5's operation cursor at the end of a segment, by segment parity
     EvState* ev_state = nullptr;     // [maxC]
     uint32_t seq_lds_bytes = 0; // tune 14: LDS bytes a workgroup of the sequential kernel asks for (0 = SEQ_LDS_BYTES_4 for four waves)
@@ -1429,7 +1430,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipMalloc((void**)&c->defer_hist, (size_t)c->maxC * DEFER_HIST_WORDS * 64 * sizeof(uint32_t)));
     }
     if (c->defer_evm && !c->ev_ops) {   // the operation rows of the deferred EVM: 4 B per symbol of the longest run
-        c->ev_pitch = ev_row_floats(c->maxT);
+        c->ev_pitch = c->ev_pitch_override ? c->ev_pitch_override : ev_row_floats(c->maxT);
         HIPCHK(c, hipMalloc((void**)&c->ev_ops, (size_t)c->maxC * c->ev_pitch * sizeof(float)));
     }
     c->dbg_waves = (c->profile || c->wave_times) ? C : 0;
@@ -1639,8 +1640,10 @@ int m17hip_diag_fetch(m17hip_ctx* c, m17_diag* diag_host, uint32_t C)
     GUARD(c);
     HIPCHK(c, hipMemcpy2DAsync(diag_host, sizeof(Diag), &c->seq_state[0].cold.diag, sizeof(SeqState), sizeof(Diag), C, hipMemcpyDeviceToHost,
                                c->stream));
+    uint32_t ovf[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(ovf, c->overflow, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return M17HIP_OK;
+    return ovf[2] ? M17HIP_EOVERFLOW : M17HIP_OK;   // (a channel outran its row of deferred EVM operations: every field but `evm` is right)
 }
 
 int m17hip_diag_log_fetch(m17hip_ctx* c, m17_diag* log_host, uint32_t* counts_host, uint32_t C, uint32_t capacity)
@@ -1653,6 +1656,9 @@ int m17hip_diag_log_fetch(m17hip_ctx* c, m17_diag* log_host, uint32_t* counts_ho
     HIPCHK(c, hipMemcpy2DAsync(log_host, (size_t)capacity * sizeof(Diag), c->diag_log, (size_t)c->diag_cap * sizeof(Diag), (size_t)n * sizeof(Diag), C,
                                hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t ovf[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpy(ovf, c->overflow, 16, hipMemcpyDeviceToHost));
+    if (ovf[2]) return M17HIP_EOVERFLOW;   // (deferred EVM operations were dropped: see m17hip_diag_fetch)
     bool trunc = false;
     for (uint32_t i = 0; i < C; ++i) trunc = trunc || counts_host[i] > n;
     return trunc ? M17HIP_ETRUNC : M17HIP_OK;
@@ -2038,6 +2044,12 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
             HIPCHK(c, hipGetLastError());
             if (!c->defer_evm && c->ev_ops) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_dev(c->ev_ops, &c->last_hip); }
         }
+        return M17HIP_OK;
+    case 18:  // (tests) floats per channel row of deferred EVM operations, 0 = what a run of max_samples can produce: a smaller value makes the overflow flag reachable
+        if (value < 0 || value > (1 << 28) || (value & 3)) return M17HIP_EINVAL;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        free_dev(c->ev_ops, &c->last_hip);
+        c->ev_pitch_override = (uint32_t)value;
         return M17HIP_OK;
     case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1, default), or in K5 (0)
         c->defer_decode = value != 0;

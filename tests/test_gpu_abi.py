@@ -211,6 +211,86 @@ def test_performance_knobs_do_not_change_results():
     c.close()
 
 
+_TOOLS_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join({root!r}, "m17-cxx-demod_amd")); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch  # noqa: F401
+import m17hip, oracle_lib as ol
+T = 96000
+p = ol.gen_params(seed=5, kind=-1, n_frames=T // 1920 - 4, lead_in=3072, noise_sigma=900.0, tail_sigma=900.0, lead_sigma=40000.0, total=T)
+x = ol.generate_batch(p, 24, T, threads=8)
+recs, counts, _ = ol.demod_batch(x, cap=2 * (T // 1920 + 2) + 4, threads=8)
+exp = np.concatenate([recs[c, :counts[c]] for c in range(24)]).tobytes()
+c = m17hip.Context(24, T)
+defaults = {{4: 0, 5: 0, 11: 1, 12: 0, 14: 0, 21: 0, 25: 1}}
+for settings in ({{11: 0}}, {{5: 2}}, {{12: 3}}, {{14: 32640}}, {{4: 9600}}, {{5: 1, 12: 2, 4: 4800}}):
+    for k, v in settings.items(): c.tune(k, v)
+    c.upload(x); c.reset(); c.run()
+    assert c.frames().tobytes() == exp, settings
+    for k in settings: c.tune(k, defaults[k])
+# the knobs of the staged path: K1 of a staged run held back (21), the first replay not queued by m17hip_demod_front (25)
+for settings in ({{21: 2}}, {{25: 0}}, {{21: 1, 25: 0}}):
+    for k, v in settings.items(): c.tune(k, v)
+    c.reset()
+    got = []
+    cuts = (0, 31000, 66000, T)     # three runs, the second and third staged and queued through m17hip_demod_front
+    for i in range(3):
+        lo, hi = cuts[i], cuts[i + 1]
+        if i == 0:
+            c.upload(np.ascontiguousarray(x[:, lo:hi]))
+        else:
+            c.tune(16, 1); c.upload(np.ascontiguousarray(x[:, lo:hi])); c.tune(16, 0)
+            c.front()
+            got.append(c.frames())
+        c.run()
+    got.append(c.frames())
+    g = np.concatenate(got)
+    g = g[np.lexsort((g["seq"], g["channel"]))]
+    assert g.tobytes() == exp, settings
+    for k in settings: c.tune(k, defaults[k])
+print("tools-build knobs ok")
+"""
+
+
+def test_measurement_build_knobs_do_not_change_results(tmp_path):
+    """the schedule-experiment members of the context (front_ahead, front_first, seq_lds_bytes, front_k1_after, gate0_early, the
+    first-segment length, round 4's K1) can only be set in the measurement build (libm17hip_tools.so, -DM17_TOOLS): drive their non-default
+    branches there and compare with the oracle, in a process of its own (this one has the production library loaded)."""
+    lib = os.path.join(ROOT, "m17-cxx-demod_amd", "libm17hip_tools.so")
+    if not os.path.exists(lib):
+        pytest.skip("measurement build not made (make -C m17-cxx-demod_amd/csrc tools)")
+    script = tmp_path / "w.py"
+    script.write_text(_TOOLS_WORKER.format(root=ROOT))
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, M17HIP_LIB=lib), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "tools-build knobs ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_deferred_evm_row_overflow_is_reported_not_silent():
+    """the rows of deferred EVM operations (m17hip_tune key 17) are sized for what a run can produce; should a channel ever
+    outrun its row, the operations beyond are dropped — m17hip_diag_fetch must SAY so (M17HIP_EOVERFLOW) instead of handing out a wrong
+    EVM.  Key 18 (tests) shrinks the rows to make that reachable; the frame records are unaffected, and with the default rows the same
+    run reports nothing."""
+    x = _signals(8, 48000, seed=33)
+    exp = _oracle_flat(x)
+    c = m17hip.Context(8, 48000)
+    d = np.zeros(8, dtype=m17hip.DIAG)
+    c.upload(x); c.reset(); c.run()
+    assert c.lib.m17hip_diag_fetch(c.h, d.ctypes.data_as(C.c_void_p), C.c_uint32(8)) == 0
+    good = d.copy()
+    c.tune(18, 64)                       # 64 operations per channel: a 48 000-sample run writes thousands
+    c.reset(); c.run()
+    assert c.frames().tobytes() == exp.tobytes()
+    assert c.lib.m17hip_diag_fetch(c.h, d.ctypes.data_as(C.c_void_p), C.c_uint32(8)) == -5
+    for f in d.dtype.names:
+        if f != "evm":
+            assert np.array_equal(d[f], good[f]), f
+    c.tune(18, 0)
+    c.reset(); c.run()                   # (the reset clears the flag)
+    assert c.lib.m17hip_diag_fetch(c.h, d.ctypes.data_as(C.c_void_p), C.c_uint32(8)) == 0 and d.tobytes() == good.tobytes()
+    c.close()
+
+
 def test_rccl_gather_single_rank():
     """m17hip_comm_* / m17hip_gather_frames with a 1-rank communicator: RCCL is bound, the counts all-gather and the
     compaction run, the root receives its own records."""

@@ -81,6 +81,8 @@ def test_pipelined_runs_from_device_memory(ctx):
     x = _signals(Cn, n * T, seed=102, sigma=800.0)
     exp, diags = _oracle(x)
     dev = torch.from_numpy(x).cuda()               # [Cn][n * T]: chunk k = columns [k T, (k + 1) T), row pitch n * T
+    torch.cuda.synchronize()                       # the producer's buffer is COMPLETE before it is handed over: a copy from pageable memory may still be in
+                                                   # flight when .cuda() returns, and the context's copy stream does not wait for torch's (seen once in ~15 full runs)
     got = _pipelined(ctx, Cn, [T] * n, lambda k: ctx.upload_device_async(dev.data_ptr() + 2 * k * T, Cn, T, pitch=n * T))
     ctx.upload_wait()
     assert got.tobytes() == exp.tobytes() and got.size > 3 * Cn
