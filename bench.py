@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--one-at-a-time-steps", type=int, default=2)
     ap.add_argument("--stream-groups", type=int, default=2, help="contexts the channels of the single-stream regime are split into (independent chains)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no launcher: print the N command lines / environments bench.py would start, and exit")
+    ap.add_argument("--duty", type=float, default=1.0, help="experiments: every channel's transmission covers this fraction of a run, loud noise for the rest (1 = BASELINE's "
+                    "always-on workload; the `bursty` leg of the default line is 0.2)")
     ap.add_argument("--bursty-steps", type=int, default=6, help="N = 1: steps of the bursty leg (the same 4096 x 480 000, every channel ONE transmission of a fifth of the run, "
                     "loud noise for the rest: the carrier detect is off 80 % of the time) reported as `bursty`; 0 = skip")
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 code path (process group, communicators, gather per step) with WORLD_SIZE = 1")
@@ -207,8 +209,8 @@ def main():
 
     # ---- synthetic input (seeded; even channels BERT, odd channels voice-like streams; loud lead-in, AWGN) -----------
     t_gen = time.time()
-    p = ol.gen_params(seed=20260101, kind=-1, n_frames=max(1, T // 1920 - 6), lead_in=3072, noise_sigma=args.sigma,
-                      tail_sigma=args.sigma, lead_sigma=40000.0, total=T)
+    p = ol.gen_params(seed=20260101, kind=-1, n_frames=max(1, int(args.duty * T / 1920) - (6 if args.duty >= 1.0 else 2)), lead_in=3072, noise_sigma=args.sigma,
+                      tail_sigma=args.sigma if args.duty >= 1.0 else 20000.0, lead_sigma=40000.0, total=T)
     F = max(1, args.in_flight) if args.config == 3 else 1
     ctxs, streams, tuned = [], [], {}
     for f in range(F):   # F independent batches of C channels, each with its own device slabs and streams
@@ -525,11 +527,17 @@ def main():
         for c_ in ctxs:
             c_.synth(pb, C, T, chan0=rank * C)
         run_steps(2 * F)
+        for c_ in ctxs:
+            c_.timing(True); c_.timing_reset()
         sync()
         tb = time.perf_counter()
         nfr = run_steps(args.bursty_steps)
         sync()
         dtb = (time.perf_counter() - tb) / args.bursty_steps
+        for c_ in ctxs:
+            c_.timing(False)
+        bkern = kernel_times(ctxs, KNAMES, args.bursty_steps)
+        ndrop = int(ctxs[0].replay_drops()) if hasattr(ctxs[0], "replay_drops") else None
         bpar = None
         if args.parity_channels > 0:
             k = min(16, C)
@@ -540,6 +548,7 @@ def main():
             bpar = bool(got.tobytes() == np.concatenate([er[c, : ec[c]] for c in range(k)]).tobytes())
         bursty = {"value": round(C * T / dtb / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtb * 1e3, 3), "steps": args.bursty_steps,
                   "ratio_to_always_on": round((C * T / dtb / 1e6) / (C * T * args.steps / dt / 1e6), 3), "frames_decoded_per_step": int(nfr),
+                  "kernel_ms": {k_: round(v["ms_per_step"], 3) for k_, v in bkern.items()},
                   "what": "every channel one transmission of %d frames (a fifth of the run) behind a loud lead-in, loud noise (sigma 20000) for the rest; "
                           "%d batches in flight as for `value`" % (nb, F), "parity_vs_oracle_first_channels": bpar}
         for c_ in ctxs:   # (the legs below run on the always-on input again)
@@ -668,7 +677,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (generated on the device)",
         "value_single_stream": single["value"] if single else None, "ms_per_step_single_stream": single["ms_per_step"] if single else None,
-        "config": {"workload": "configs[2]: full demod chain incl. Viterbi/Trellis, %d channels x %d samples per step and GPU, bit-exact frame check; "
+        "config": {"duty": args.duty, "workload": "configs[2]: full demod chain incl. Viterbi/Trellis, %d channels x %d samples per step and GPU, bit-exact frame check; "
                                "`value`: %d INDEPENDENT batches of that size resident and in flight per GPU (fresh demodulators every step); "
                                "`value_single_stream`: one batch, the same channels continued run after run" % (C, T, F),
                    "channels_per_gpu": C, "channels_resident_per_gpu": C * F, "samples_per_channel": T, "awgn_sigma_lsb": args.sigma, "frames_decoded_per_step": total_frames,

@@ -109,7 +109,9 @@ int m17hip_upload_i16_async(m17hip_ctx* ctx, const int16_t* host, uint32_t chann
 /* Block until the copy queued by the last m17hip_upload_i16_async / m17hip_upload_i16_device_async has left its source buffer. */
 int m17hip_upload_wait(m17hip_ctx* ctx);
 /* The same staging from DEVICE memory (a producer on the GPU hands a chunk over): a device-to-device copy on the context's copy
- * stream, NOT complete when the call returns — `dev` must stay valid and unmodified until m17hip_upload_wait has returned. */
+ * stream, NOT complete when the call returns — `dev` must stay valid and unmodified until m17hip_upload_wait has returned.  The copy
+ * stream does not wait for the producer's stream: `dev` must be COMPLETE when the call is made (the producer synchronised, or the hand-over
+ * ordered by the caller). */
 int m17hip_upload_i16_device_async(m17hip_ctx* ctx, const int16_t* dev, uint32_t channels, uint32_t samples, size_t pitch);
 /* Staging without a copy: declares that the context's second input slab — the one the run BEFORE the latest run consumed, or
  * that an earlier m17hip_upload_i16_async filled — already holds the next run's `channels` x `samples` input (two resident slabs
