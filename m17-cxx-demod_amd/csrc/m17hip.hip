@@ -678,7 +678,7 @@ int m17hip_advice(const m17hip_ctx* ctx)
     const char* q = std::getenv("GPU_MAX_HW_QUEUES");
     return (!q || std::atoi(q) < 8) ? M17HIP_ADVICE_HW_QUEUES : 0;
 }
-int m17hip_version(void) { return 400; }
+int m17hip_version(void) { return 500; }
 
 int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out)
 {

@@ -1,7 +1,5 @@
-B="python bench.py --steps 10 --warmup 3 --prewarm 20 --cpu-seconds 0 --h2d-steps 0 --config2-steps 0 --single-stream 0 --parity-channels 0 --one-at-a-time 0 --bursty-steps 10"
-P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["ms_per_step"], d["bursty"]["ms_per_step"], d["bursty"]["ratio_to_always_on"])'
-$B 2>/dev/null | python3 -c "$P" "default"
-$B --tune 10=1 2>/dev/null | python3 -c "$P" "k3_latency_form"
-$B --in-flight 3 2>/dev/null | python3 -c "$P" "inflight3"
-$B --in-flight 4 --tune 10=1 2>/dev/null | python3 -c "$P" "inflight4_k3lat"
-$B --in-flight 1 2>/dev/null | python3 -c "$P" "inflight1"
+for r in 1 2; do
+for L in tools/ab/libm17hip_k3base.so tools/ab/libm17hip_k3ring.so; do
+  M17HIP_LIB=$PWD/$L python bench.py --steps 10 --warmup 3 --cpu-seconds 0 --h2d-steps 0 --config2-steps 0 --bursty-steps 0 --parity-channels 0 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d['ms_per_step'], d['ms_per_step_single_stream'], d['roofline']['ms_per_step'], d['roofline']['kernel_ms_per_launch']['dcd'])" $L
+done; done
