@@ -320,7 +320,8 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  *        Same table either way.  NOTE: -1 consults PROCESS-WIDE state (a registry of the process's contexts on the device and their last
  *        end-of-run events): the form, and with it a run's latency, depends on what other contexts of the process did lately — never a
  *        result.  A host that needs the same latency whatever else the process runs pins 0 or 1.
- * key 13: workgroups of the matched filter's bounded grid (K1 loops over (channel, tile) items), 0 (default) = five per compute unit.
+ * key 13: workgroups of the matched filter's grid (a K1 workgroup loops over (channel, tile) items), 0 (default) = about three items per workgroup
+ *        for runs that get K3's latency form (key 10), eight for the others, at least five workgroups per compute unit.
  * key 20: what happens after a forced dcd.unlock() took a channel off the limit-filter replay: 0 (default) = the replay's state is re-derived
  *        beside the sequential kernel and the channel computes its own filter history through the next segment (the sequential kernel never
  *        waits: best wherever its chain of launches is what a step lasts — a continued stream, one batch at a time); 1 = the replay of the next

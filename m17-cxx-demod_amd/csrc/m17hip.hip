@@ -121,7 +121,8 @@ struct m17hip_ctx {
     float* taps = nullptr;
     float* taps_skew = nullptr;      // tap table of fir_rrc150_skew_kernel (fs_build_tap_table)
     int fir_form = 1;                // (tools build, key 11) K1: 1 = skewed-pair form on a bounded grid, 0 = round 4's rolled R = 15 form, one workgroup per tile
-    uint32_t fir_grid = 0;           // workgroups of the bounded grid (0 = default: FIR_GRID_PER_CU per CU)
+    uint32_t fir_grid = 0;           // tuning knob 13: workgroups of K1's grid (0 = default: from the items per workgroup below)
+    bool fir_latency = false;        // the run being queued is one whose chain of K5 launches decides (= it gets K3's latency form): few items per K1 workgroup
     uint32_t n_cu = 256;
     uint32_t* defer_llr = nullptr;   // [maxC][rec_cap_alloc][46]: LLR frames (nibbles) K5 leaves for decode_deferred_kernel (tune 15)
     uint32_t* defer_hist = nullptr;  // [maxC][101][64]: that kernel's decision words
@@ -609,7 +610,12 @@ __global__ void compact_kernel(const FrameRec* recs, uint32_t rec_cap, const uin
 
 // t0: first sample of the slab to process (segment of a run); the kernels see the slab from there on
 constexpr size_t SEQ_LDS_BYTES_4 = 34816;   // see the K5 launch
-constexpr uint32_t FIR_GRID_PER_CU = 5;   // workgroups of the bounded K1 grid per CU: what a CU holds of them when it has nothing else to do
+// K1's grid.  A workgroup loops over (channel, tile) items; how many it takes decides how long it holds its place on a CU, i.e. how long a K5
+// launch that becomes ready waits for room: 38 items per workgroup (five workgroups per CU) cost a continued stream 1.5 ms per step and one batch
+// at a time 2 ms against 3 items per workgroup, while two batches in flight are 2 % faster with 6-12 than with 3 (NOTES 5.7).  So: about three
+// items per workgroup for the runs that get the latency form of K3 (a continued stream, or nothing else in flight), eight for the others, and
+// never fewer workgroups than a CU can hold of them five times over.
+constexpr uint32_t FIR_GRID_PER_CU = 5, FIR_ITEMS_LATENCY = 3, FIR_ITEMS_THROUGHPUT = 8;
 int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0)
 {
     Timed tm(c, KT_FIR, st);
@@ -624,7 +630,8 @@ int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_
         const uint64_t items64 = (uint64_t)tiles * C;
         if (items64 > 0xFFFFFFFFull) return M17HIP_EINVAL;
         const uint32_t items = (uint32_t)items64;
-        const uint32_t cap = c->fir_grid ? c->fir_grid : FIR_GRID_PER_CU * c->n_cu;
+        const uint32_t per = c->fir_latency ? FIR_ITEMS_LATENCY : FIR_ITEMS_THROUGHPUT;
+        const uint32_t cap = c->fir_grid ? c->fir_grid : std::max(FIR_GRID_PER_CU * c->n_cu, (items + per - 1) / per);
         const dim3 grid(std::min(items, cap));
         if (flags & 1u)
             hipLaunchKernelGGL(fir_rrc150_skew_kernel<true>, grid, dim3(FS_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, c->taps_skew, tiles, items);
@@ -989,6 +996,7 @@ int m17hip_fir_rrc150(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, flo
     GUARD(c);
     if (c->front_pending) return M17HIP_ESTATE;
     if (!c->uploaded) return M17HIP_ESTATE;
+    c->fir_latency = false;   // (an operator call: the whole chip is its own)
     int r = launch_fir(c, C, T, flags, c->stream);
     if (r) return r;
     if (out_host) {
@@ -1284,6 +1292,7 @@ static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, b
     if (r) return r;
     const uint32_t ahead = c->front_ahead ? c->front_ahead : sp.nseg;
     c->dcd_latency = c->dcd_form < 0 ? (from_front || !runs_overlap(c)) : c->dcd_form == 1;
+    c->fir_latency = c->dcd_latency;
     c->front_segs = std::min(ahead, sp.nseg);
     for (uint32_t k = 0; k < c->front_segs; ++k)
         if ((r = launch_front_seg(c, sp, k, C, flags))) return r;
@@ -1305,6 +1314,7 @@ int m17hip_fir_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags,
     if (c->front_pending) return M17HIP_ESTATE;
     if (!c->uploaded) return M17HIP_ESTATE;
     const size_t n = (size_t)C * T;
+    c->fir_latency = false;
     int r = ensure_scratch(c, 5 * n * sizeof(float) + (size_t)C * 4 * sizeof(float));
     if (r) return r;
     float* limit = (float*)c->scratch;
@@ -1421,6 +1431,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
         HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork, 0));
         c->dcd_latency = c->dcd_form < 0 ? !runs_overlap(c) : c->dcd_form == 1;
+        c->fir_latency = c->dcd_latency;
         c->front_segs = std::min(ahead, nseg);
         for (uint32_t k = 0; k < c->front_segs; ++k)
             if ((r = launch_front_seg(c, sp, k, C, flags))) return r;

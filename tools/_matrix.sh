@@ -1,5 +1,4 @@
-for r in 1 2; do
-for L in tools/ab/libm17hip_k3base.so tools/ab/libm17hip_k3ring.so; do
-  M17HIP_LIB=$PWD/$L python bench.py --steps 10 --warmup 3 --cpu-seconds 0 --h2d-steps 0 --config2-steps 0 --bursty-steps 0 --parity-channels 0 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d['ms_per_step'], d['ms_per_step_single_stream'], d['roofline']['ms_per_step'], d['roofline']['kernel_ms_per_launch']['dcd'])" $L
+for r in 1 2; do for g in 0 1280 1024 2048 4096 12288; do
+python bench.py --config 2 --steps 5 --warmup 2 --cpu-seconds 0 --parity-channels 0 --tune 13=$g 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config2 grid', sys.argv[1], d['value'], d['ms_per_step'])" $g
 done; done
