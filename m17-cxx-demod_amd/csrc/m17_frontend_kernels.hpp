@@ -227,8 +227,11 @@ __device__ __forceinline__ v2f fs_tap_pair_times(v2f taps, v2f wpair)
 
 template <bool INVERT>
 __global__ __launch_bounds__(FS_THREADS, 4) void fir_rrc150_skew_kernel(const int16_t* __restrict__ x, size_t xpitch, float* __restrict__ y, size_t ypitch,
-                                                                       uint32_t T, const float* __restrict__ tab, uint32_t tiles, uint32_t items)
+                                                                       uint32_t T, const float* __restrict__ tab, uint32_t tiles, uint32_t items,
+                                                                       const uint32_t* __restrict__ first_needed)
 {
+    // first_needed (may be null): per channel, the first sample of this slab the carrier can be on for (gate_forecast_kernel): tiles that end
+    // before it are skipped
     __shared__ __attribute__((aligned(16))) float win[FS_LDS_FLOATS];
     const int tid = threadIdx.x;
     typedef int v4i __attribute__((ext_vector_type(4)));
@@ -273,14 +276,25 @@ __global__ __launch_bounds__(FS_THREADS, 4) void fir_rrc150_skew_kernel(const in
             }
         }
     };
-    uint32_t item = blockIdx.x;
+    auto next_item = [&](uint32_t it) {               // the first item from `it` on (stride = the grid) that is not skipped
+        if (first_needed) {
+            while (it < items) {
+                const uint32_t c = it / tiles, tile = it - c * tiles;
+                if ((uint64_t)(tile + 1u) * FS_TILE > (uint64_t)first_needed[c]) break;
+                it += gridDim.x;
+            }
+        }
+        return it;
+    };
+    uint32_t item = next_item(blockIdx.x);
     if (item < items) fetch(item);
     const float* lbase = win + FS_PADF + 18 * tid;    // lane-relative element e at lbase[fs_off(e)]
-    for (; item < items; item += gridDim.x) {
+    while (item < items) {
         const uint32_t c = item / tiles, tile = item - c * tiles;
+        const uint32_t following = next_item(item + gridDim.x);
         stage();
         dp_handover();                                // (LDS only: no wait for the stores of the item before)
-        if (item + gridDim.x < items) fetch(item + gridDim.x);   // in flight during the tap loop
+        if (following < items) fetch(following);      // in flight during the tap loop
         v2f acc[8], ring[16];
         v2f late = {0.0f, 0.0f};                      // pair 7's product of the step before (added one step late: +0 first, harmless)
 #pragma unroll
@@ -336,6 +350,7 @@ __global__ __launch_bounds__(FS_THREADS, 4) void fir_rrc150_skew_kernel(const in
             }
         }
         dp_handover();                                // every wave is through with the window before the next item is staged
+        item = following;
     }
 }
 

@@ -396,4 +396,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     limit_track_pass(P, (P.flags & 2u) != 0, c, valid, P.chain_in != nullptr, P.only ? P.bnd : nullptr, lds_dyn);
 }
 
+// =====================================================================================================
+// Gate-aware front end (m17hip_tune key 26): which samples of segment k + 2 can the carrier be ON for?
+// The reference runs neither the matched filter nor the correlator while its carrier detect is off (M17Demodulator.h:675-689).  The
+// detector's lower threshold is 0.1 and noise gives a bin ratio of about 1, so once triggered it never falls off by itself: every off
+// transition is a forced dcd.unlock() of the state machine, which only K5 knows.  But a channel that IS off stays off until an update
+// point finds level > 4.0 — a function of the table and of the off state alone (no state machine runs while the gate is closed).  So:
+// K5 leaves the TRUE gate state at the end of segment k (GateTruth); one lane per channel walks the update points of segments k + 1
+// and k + 2 from it (the arithmetic of limit_track_pass's carrier-off branch = M17Demodulator.h:675-689, DataCarrierDetect.h:63-69)
+// and writes the first sample of segment k + 2 for which the gate can be open: 0 for a channel that was on or initialising (nothing
+// is known about when it closes), 0xFFFFFFFF if it cannot open.  K1 of segment k + 2 skips the tiles that end before that sample —
+// K5 patches the first 148 outputs of a gated run itself and K2's replay (which may be on a trajectory of its own after a forced
+// unlock: such channels are off the replay and redone from K5's boundary record) finds stale but finite values there.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void gate_forecast_kernel(const GateTruth* __restrict__ truth, const float* __restrict__ dcd_table, uint32_t ticks_cap, uint64_t tick_row0,
+                                                           uint64_t pos_start, uint32_t target_begin, uint32_t horizon, uint32_t* __restrict__ first_needed, uint32_t C)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const GateTruth t = truth[c];
+    if (t.init > 0 || t.on) { first_needed[c] = 0u; return; }
+    const float* tab = dcd_table + (size_t)c * ticks_cap * 12;
+    float level = t.level;
+    uint32_t trig = t.trig, seg = t.seg, count = t.count;
+    uint64_t pos = pos_start;                       // absolute index of the next sample to be counted
+    uint32_t out = 0xFFFFFFFFu;
+    while (true) {
+        const uint64_t te = pos + (384u - count) - 1u;   // the sample that makes count == 384: an update point (always the last sample of a tick)
+        if (te >= pos_start + horizon) break;
+        if (trig) {                                  // update_dcd -> dcd_on: the gated run starts with the next sample
+            const uint64_t on_at = te + 1u;
+            out = on_at <= pos_start + target_begin ? 0u : (uint32_t)(on_at - (pos_start + target_begin));
+            break;
+        }
+        const uint64_t k = te / TICK;
+        const uint64_t krow = min(k - tick_row0, (uint64_t)ticks_cap - 1);
+        const float* row = tab + (size_t)krow * 12;
+        const int jsum = (uint32_t)(k + 1 - seg) > 5 ? 5 : (int)(seg % 5u);
+        const float l1 = row[jsum], l2 = row[6 + jsum];
+        level = (float)((double)level * 0.8 + 0.2 * (double)(l1 / l2));
+        seg = (uint32_t)(k + 1);
+        trig = level > 4.0f;                         // (the trigger was clear: the upper threshold applies)
+        count = 0;
+        pos = te + 1u;
+    }
+    first_needed[c] = out;
+}
+
 }  // namespace m17

@@ -112,6 +112,14 @@ struct Boundary {
     uint32_t seg;
     int16_t hist[150];
 };
+// The TRUE gate state of a channel at the end of a segment (forced unlocks included): what the gate-aware front end forecasts from
+// (gate_forecast_kernel, m17_gate_kernel.hpp).  Same fields as the replay's start state.
+struct GateTruth {
+    int32_t init;
+    uint32_t on, trig, count;
+    float level;
+    uint32_t seg;
+};
 struct SeqParams {
     const int16_t* x;
     size_t xpitch;
@@ -147,6 +155,7 @@ struct SeqParams {
     float* ev_ops;            // optional [C][ev_pitch]: the running EVM is deferred to evm_fold_pass (below); nullptr: K5 folds it itself
     uint32_t ev_pitch;
     uint32_t* ev_cursor_out;  // [C] the channel's operation cursor at the end of this segment
+    GateTruth* truth_out;     // optional [C]: the gate state at the end of this segment (gate-aware front end); overflow[3] counts the channels whose carrier is off there
 };
 
 // ---- the running EVM, deferred ------------------------------------------------------------------------------------------------------

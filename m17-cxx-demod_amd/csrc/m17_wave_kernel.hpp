@@ -1398,6 +1398,12 @@ __global__ __launch_bounds__(64 * WPB, M17_WAVE_MINW) void demod_wave_kernel(Seq
     for (int k = wl; k < 92; k += 64) gs->llr[k] = DL.llr[k];
     for (int k = wl; k < 8; k += 64) gs->lsf[k] = DL.lsf[k];
     P.rec_count[c] = cd->n_run;
+    if (P.truth_out && wl == 0) {
+        GateTruth gt;
+        gt.init = s.initializing; gt.on = s.dcd_on; gt.trig = s.dcd_trig; gt.count = s.count; gt.level = cd->dcd_level; gt.seg = cd->seg_start_tick;
+        P.truth_out[c] = gt;
+        if (!(s.initializing > 0 || s.dcd_on)) atomicAdd(P.overflow + 3, 1u);
+    }
     if (P.ev_cursor_out && wl == 0) {
         P.ev_cursor_out[c] = cd->ev_cursor;
         if (cd->ev_cursor > P.ev_pitch) atomicOr(P.overflow + 2, 1u);   // operations were dropped: the EVM of this run's diagnostics is not to be trusted (m17hip_diag_fetch says so)

@@ -121,6 +121,11 @@ struct m17hip_ctx {
     float* taps = nullptr;
     float* taps_skew = nullptr;      // tap table of fir_rrc150_skew_kernel (fs_build_tap_table)
     int fir_form = 1;                // (tools build, key 11) K1: 1 = skewed-pair form on a bounded grid, 0 = round 4's rolled R = 15 form, one workgroup per tile
+    int gate_aware = -1;             // tuning knob 26: K1 skips what the carrier cannot be on for (1), never (0), or chosen per run from how much of the previous run's channel-segments ended with the carrier off (-1, default)
+    bool gate_run = false;           // the run being queued is gate-aware
+    GateTruth* truth = nullptr;      // [2][maxC] by segment parity: K5's gate state at the end of a segment
+    uint32_t* first_needed = nullptr;   // [maxC] gate_forecast_kernel -> K1
+    uint32_t off_segs_prev = 0, chan_segs_prev = 0;   // channel-segments of the last FETCHED run that ended with the carrier off / in all
     uint32_t fir_grid = 0;           // tuning knob 13: workgroups of K1's grid (0 = default: from the items per workgroup below)
     bool fir_latency = false;        // the run being queued is one whose chain of K5 launches decides (= it gets K3's latency form): few items per K1 workgroup
     uint32_t n_cu = 256;
@@ -616,7 +621,7 @@ constexpr size_t SEQ_LDS_BYTES_4 = 34816;   // see the K5 launch
 // items per workgroup for the runs that get the latency form of K3 (a continued stream, or nothing else in flight), eight for the others, and
 // never fewer workgroups than a CU can hold of them five times over.
 constexpr uint32_t FIR_GRID_PER_CU = 5, FIR_ITEMS_LATENCY = 3, FIR_ITEMS_THROUGHPUT = 8;
-int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0)
+int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0, const uint32_t* first_needed = nullptr)
 {
     Timed tm(c, KT_FIR, st);
 #ifdef M17_TOOLS
@@ -634,9 +639,9 @@ int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_
         const uint32_t cap = c->fir_grid ? c->fir_grid : std::max(FIR_GRID_PER_CU * c->n_cu, (items + per - 1) / per);
         const dim3 grid(std::min(items, cap));
         if (flags & 1u)
-            hipLaunchKernelGGL(fir_rrc150_skew_kernel<true>, grid, dim3(FS_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, c->taps_skew, tiles, items);
+            hipLaunchKernelGGL(fir_rrc150_skew_kernel<true>, grid, dim3(FS_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, c->taps_skew, tiles, items, first_needed);
         else
-            hipLaunchKernelGGL(fir_rrc150_skew_kernel<false>, grid, dim3(FS_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, c->taps_skew, tiles, items);
+            hipLaunchKernelGGL(fir_rrc150_skew_kernel<false>, grid, dim3(FS_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, c->taps_skew, tiles, items, first_needed);
     }
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
@@ -710,6 +715,9 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     } while (0)
     ALLOC(c->xbuf, C * c->xpitch * sizeof(int16_t));
     ALLOC(c->ybuf, C * c->ypitch * sizeof(float));
+    // (a gate-aware K1 leaves tiles unwritten: what K2's replay may read there must be finite.  A memset is queued, not done, when it returns: wait —
+    //  the first run's K1 is on a stream of its own that would not)
+    if (hipMemset(c->ybuf, 0, C * c->ypitch * sizeof(float)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(M17HIP_EHIP);
     ALLOC(c->hbuf, C * c->ypitch * sizeof(float));
     ALLOC(c->final_h, 2 * C * 4 * sizeof(float));
     ALLOC(c->gate_exp, C * sizeof(GateExport));
@@ -808,7 +816,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
             for (auto e : *v) hipEventDestroy(e);
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
                     c->overflow, c->tables, c->taps, c->taps_skew, c->llr_edges, c->level_gain, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist,
-                    c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->bnd, c->ev_ops, c->ev_cur, c->ev_state};
+                    c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->bnd, c->ev_ops, c->ev_cur, c->ev_state, c->truth, c->first_needed};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);   // (the context is going away: nothing to report to)
     delete c;
@@ -833,10 +841,17 @@ static int stage_prepare(m17hip_ctx* c)
             return M17HIP_OK;
         };
         int r;   // (a call that failed half way is picked up where it stopped: nothing is allocated twice)
-        if (!c->yalt && (r = alloc((void**)&c->yalt, (size_t)c->maxC * c->ypitch * sizeof(float)))) return r;
+        bool fresh_y = false;
+        if (!c->yalt) {
+            if ((r = alloc((void**)&c->yalt, (size_t)c->maxC * c->ypitch * sizeof(float)))) return r;
+            fresh_y = true;
+        }
         if (!c->halt && (r = alloc((void**)&c->halt, (size_t)c->maxC * c->ypitch * sizeof(float)))) return r;
         if (!c->dcd_alt && (r = alloc((void**)&c->dcd_alt, (size_t)c->maxC * c->ticks_cap * 12 * sizeof(float)))) return r;
         if (!c->copy) HIPCHK(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+        // (zeroed as ybuf is — ON the copy stream: the staged run's K1 waits for that stream's ev_in_ready, a memset on the default stream would
+        //  sit behind the run in flight and land in the middle of the staged one)
+        if (fresh_y) HIPCHK(c, hipMemsetAsync(c->yalt, 0, (size_t)c->maxC * c->ypitch * sizeof(float), c->copy));
         if (!c->ev_copy) HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
         if (!c->ev_in_ready) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in_ready, hipEventDisableTiming));
         if ((r = alloc((void**)&c->xstage, (size_t)c->maxC * c->xpitch * sizeof(int16_t)))) return r;   // last: its presence says "all of it is there"
@@ -1204,11 +1219,26 @@ static int ensure_seg_events(m17hip_ctx* c, int q, uint32_t nseg)
     return M17HIP_OK;
 }
 
+// Is the run being queued gate-aware (m17hip_tune key 26)?  -1: yes when more than a quarter of the channel-segments of the last fetched run
+// ended with the carrier off (K5 counts them: overflow[3], read with every fetch) — an always-on load keeps K1 running ahead freely.
+// Needs at least three segments and the default front-end schedule.
+static int gate_mode_for_run(m17hip_ctx* c, const SegPlan& sp)
+{
+    const bool want = c->gate_aware == 1 || (c->gate_aware < 0 && c->chan_segs_prev && 4ull * c->off_segs_prev > (uint64_t)c->chan_segs_prev);
+    c->gate_run = want && sp.nseg >= 3u && !c->front_ahead && !c->profile;
+    if (!c->truth) {   // (K5 leaves the gate state and counts the closed gates in every mode: the next run's choice comes from it)
+        HIPCHK(c, hipMalloc((void**)&c->truth, 2 * (size_t)c->maxC * sizeof(GateTruth)));
+        HIPCHK(c, hipMalloc((void**)&c->first_needed, (size_t)c->maxC * sizeof(uint32_t)));
+    }
+    return M17HIP_OK;
+}
+
 // K3 and K1 of segment k of the run being queued (slab pair c->slot), on the two side streams.
 // The front end of segment k may be held back until K5 of segment k - front_ahead is done (tuning knob 5), to spread it over
 // the step; measured, letting it run ahead freely is faster (K3 is a latency chain of 1.7 ms per segment: held back, it is
 // what K5 ends up waiting for).
-static int launch_front_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, uint32_t C, uint32_t flags)
+// `which`: bit 0 = K3, bit 1 = K1 (a gate-aware run queues K1 of segment k >= 2 later, behind K5 of segment k - 2: launch_gated_fir).
+static int launch_front_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, uint32_t C, uint32_t flags, uint32_t which = 3u)
 {
     if (k >= sp.nseg) return M17HIP_OK;
     const int q = c->slot;
@@ -1220,10 +1250,42 @@ static int launch_front_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, uint32
     }
     if (k == 1) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fir_[q][0], 0));   // segment 0's front end first: K2/K5 wait for it
     int r2;
-    if ((r2 = launch_dcd(c, C, len, flags, c->side, t0))) return r2;
-    HIPCHK(c, hipEventRecord(c->ev_dcd_[q][k], c->side));
-    if ((r2 = launch_fir(c, C, len, flags, c->side2, t0))) return r2;
-    HIPCHK(c, hipEventRecord(c->ev_fir_[q][k], c->side2));
+    if (which & 1u) {
+        if ((r2 = launch_dcd(c, C, len, flags, c->side, t0))) return r2;
+        HIPCHK(c, hipEventRecord(c->ev_dcd_[q][k], c->side));
+    }
+    if (which & 2u) {
+        if ((r2 = launch_fir(c, C, len, flags, c->side2, t0))) return r2;
+        HIPCHK(c, hipEventRecord(c->ev_fir_[q][k], c->side2));
+    }
+    return M17HIP_OK;
+}
+
+// The whole front end of a run as far as it can be queued at once: K3 and K1 of every segment — or, for a gate-aware run, K3 of every segment
+// and K1 of the first two (K1 of segment k >= 2 follows K5 of segment k - 2 and its forecast: launch_gated_fir, from the K5 loop).
+static int launch_front_all(m17hip_ctx* c, const SegPlan& sp, uint32_t C, uint32_t flags)
+{
+    int r;
+    for (uint32_t k = 0; k < c->front_segs; ++k)
+        if ((r = launch_front_seg(c, sp, k, C, flags, (c->gate_run && k >= 2u) ? 1u : 3u))) return r;
+    return M17HIP_OK;
+}
+
+// Gate-aware run, after K5 of segment k has been queued (ev_seq[k] recorded): the forecast for segment k + 2 from K5's gate state at the
+// end of segment k and the table rows of segments k + 1 and k + 2, then K1 of segment k + 2 over what the carrier can be on for.
+static int launch_gated_fir(m17hip_ctx* c, const SegPlan& sp, uint32_t k, uint32_t C, uint32_t flags)
+{
+    if (k + 2u >= sp.nseg) return M17HIP_OK;
+    const int q = c->slot;
+    const uint32_t t1 = sp.t0(k + 1u), t2 = sp.t0(k + 2u), t3 = sp.t0(k + 3u);
+    HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_seq_[q][k], 0));
+    HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_dcd_[q][k + 2u], 0));
+    hipLaunchKernelGGL(gate_forecast_kernel, dim3((C + 63) / 64), dim3(64), 0, c->side2, c->truth + (size_t)(k & 1u) * c->maxC, c->dcd_table, c->ticks_cap,
+                       (uint64_t)(c->pos / TICK), (uint64_t)(c->pos + t1), t2 - t1, t3 - t1, c->first_needed, C);
+    HIPCHK(c, hipGetLastError());
+    int r = launch_fir(c, C, t3 - t2, flags, c->side2, t2, c->first_needed);
+    if (r) return r;
+    HIPCHK(c, hipEventRecord(c->ev_fir_[q][k + 2u], c->side2));
     return M17HIP_OK;
 }
 
@@ -1294,8 +1356,8 @@ static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, b
     c->dcd_latency = c->dcd_form < 0 ? (from_front || !runs_overlap(c)) : c->dcd_form == 1;
     c->fir_latency = c->dcd_latency;
     c->front_segs = std::min(ahead, sp.nseg);
-    for (uint32_t k = 0; k < c->front_segs; ++k)
-        if ((r = launch_front_seg(c, sp, k, C, flags))) return r;
+    if ((r = gate_mode_for_run(c, sp))) return r;
+    if ((r = launch_front_all(c, sp, C, flags))) return r;
     c->front_was_staged = true;
     c->frontC = C; c->frontT = T; c->front_flags = flags;
     return M17HIP_OK;
@@ -1433,8 +1495,8 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         c->dcd_latency = c->dcd_form < 0 ? !runs_overlap(c) : c->dcd_form == 1;
         c->fir_latency = c->dcd_latency;
         c->front_segs = std::min(ahead, nseg);
-        for (uint32_t k = 0; k < c->front_segs; ++k)
-            if ((r = launch_front_seg(c, sp, k, C, flags))) return r;
+        if ((r = gate_mode_for_run(c, sp))) return r;
+        if ((r = launch_front_all(c, sp, C, flags))) return r;
     }
     if (c->defer_decode && !c->defer_llr) {   // the deferred-frame stores exist only where that mode is used (184 B per record slot)
         HIPCHK(c, hipMalloc((void**)&c->defer_llr, (size_t)c->maxC * c->rec_cap_alloc * 46 * sizeof(uint32_t)));
@@ -1491,9 +1553,11 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         P.defer = c->defer_decode ? c->defer_llr : nullptr;
         if (c->defer_evm) { P.ev_ops = c->ev_ops; P.ev_pitch = c->ev_pitch; P.ev_cursor_out = c->ev_cur + (size_t)(k & 1u) * c->maxC; }
         P.bnd_out = c->bnd + (size_t)((k + 1u) & 1u) * c->maxC;
+        P.truth_out = c->truth ? c->truth + (size_t)(k & 1u) * c->maxC : nullptr;
         P.dbg = (c->profile || c->wave_times) ? c->dbg : nullptr;
         return P;
     };
+    HIPCHK(c, hipMemsetAsync(c->overflow + 3, 0, 4, c->stream));   // channel-segments of THIS run that end with the carrier off (K5 counts)
     for (uint32_t k = 0; k < nseg; ++k) {
         const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
         HIPCHK(c, hipStreamWaitEvent(c->stream, ev_fir[k], 0));
@@ -1541,6 +1605,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(ev_seq[k], c->stream));
         if (k + ahead < nseg && (r = launch_front_seg(c, sp, k + ahead, C, flags))) return r;
+        if (c->gate_run && (r = launch_gated_fir(c, sp, k, C, flags))) return r;
     }
     HIPCHK(c, hipGetLastError());
     // the tails a run that continues in THESE slabs (input uploaded in place) will find as its prefixes; a staged run takes them from
@@ -1602,6 +1667,7 @@ static int compact_into(m17hip_ctx* c, FrameRec* dev_out, uint64_t cap, uint64_t
     HIPCHK(c, hipMemcpyAsync(ovf, c->overflow, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (count) *count = total;
+    c->off_segs_prev = ovf[3]; c->chan_segs_prev = c->lastC * std::max(1u, c->last_nseg);   // (what the next run's gate-aware choice looks at)
     if (ovf[0]) return M17HIP_EOVERFLOW;
     if (dev_out && total > cap) return M17HIP_ETRUNC;
     return M17HIP_OK;
@@ -2076,6 +2142,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         return M17HIP_OK;
     case 16:  // the in-place producers (m17hip_upload_i16, m17hip_upload_i16_device, m17hip_synth_i16) write the STAGING slab instead
         c->stage_inputs = value != 0;
+        return M17HIP_OK;
+    case 26:  // gate-aware front end: 1 = K1 of segment k >= 2 skips what the carrier cannot be on for, 0 = never, -1 (default) = per run from the previous run's share of closed gates
+        if (value < -1 || value > 1) return M17HIP_EINVAL;
+        c->gate_aware = (int)value;
         return M17HIP_OK;
     case 13:  // workgroups of K1's bounded grid (0 = default)
         if (value < 0 || value > (1 << 20)) return M17HIP_EINVAL;

@@ -669,3 +669,39 @@ def test_cxx_drop_in_demodulator_app():
     recs, _ = ol.demod(s)
     exp = [f"{int(r['frame_type'])} {int(r['cost'])} {bytes(r['payload'][:r['len']]).hex()}" for r in recs]
     assert got == exp and len(exp) > 3
+
+
+@pytest.mark.parametrize("seg", [4800, 9600, 48000])
+def test_gate_aware_front_end_on_bursty_channels(seg):
+    """m17hip_tune key 26 = 1 (NOTES 5.8): K1 of segment k >= 2 skips the tiles the carrier cannot be on for, forecast from K5's TRUE gate state
+    at the end of segment k - 2 and K3's table.  Channels made of short transmissions of every kind between long stretches of loud, quiet
+    and no noise (the gate closes by forced unlocks and reopens on the next preamble, at any place relative to the segments and to K1's
+    tiles), 40 channels x 240 000 samples: records and diagnostics equal the oracle's, and equal the run with the gate-aware path off."""
+    Cn, T = 40, 240000
+    rng = np.random.default_rng(4242 + seg)
+    x = np.zeros((Cn, T), dtype=np.int16)
+    for c in range(Cn):
+        pos = 0
+        while pos < T - 9000:
+            n = min(int(rng.integers(9000, 70000)), T - pos)
+            p = ol.gen_params(seed=int(rng.integers(1, 1 << 30)), kind=int(rng.choice([0, 1, 2, 4])), n_frames=int(rng.integers(1, 9)),
+                              lead_in=int(rng.integers(0, 6000)), lead_sigma=float(rng.choice([100.0, 20000.0, 40000.0])), noise_sigma=float(rng.choice([100.0, 600.0, 1500.0])),
+                              tail_sigma=float(rng.choice([100.0, 5000.0, 20000.0])), phase=int(rng.integers(-1, 10)), total=n)
+            x[c, pos:pos + n] = ol.generate(p)[:n]; pos += n
+        x[c, pos:] = rng.integers(-300, 300, T - pos)
+    recs, counts, diags = ol.demod_batch(x, cap=2 * (T // 1920 + 2) + 4, threads=8)
+    exp = np.concatenate([recs[c, :counts[c]] for c in range(Cn)])
+    ctx = m17hip.Context(Cn, T)
+    ctx.tune(3, seg)
+    outs = []
+    for mode in (1, 0):
+        ctx.tune(26, mode)
+        ctx.upload(x); ctx.reset(); ctx.run()
+        got = ctx.frames()
+        assert got.tobytes() == exp.tobytes(), (seg, mode)
+        d = ctx.diag(Cn)
+        for f in ("dcd", "locked", "sample_index", "viterbi_cost", "n_diag", "demod_state", "n_frames", "evm", "deviation", "offset", "clock", "dcd_level"):
+            assert np.array_equal(d[f], diags[f], equal_nan=True), (seg, mode, f)
+        outs.append(got.tobytes())
+    assert outs[0] == outs[1]
+    ctx.close()

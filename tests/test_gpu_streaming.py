@@ -32,7 +32,8 @@ def _sorted(parts):
     return got[np.lexsort((got["seq"], got["channel"]))]
 
 
-@pytest.fixture(scope="module", params=[{}, {15: 0, 17: 0}, {3: 7001}, {3: 9600, 15: 0}, {10: 0, 20: 1, 17: 0}], ids=["default", "decode_and_evm_in_k5", "seg7001", "seg9600_decode_in_k5", "k3_throughput_form_redo_in_front_evm_in_k5"])
+@pytest.fixture(scope="module", params=[{}, {15: 0, 17: 0}, {3: 7001}, {3: 9600, 15: 0}, {10: 0, 20: 1, 17: 0}, {26: 1, 3: 4800}, {26: 1, 3: 7001, 15: 0}],
+                ids=["default", "decode_and_evm_in_k5", "seg7001", "seg9600_decode_in_k5", "k3_throughput_form_redo_in_front_evm_in_k5", "gate_aware_seg4800", "gate_aware_seg7001_decode_in_k5"])
 def ctx(request):
     c = m17hip.Context(64, 48000)
     for k, v in request.param.items():

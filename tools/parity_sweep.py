@@ -35,7 +35,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     # (payload frames decoded after the run [m17hip_tune 15], segment length, run boundaries, staged + m17hip_demod_front; the redo policy [20] and the EVM fold's place [17] alternate)
     for spec, seg, pieces, piped in ((1, 19200, None, 0), (1, rseg, None, 0), (0, rseg, None, 0), (1, 0, None, 0), (1, 19200, [0] + cuts + [T], 0),
                                      (1, 19200, [0] + cuts + [T], 1), (0, rseg, [0] + cuts + [T], 1), (1, 4800, [0] + cuts + [T], 1)):
-        ctx.tune(15, spec); ctx.tune(3, seg); ctx.tune(20, (seed + spec + piped) & 1); ctx.tune(17, (seed + piped + (seg & 1)) & 1); ctx.reset()
+        ctx.tune(15, spec); ctx.tune(3, seg); ctx.tune(20, (seed + spec + piped) & 1); ctx.tune(17, (seed + piped + (seg & 1)) & 1); ctx.tune(26, (seed + spec + (seg >> 2)) & 1); ctx.reset()
         if pieces is None:
             ctx.upload(x); ctx.run(flags=inv); got = ctx.frames()
         elif not piped:   # the same stream as three runs (state, filter history and DCD sums carried between them)
