@@ -518,8 +518,9 @@ def main():
 
     # ---- bursty input (N = 1, outside the timed regions): what the chain does when the reference's carrier detect is OFF most of the time.
     #      The reference runs neither the matched filter nor the correlator while it is (M17Demodulator.h:675-689) and gets ~10 x cheaper there;
-    #      here K1 and K3 still see every sample (the gate that would let K1 skip is the TRUE one, forced unlocks included, which
-    #      only K5 knows), K2 and K5 do not.  Same regime as `value` (the batches in flight, fresh demodulators every step); bit-exactness on it checked.
+    #      here the library turns its gate-aware front end on by itself on such input (m17hip_tune key 26 = -1: K1 skips what the carrier cannot be
+    #      on for, forecast from K5's true gate state), K3 still sees every sample.  Same regime as `value` (the batches in flight, fresh
+    #      demodulators every step); bit-exactness on it checked.
     bursty = None
     if not multi and args.bursty_steps > 0:
         nb = max(1, int(0.2 * T / 1920) - 2)

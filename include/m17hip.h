@@ -322,6 +322,13 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  *        result.  A host that needs the same latency whatever else the process runs pins 0 or 1.
  * key 13: workgroups of the matched filter's grid (a K1 workgroup loops over (channel, tile) items), 0 (default) = about three items per workgroup
  *        for runs that get K3's latency form (key 10), eight for the others, at least five workgroups per compute unit.
+ * key 26: gate-aware front end.  The reference runs neither the matched filter nor the correlator while its carrier detect is off
+ *        (M17Demodulator.h:675-689).  1 = the matched filter of segment k >= 2 of a run skips what the carrier cannot be on for: the sequential
+ *        kernel leaves the TRUE gate state at the end of every segment, a forecast walks the carrier-off update points of the next two segments
+ *        from it (a closed gate reopens only when an update finds level > 4.0: a function of the table and the off state alone) and K1 follows
+ *        K5 of segment k - 2 instead of running ahead — on input that is idle most of the time 1.35 x the throughput, on always-on input 5 %
+ *        less (K1 on the chain); 0 = never; -1 (default) = per run: on when more than a quarter of the channel-segments of the last FETCHED run
+ *        ended with the carrier off.  Same results either way.
  * key 20: what happens after a forced dcd.unlock() took a channel off the limit-filter replay: 0 (default) = the replay's state is re-derived
  *        beside the sequential kernel and the channel computes its own filter history through the next segment (the sequential kernel never
  *        waits: best wherever its chain of launches is what a step lasts — a continued stream, one batch at a time); 1 = the replay of the next

@@ -1,4 +1,9 @@
-for r in 1 2; do for g in 0 1280 1024 2048 4096 12288; do
-python bench.py --config 2 --steps 5 --warmup 2 --cpu-seconds 0 --parity-channels 0 --tune 13=$g 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config2 grid', sys.argv[1], d['value'], d['ms_per_step'])" $g
-done; done
+B="python bench.py --steps 10 --warmup 4 --cpu-seconds 0 --h2d-steps 0 --config2-steps 0 --parity-channels 0 --bursty-steps 10 --single-stream 0 --one-at-a-time 0"
+P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["ms_per_step"], d["bursty"]["ms_per_step"], d["bursty"]["ratio_to_always_on"], d["bursty"]["kernel_ms"])'
+$B 2>/dev/null | python3 -c "$P" "auto"
+$B --tune 10=1 2>/dev/null | python3 -c "$P" "k3_latency_form"
+$B --in-flight 3 2>/dev/null | python3 -c "$P" "inflight3"
+$B --in-flight 4 2>/dev/null | python3 -c "$P" "inflight4"
+$B --in-flight 4 --tune 10=1 2>/dev/null | python3 -c "$P" "inflight4_k3lat"
+$B --tune 3=24000 2>/dev/null | python3 -c "$P" "seg24000"
+$B --tune 3=32000 2>/dev/null | python3 -c "$P" "seg32000"
