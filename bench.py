@@ -667,7 +667,10 @@ def main():
                    "value": round(C2 * T / dt2 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt2 * 1e3, 3), "steps": args.config2_steps,
                    "roofline": {"bound": "hbm", "kernel": dom2, "achieved": round(ach2, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach2 / HBM_PEAK_GBS, 5),
                                 "traffic": None, "alg_bytes_per_sample": FRONT_BYTES, "kernel_ms": {k: round(v["ms_per_step"], 4) for k, v in k2.items()},
-                                "chain_achieved_GBs": round(FRONT_BYTES * C2 * T / dt2 / 1e9, 2), "chain_frac": round(FRONT_BYTES * C2 * T / dt2 / 1e9 / HBM_PEAK_GBS, 6)}}
+                                "chain_achieved_GBs": round(FRONT_BYTES * C2 * T / dt2 / 1e9, 2), "chain_frac": round(FRONT_BYTES * C2 * T / dt2 / 1e9 / HBM_PEAK_GBS, 6),
+                                # each kernel on the bytes IT moves (K1: int16 in + f32 out; the limit chain, which the `correlator` timer brackets: f32 in + f32 out)
+                                "kernel_own_bytes_per_sample": {"fir_rrc150": 6.0, "correlator": 8.0},
+                                "kernel_own_frac": {k: round(ob * C2 * T / (k2[k]["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS, 5) for k, ob in (("fir_rrc150", 6.0), ("correlator", 8.0)) if k2[k]["ms_per_step"]}}}
         c2.close()
 
     cpu = cpu_baseline(args, ol, x, C, T, ncpu, ncpu_affinity, cpu_quota, chain=True) if (args.cpu_seconds > 0 and not multi) else None
