@@ -382,6 +382,36 @@ __global__ __launch_bounds__(256) void correlate_kernel(const float* __restrict_
     }
 }
 
+// The same values, FOUR consecutive samples per lane (round 5: beside the matched filter's pieces the one-sample form's 8 four-byte loads, 64 VALU
+// operations and 4 four-byte stores per sample took issue slots from K1): 8 sixteen-byte loads (8-byte aligned: t - 70 + 10 i is even) and 4
+// sixteen-byte stores per four samples, and |word| * y formed once per tap for the four words (word = +-3: (-3) y = -(3 y) exactly, so
+// r + (-3) y = r - 3 y, the same IEEE sum).  Preconditions (else correlate_kernel): t0, T, Ttot multiples of 4.
+__global__ __launch_bounds__(256) void correlate4_kernel(const float* __restrict__ y, size_t ypitch, float* __restrict__ corr,
+                                                         uint32_t C, uint32_t T, uint32_t t0, uint32_t Ttot)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    static constexpr int8_t W[4][8] = {{+3, -3, +3, -3, +3, -3, +3, -3}, {+3, +3, +3, +3, -3, -3, +3, -3}, {+3, -3, +3, +3, -3, -3, -3, -3}, {+3, +3, +3, +3, +3, +3, -3, +3}};
+    const uint32_t c = blockIdx.y;
+    const uint32_t t = t0 + 4u * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= t0 + T) return;
+    const float* yr = y + (size_t)c * ypitch + YPRE;
+    v4f q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v4f v;
+        __builtin_memcpy(&v, __builtin_assume_aligned(yr + ((int64_t)t - 70 + 10 * i), 8), 16);
+        q[i] = 3.0f * v;
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        static_assert(W[0][0] == 3, "");
+        v4f r = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r = W[w][i] > 0 ? r + q[i] : r - q[i];
+        *reinterpret_cast<v4f*>(corr + ((size_t)w * C + c) * Ttot + t) = r;
+    }
+}
+
 // =====================================================================================================
 // limit_kernel — reference a3: Correlator::sample's limit_ = BaseIirFilter<float,3>(|y|)
 // (Correlator.h:43-45, IirFilter.h:26-42, coefficients Correlator.h:38-39).  A float recurrence: strictly
@@ -917,6 +947,150 @@ __global__ __launch_bounds__(320, 1) void limit_pipe_kernel(const float* __restr
                     o.z = iir_output(h.z, h.y, h.x);
                     o.w = iir_output(h.w, h.z, h.y);
                     if (c0 + r < C) *reinterpret_cast<float4*>(limit + (size_t)(c0 + r) * lpitch + (size_t)tile * LP_TILE + 4u * col) = o;
+                }
+            }
+            dp_handover();
+        }
+    }
+}
+
+// =====================================================================================================
+// The same filter with the recurrence RELAYED between two waves (round 5, NOTES 5.9).  What a lone wave pays is the NUMBER of
+// instructions it issues — one per four cycles whether dependent or not (`tools/issue_bench.hip`: the bare three-instruction chain 6.0 ns per
+// sample, every further independent instruction + 1.7 ns) — and a 16-byte LDS write holds the issue for ~ 28 cycles (VGPR data read out at
+// issue; two 8-byte writes cost the same): in limit_pipe_kernel's R wave the hand-over of the trajectory was a third of the time per
+// sample.  Here the wave that carries the chain issues NOTHING else: a tile's 128 samples sit in 128 registers, each overwritten in place by
+// its history value, three instructions per sample in one asm statement (no compiler-made v_mov / s_nop between them); then the chain's
+// state (h[-2], h[-1], eight bytes through LDS) goes to the OTHER recurrence wave, which has the next tile in its registers already, and while
+// that one computes, the first writes its 128 values out and reads the tile after next in.
+//   step i:   P        tile i     global -> ytile[i & 1]                     (one wave: 16 rows x 512 bytes, four tiles in flight)
+//             R(w)     w = parity of its tiles.  (i - w) even: the chain over tile i - 2;
+//                      odd: tile i - 3's values -> htile[w], tile i - 1's samples ytile[w] -> registers
+//             O0, O1   tile i - 4: limit = b0 h0 + b1 h1 + b2 h2 from htile, 16-byte coalesced stores (8 rows each)
+// One workgroup barrier per step.  Bit-identical to limit_kernel (the same IEEE products and differences in the same order).
+// Preconditions (else the host launches limit_kernel): T a multiple of 128.
+// =====================================================================================================
+constexpr int LR_CH = 16;
+constexpr int LR_TILE = 128;
+constexpr int LR_YP = LR_TILE + 4;        // row pitch (floats): sixteen rows start in sixteen different bank groups
+constexpr int LR_HP = 4 + LR_TILE + 4;    // 4 floats of history in front ([2], [3] = h[-2], h[-1])
+constexpr int LR_PF = 4;
+#define LR_CLOBBERS \
+    "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", \
+    "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", \
+    "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", \
+    "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", \
+    "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", \
+    "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", \
+    "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", \
+    "s20", "s21", "s22", "s23", "s24", "s25", "scc", "memory"
+
+// the recurrence waves' whole life as ONE asm statement: registers v96 .. v223 hold a tile across steps, nothing of the compiler's runs in between
+// v[224:225] = (h[-2], h[-1]) of the tile in the registers; v[226:227], v[228:229] = (a1 h, a2 h) of the last even / odd sample; v230 = |x| - a1 h1
+#define LR_PAIR(E0, E1) \
+    "v_sub_f32_e64 v230, |v[" E0 "+4*m17k]|, v228\n v_sub_f32_e32 v[" E0 "+4*m17k], v230, v227\n" \
+    "v_pk_mul_f32 v[226:227], v[" E0 "+4*m17k:" E1 "+4*m17k], s[20:21] op_sel:[0,0] op_sel_hi:[0,1]\n" \
+    "v_sub_f32_e64 v230, |v[" E1 "+4*m17k]|, v226\n v_sub_f32_e32 v[" E1 "+4*m17k], v230, v229\n" \
+    "v_pk_mul_f32 v[228:229], v[" E0 "+4*m17k:" E1 "+4*m17k], s[20:21] op_sel:[1,0] op_sel_hi:[1,1]\n"
+
+__global__ __launch_bounds__(320, 1) void limit_relay_kernel(const float* __restrict__ y, size_t ypitch, float* __restrict__ limit, size_t lpitch, uint32_t C, uint32_t T,
+                                                             const float* __restrict__ state_in, float* __restrict__ state_out)
+{
+    __shared__ __attribute__((aligned(16))) float ytile[2][LR_CH][LR_YP];
+    __shared__ __attribute__((aligned(16))) float htile[2][LR_CH][LR_HP];
+    __shared__ __attribute__((aligned(16))) float relay[LR_CH][2];
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 = P; 1, 2 = R(0), R(1); 3, 4 = O0, O1
+    const int lane = threadIdx.x & 63;
+    const uint32_t c0 = blockIdx.x * (uint32_t)LR_CH;
+    const uint32_t NT = T / LR_TILE;
+    const uint32_t NI = (NT + 4u + LR_PF - 1u) / LR_PF * LR_PF;
+    auto row_of = [&](uint32_t r) -> uint32_t { return min(c0 + r, C - 1u); };   // rows beyond the last channel shadow it
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const uint32_t sub = (uint32_t)lane >> 5, col = (uint32_t)lane & 31u;       // P, O: two rows per instruction, 32 lanes x 16 bytes = a row's 512-byte tile
+    if (role == 0) {
+        v4f pf[LR_PF][8];
+        const float* ybase[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ybase[q] = y + (size_t)row_of(2u * (uint32_t)q + sub) * ypitch + YPRE + 4u * col;
+        auto issue = [&](uint32_t tile, int slot) {
+            const uint32_t t0 = min(tile, NT - 1u) * LR_TILE;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pf[slot][q] = *reinterpret_cast<const v4f*>(ybase[q] + t0);
+        };
+#pragma unroll
+        for (int j = 0; j < LR_PF; ++j) issue((uint32_t)j, j);
+        for (uint32_t i0 = 0; i0 < NI; i0 += LR_PF) {
+#pragma unroll
+            for (int slot = 0; slot < LR_PF; ++slot) {
+                const uint32_t i = i0 + (uint32_t)slot;
+                v4f v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = pf[slot][q];
+                issue(i + LR_PF, slot);
+                if (i < NT) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) *reinterpret_cast<v4f*>(&ytile[i & 1u][2u * (uint32_t)q + sub][4u * col]) = v[q];
+                }
+                dp_handover();
+            }
+        }
+    } else if (role <= 2) {
+        const uint32_t w = (uint32_t)(role - 1), r = (uint32_t)lane & 15u;
+        float h2 = 0.f, h1 = 0.f;
+        if (state_in) { const v4f s4 = *reinterpret_cast<const v4f*>(state_in + 4 * (size_t)row_of(r)); h2 = s4.z; h1 = s4.w; }
+        const uint32_t ya = (uint32_t)(uintptr_t)as_lds(&ytile[w][r][0]), ha = (uint32_t)(uintptr_t)as_lds(&htile[w][r][0]);
+        const uint32_t sa = (uint32_t)(uintptr_t)as_lds(&relay[r][0]);
+        float o0, o1, o2, o3;
+        asm volatile(
+            "s_setprio 3\n"
+            "v_mov_b32 v224, %[h2]\n v_mov_b32 v225, %[h1]\n"
+            "s_mov_b32 s20, 0xbffda16a\n s_mov_b32 s21, 0x3f7b4df5\n s_mov_b32 s22, 0\n"
+            "Lstep%=:\n"
+            "s_sub_u32 s24, s22, %[w]\n s_and_b32 s24, s24, 1\n s_cmp_eq_u32 s24, 0\n s_cbranch_scc0 Lidle%=\n"
+            // ---- the chain over tile i - 2
+            "s_cmp_lt_u32 s22, 2\n s_cbranch_scc1 Lsync%=\n s_sub_u32 s25, s22, 2\n s_cmp_ge_u32 s25, %[nt]\n s_cbranch_scc1 Lsync%=\n"
+            "s_cmp_eq_u32 s25, 0\n s_cbranch_scc1 Lgo%=\n"
+            "ds_read_b64 v[224:225], %[sa]\n"
+            "Lgo%=:\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_pk_mul_f32 v[226:227], v[224:225], s[20:21] op_sel:[0,0] op_sel_hi:[0,1]\n"     // (a1 h[-2], a2 h[-2])
+            "v_pk_mul_f32 v[228:229], v[224:225], s[20:21] op_sel:[1,0] op_sel_hi:[1,1]\n"     // (a1 h[-1], a2 h[-1])
+            ".set m17k, 0\n .rept 32\n" LR_PAIR("96", "97") LR_PAIR("98", "99") ".set m17k, m17k+1\n .endr\n"
+            "ds_write_b64 %[sa], v[222:223]\n"
+            "s_branch Lsync%=\n"
+            // ---- tile i - 3 out, tile i - 1 in
+            "Lidle%=:\n"
+            "s_cmp_lt_u32 s22, 3\n s_cbranch_scc1 Lpre%=\n s_sub_u32 s25, s22, 3\n s_cmp_ge_u32 s25, %[nt]\n s_cbranch_scc1 Lpre%=\n"
+            "ds_write_b64 %[ha], v[224:225] offset:8\n"
+            ".set m17k, 0\n .rept 32\n ds_write_b128 %[ha], v[96+4*m17k:99+4*m17k] offset:16+16*m17k\n .set m17k, m17k+1\n .endr\n"
+            "Lpre%=:\n"
+            "s_cmp_lt_u32 s22, 1\n s_cbranch_scc1 Lsync%=\n s_sub_u32 s25, s22, 1\n s_cmp_ge_u32 s25, %[nt]\n s_cbranch_scc1 Lsync%=\n"
+            ".set m17k, 0\n .rept 32\n ds_read_b128 v[96+4*m17k:99+4*m17k], %[ya] offset:16*m17k\n .set m17k, m17k+1\n .endr\n"
+            "Lsync%=:\n"
+            "s_waitcnt lgkmcnt(0)\n s_barrier\n"
+            "s_add_u32 s22, s22, 1\n s_cmp_lt_u32 s22, %[ni]\n s_cbranch_scc1 Lstep%=\n"
+            "v_mov_b32 %[o0], v220\n v_mov_b32 %[o1], v221\n v_mov_b32 %[o2], v222\n v_mov_b32 %[o3], v223\n"
+            : [o0] "=v"(o0), [o1] "=v"(o1), [o2] "=v"(o2), [o3] "=v"(o3)
+            : [h2] "v"(h2), [h1] "v"(h1), [ya] "v"(ya), [ha] "v"(ha), [sa] "v"(sa), [w] "s"(w), [nt] "s"(NT), [ni] "s"(NI)
+            : LR_CLOBBERS);
+        if (state_out && ((NT - 1u) & 1u) == w && lane < LR_CH && c0 + r < C)
+            *reinterpret_cast<v4f*>(state_out + 4 * (size_t)(c0 + r)) = v4f{o0, o1, o2, o3};
+    } else {
+        for (uint32_t i = 0; i < NI; ++i) {
+            if (i >= 4u && i < NT + 4u) {
+                const uint32_t tile = i - 4u, b = tile & 1u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t r = 8u * (uint32_t)(role - 3) + 2u * (uint32_t)q + sub;
+                    const float* hrow = &htile[b][r][0];
+                    const float4 p = *reinterpret_cast<const float4*>(hrow + 4u * col);        // h[k0-4 .. k0-1]
+                    const float4 h = *reinterpret_cast<const float4*>(hrow + 4u + 4u * col);   // h[k0 .. k0+3]
+                    float4 o;
+                    o.x = iir_output(h.x, p.w, p.z);
+                    o.y = iir_output(h.y, h.x, p.w);
+                    o.z = iir_output(h.z, h.y, h.x);
+                    o.w = iir_output(h.w, h.z, h.y);
+                    if (c0 + r < C) *reinterpret_cast<float4*>(limit + (size_t)(c0 + r) * lpitch + (size_t)tile * LR_TILE + 4u * col) = o;
                 }
             }
             dp_handover();

@@ -120,6 +120,7 @@ struct m17hip_ctx {
     DecodeTables* tables = nullptr;
     float* taps = nullptr;
     float* taps_skew = nullptr;      // tap table of fir_rrc150_skew_kernel (fs_build_tap_table)
+    int limit_form = 1;              // (tools build, key 27) configs[1]'s limit filter: 1 = the chain relayed between two waves, 0 = round 4's one recurrence wave
     int fir_form = 1;                // (tools build, key 11) K1: 1 = skewed-pair form on a bounded grid, 0 = round 4's rolled R = 15 form, one workgroup per tile
     int gate_aware = -1;             // tuning knob 26: K1 skips what the carrier cannot be on for (1), never (0), or chosen per run from how much of the previous run's channel-segments ended with the carrier off (-1, default)
     bool gate_run = false;           // the run being queued is gate-aware
@@ -1036,10 +1037,13 @@ int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, 
         Timed tm(c, KT_CORR);
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        hipLaunchKernelGGL(correlate_kernel, dim3((T + 255) / 256, C), dim3(256), 0, c->side, c->ybuf, c->ypitch, corr, C, T, 0u, T);
+        if (T % 4 == 0) hipLaunchKernelGGL(correlate4_kernel, dim3((T / 4 + 255) / 256, C), dim3(256), 0, c->side, c->ybuf, c->ypitch, corr, C, T, 0u, T);
+        else hipLaunchKernelGGL(correlate_kernel, dim3((T + 255) / 256, C), dim3(256), 0, c->side, c->ybuf, c->ypitch, corr, C, T, 0u, T);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
-        if (T % LP_TILE == 0 && T >= 4 * LP_TILE && (((size_t)C * T) & 3) == 0)
+        if (T % LR_TILE == 0 && c->limit_form == 1)
+            hipLaunchKernelGGL(limit_relay_kernel, dim3((C + LR_CH - 1) / LR_CH), dim3(320), 0, c->stream, c->ybuf, c->ypitch, limit, (size_t)T, C, T, (const float*)nullptr, (float*)nullptr);
+        else if (T % LP_TILE == 0 && T >= 4 * LP_TILE && (((size_t)C * T) & 3) == 0)
             hipLaunchKernelGGL(limit_pipe_kernel, dim3((C + LP_CH - 1) / LP_CH), dim3(320), 0, c->stream, c->ybuf, c->ypitch, limit, (size_t)T, C, T, (const float*)nullptr, (float*)nullptr);
         else
             hipLaunchKernelGGL(limit_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
@@ -1404,8 +1408,14 @@ int m17hip_fir_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags,
         HIPCHK(c, hipStreamWaitEvent(st_corr, ev_fir[k], 0));
         HIPCHK(c, hipStreamWaitEvent(st_chain, ev_fir[k], 0));
         Timed tm(c, KT_CORR, st_chain);
-        hipLaunchKernelGGL(correlate_kernel, dim3((len + 255) / 256, C), dim3(256), 0, st_corr, c->ybuf, c->ypitch, corr, C, len, t0, T);
-        if (tiled)
+        if (T % 4 == 0 && t0 % 4 == 0 && len % 4 == 0)
+            hipLaunchKernelGGL(correlate4_kernel, dim3((len / 4 + 255) / 256, C), dim3(256), 0, st_corr, c->ybuf, c->ypitch, corr, C, len, t0, T);
+        else
+            hipLaunchKernelGGL(correlate_kernel, dim3((len + 255) / 256, C), dim3(256), 0, st_corr, c->ybuf, c->ypitch, corr, C, len, t0, T);
+        if (tiled && c->limit_form == 1)
+            hipLaunchKernelGGL(limit_relay_kernel, dim3(chain_wgs), dim3(320), 0, st_chain, c->ybuf + t0, c->ypitch, limit + t0, (size_t)T, C, len,
+                               (const float*)lstate, lstate);
+        else if (tiled)
             hipLaunchKernelGGL(limit_pipe_kernel, dim3(chain_wgs), dim3(320), 0, st_chain, c->ybuf + t0, c->ypitch, limit + t0, (size_t)T, C, len,
                                (const float*)lstate, lstate);
         else
@@ -2152,6 +2162,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         c->fir_grid = (uint32_t)value;
         return M17HIP_OK;
 #ifdef M17_TOOLS
+    case 27:  // configs[1]'s limit filter: 1 (default) = limit_relay_kernel, 0 = round 4's limit_pipe_kernel
+        if (value < 0 || value > 1) return M17HIP_EINVAL;
+        c->limit_form = (int)value;
+        return M17HIP_OK;
     case 11:  // K1 form: 1 (default) = skewed pairs on a bounded grid, 0 = round 4's rolled R = 15 form with one workgroup per tile
         if (value < 0 || value > 1) return M17HIP_EINVAL;
         c->fir_form = (int)value;

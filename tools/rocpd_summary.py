@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd SQLite result (`*_results.db`) into a per-kernel table:
 calls, total/avg/min/max duration and, when the run collected --pmc counters, the per-dispatch
-average of every counter over its hardware instances (`=value xN`: N instances per dispatch, total = value x N).  Usage: rocpd_summary.py results.db [out.md]"""
+average of every counter over its hardware instances (`=value xN`: N instances per dispatch, total = value x N).  Usage: rocpd_summary.py results.db [out.md]
+`--timeline N` (after the db): instead of the table, the LAST N dispatches in start order (start / end in ms from the first of them, kernel, grid)."""
 import sqlite3
 import sys
 from collections import defaultdict
@@ -14,6 +15,12 @@ def main():
     kd, ks = t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol")
     names = {r[0]: r[1] for r in db.execute(f"select id, kernel_name from {ks}")}
     rows = db.execute(f"select id, kernel_id, start, end, grid_size_x, grid_size_y, workgroup_size_x, event_id from {kd}").fetchall()
+    if len(sys.argv) > 3 and sys.argv[2] == "--timeline":
+        last = sorted(rows, key=lambda r: r[2])[-int(sys.argv[3]):]
+        t0 = last[0][2]
+        for did, kid, st, en, gx, gy, wx, ev in last:
+            print(f"{(st - t0) / 1e6:9.3f} {(en - t0) / 1e6:9.3f}  {(en - st) / 1e6:7.3f} ms  {names[kid].split('(')[0][:60]:60s} {gx}x{gy}")
+        return
     stats = defaultdict(list)
     disp_kernel = {}
     for did, kid, st, en, gx, gy, wx, ev in rows:
