@@ -162,9 +162,12 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state
     // whole aligned tick, no patched outputs: lane r stages float4 r, r + GT_LPC, ... (16-byte loads issued one tick ahead)
     auto stage_tick = [&]() {
         const float4* src = reinterpret_cast<const float4*>(yr + t) + r;
-        if (pre_t != t && valid) {   // (an idle lane loads nothing: a redo pass of one channel does not read its fifteen neighbours' rows)
+        if (pre_t != t) {            // not requested a tick ahead (the first tick of a streak)
+            if (valid) {             // (an idle lane loads nothing: a redo pass of one channel does not read its fifteen neighbours' rows)
 #pragma unroll
-            for (int b = 0; b < GT_F4; ++b) pre[b] = src[GT_LPC * b];
+                for (int b = 0; b < GT_F4; ++b) pre[b] = src[GT_LPC * b];
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) HERE: the wait below then only has the prefetched case to cover, with its twelve stores counted
         }
         float4* dst = reinterpret_cast<float4*>(&yl[g][0]) + r;
 #pragma unroll
@@ -185,26 +188,23 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state
         o.w = iir_advance_pk(fabsf(v.w), h0, m2); h2 = h1; h1 = h0; h0 = o.w;
         return o;
     };
-    auto iir_tick = [&]() {   // straight-line: 48 blocks of 4 samples, the next block's read in flight
-        float m2 = IirCoef::a2 * h1;
-        const float4* yv = reinterpret_cast<const float4*>(&yl[g][0]);
-        float4* hv = reinterpret_cast<float4*>(&hl[g][0]);
-        float4 a0 = yv[0];
-#pragma unroll
-        for (int b = 0; b < TICK / 4; ++b) {
-            float4 n0 = a0;
-            if (b + 1 < TICK / 4) n0 = yv[b + 1];
-            hv[b] = four(a0, m2);
-            a0 = n0;
-            __builtin_amdgcn_sched_barrier(0);   // (keeps the read-ahead at one block: the kernel has to fit beside K5's waves)
-        }
+    auto iir_tick = [&]() {   // (m17_frontend_kernels.hpp: one asm statement, three instructions per sample)
+        iir_tick_in_place((uint32_t)(uintptr_t)as_lds(&yl[g][0]), h0, h1, h2);
     };
-    auto store_tick = [&]() {
-        float4* o = reinterpret_cast<float4*>(hr + t) + r;
-        const float4* i4 = reinterpret_cast<const float4*>(&hl[g][0]) + r;
+    // The tick's history values, LDS -> hbuf: twelve 16-byte stores per lane that are ALWAYS issued — a lane with nothing to store (an idle
+    // channel, a pass that keeps no history) points beyond the end of the buffer descriptor and its store is dropped.  Behind a branch the
+    // compiler cannot count them, and the next tick's wait for its prefetched samples (one counter for loads and stores, in order) became a
+    // wait for these stores: a store round trip, ~1.5 us, per tick of ~4 (NOTES 5.9).
+    typedef int gt_v4i __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(P.h + (size_t)(blockIdx.x * GT_CPW) * P.ypitch), 0,
+                                                                            (int)min((size_t)GT_CPW * P.ypitch * 4u, (size_t)0x7FFF0000u), 0x00020000);
+    const uint32_t hvoff = (valid && store) ? (uint32_t)(((size_t)g * P.ypitch + YPRE + t0) * 4u + (size_t)r * 16u) : 0x7FFF0000u;
+    auto store_tick = [&](bool fed) {   // (`fed`: this lane's channel was fed in this tick)
+        const gt_v4i* i4 = reinterpret_cast<const gt_v4i*>(&hl[g][0]) + r;
+        const uint32_t voff = fed ? hvoff : 0x7FFF0000u;
 #pragma unroll
         for (int b = 0; b < GT_F4; ++b) {
-            o[GT_LPC * b] = i4[GT_LPC * b];
+            __builtin_amdgcn_raw_buffer_store_b128(i4[GT_LPC * b], hrsrc, (int)(voff + t * 4u + 64u * (uint32_t)b), 0, 0);
             if (b % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // three 16-byte rows in flight at a time (not all twelve: registers)
         }
     };
@@ -226,7 +226,7 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state
                 lds_sync();
                 if (r == 0) iir_tick();
                 lds_sync();
-                if (valid && store) store_tick();
+                store_tick(true);
                 lds_sync();
                 count += TICK;
                 if (upd) {
@@ -324,7 +324,7 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state
             lds_sync();
             if (feed && valid && store) {
                 if (fast) {
-                    store_tick();
+                    store_tick(true);
                 } else {
 #pragma clang loop unroll(disable) vectorize(disable)
                     for (uint32_t i = r; i < n; i += GT_LPC) hr[t + i] = hl[g][i];
@@ -362,6 +362,8 @@ __device__ __forceinline__ void limit_track_pass(const GateParams& P, bool state
         }
         t += n;
         if (phase + n == TICK) { phase = 0; ++k_cur; } else phase += n;
+        // (this path's loads and stores sit behind branches: nothing of it stays in flight into a steady tick, whose waits are counted)
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     }
     if (r == 0 && valid) {
         float* f = P.final_h + fh_off + (size_t)c * 4;
