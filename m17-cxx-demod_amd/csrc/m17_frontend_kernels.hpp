@@ -883,6 +883,7 @@ constexpr int LP_YP = LP_TILE + 4;        // ytile row pitch (floats): sixteen r
 constexpr int LP_HP = 4 + LP_TILE + 4;    // htile row pitch: 4 floats of the previous tile in front
 constexpr int LP_PF = 3;
 
+#ifdef M17_TOOLS   // round 4's form, kept in the measurement build for same-box comparisons (m17hip_tune key 27); the product runs limit_relay_kernel below
 // `T` samples from y (row pitch ypitch) to limit (row pitch lpitch); state (may be null = zero history / not kept): the last four history values of a
 // channel, h[-4 .. -1], so that a run can be cut into pieces in time (m17hip_fir_correlator pipelines the matched filter with this chain)
 __global__ __launch_bounds__(320, 1) void limit_pipe_kernel(const float* __restrict__ y, size_t ypitch, float* __restrict__ limit, size_t lpitch, uint32_t C, uint32_t T,
@@ -997,6 +998,7 @@ __global__ __launch_bounds__(320, 1) void limit_pipe_kernel(const float* __restr
         }
     }
 }
+#endif
 
 // =====================================================================================================
 // The same filter with the recurrence RELAYED between two waves (round 5, NOTES 5.9).  What a lone wave pays is the NUMBER of

@@ -120,7 +120,7 @@ struct m17hip_ctx {
     DecodeTables* tables = nullptr;
     float* taps = nullptr;
     float* taps_skew = nullptr;      // tap table of fir_rrc150_skew_kernel (fs_build_tap_table)
-    int limit_form = 1;              // (tools build, key 27) configs[1]'s limit filter: 1 = the chain relayed between two waves, 0 = round 4's one recurrence wave
+    int limit_form = 1;              // (tools build only, key 27) configs[1]'s limit filter: 1 = the chain relayed between two waves, 0 = round 4's one recurrence wave
     int fir_form = 1;                // (tools build, key 11) K1: 1 = skewed-pair form on a bounded grid, 0 = round 4's rolled R = 15 form, one workgroup per tile
     int gate_aware = -1;             // tuning knob 26: K1 skips what the carrier cannot be on for (1), never (0), or chosen per run from how much of the previous run's channel-segments ended with the carrier off (-1, default)
     bool gate_run = false;           // the run being queued is gate-aware
@@ -1041,10 +1041,13 @@ int m17hip_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, float* limit_host, 
         else hipLaunchKernelGGL(correlate_kernel, dim3((T + 255) / 256, C), dim3(256), 0, c->side, c->ybuf, c->ypitch, corr, C, T, 0u, T);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
-        if (T % LR_TILE == 0 && c->limit_form == 1)
-            hipLaunchKernelGGL(limit_relay_kernel, dim3((C + LR_CH - 1) / LR_CH), dim3(320), 0, c->stream, c->ybuf, c->ypitch, limit, (size_t)T, C, T, (const float*)nullptr, (float*)nullptr);
-        else if (T % LP_TILE == 0 && T >= 4 * LP_TILE && (((size_t)C * T) & 3) == 0)
+#ifdef M17_TOOLS
+        if (c->limit_form == 0 && T % LP_TILE == 0 && T >= 4 * LP_TILE && (((size_t)C * T) & 3) == 0)
             hipLaunchKernelGGL(limit_pipe_kernel, dim3((C + LP_CH - 1) / LP_CH), dim3(320), 0, c->stream, c->ybuf, c->ypitch, limit, (size_t)T, C, T, (const float*)nullptr, (float*)nullptr);
+        else
+#endif
+        if (T % LR_TILE == 0 && (((size_t)C * T) & 3) == 0)
+            hipLaunchKernelGGL(limit_relay_kernel, dim3((C + LR_CH - 1) / LR_CH), dim3(320), 0, c->stream, c->ybuf, c->ypitch, limit, (size_t)T, C, T, (const float*)nullptr, (float*)nullptr);
         else
             hipLaunchKernelGGL(limit_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->ybuf, c->ypitch, limit, C, T);
         HIPCHK(c, hipGetLastError());
@@ -1412,11 +1415,14 @@ int m17hip_fir_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags,
             hipLaunchKernelGGL(correlate4_kernel, dim3((len / 4 + 255) / 256, C), dim3(256), 0, st_corr, c->ybuf, c->ypitch, corr, C, len, t0, T);
         else
             hipLaunchKernelGGL(correlate_kernel, dim3((len + 255) / 256, C), dim3(256), 0, st_corr, c->ybuf, c->ypitch, corr, C, len, t0, T);
-        if (tiled && c->limit_form == 1)
-            hipLaunchKernelGGL(limit_relay_kernel, dim3(chain_wgs), dim3(320), 0, st_chain, c->ybuf + t0, c->ypitch, limit + t0, (size_t)T, C, len,
-                               (const float*)lstate, lstate);
-        else if (tiled)
+#ifdef M17_TOOLS
+        if (tiled && c->limit_form == 0)
             hipLaunchKernelGGL(limit_pipe_kernel, dim3(chain_wgs), dim3(320), 0, st_chain, c->ybuf + t0, c->ypitch, limit + t0, (size_t)T, C, len,
+                               (const float*)lstate, lstate);
+        else
+#endif
+        if (tiled)
+            hipLaunchKernelGGL(limit_relay_kernel, dim3(chain_wgs), dim3(320), 0, st_chain, c->ybuf + t0, c->ypitch, limit + t0, (size_t)T, C, len,
                                (const float*)lstate, lstate);
         else
             hipLaunchKernelGGL(limit_kernel, dim3((C + 63) / 64), dim3(64), 0, st_chain, c->ybuf, c->ypitch, limit, C, T);

@@ -250,13 +250,22 @@ for settings in ({{21: 2}}, {{25: 0}}, {{21: 1, 25: 0}}):
     g = g[np.lexsort((g["seq"], g["channel"]))]
     assert g.tobytes() == exp, settings
     for k in settings: c.tune(k, defaults[k])
+# round 4's limit pipeline (key 27 = 0) against the relayed recurrence (default): configs[1] in one call and as the per-operator call
+c.upload(x)
+ref = c.fir_correlator()
+lim_ref, corr_ref = c.correlator()
+c.tune(27, 0)
+got = c.fir_correlator()
+lim_old, corr_old = c.correlator()
+c.tune(27, 1)
+assert all(np.array_equal(a, b) for a, b in zip(ref, got)) and np.array_equal(lim_ref, lim_old) and np.array_equal(corr_ref, corr_old) and np.array_equal(ref[1], lim_ref)
 print("tools-build knobs ok")
 """
 
 
 def test_measurement_build_knobs_do_not_change_results(tmp_path):
     """the schedule-experiment members of the context (front_ahead, front_first, seq_lds_bytes, front_k1_after, gate0_early, the
-    first-segment length, round 4's K1) can only be set in the measurement build (libm17hip_tools.so, -DM17_TOOLS): drive their non-default
+    first-segment length, round 4's K1, round 4's limit pipeline) can only be set in the measurement build (libm17hip_tools.so, -DM17_TOOLS): drive their non-default
     branches there and compare with the oracle, in a process of its own (this one has the production library loaded)."""
     lib = os.path.join(ROOT, "m17-cxx-demod_amd", "libm17hip_tools.so")
     if not os.path.exists(lib):

@@ -42,11 +42,13 @@ def test_config2_fir_and_correlator_at_1024_channels():
     ctx.close()
 
 
-@pytest.mark.parametrize("Cn,T", [(70, 64 * 37), (1, 256), (64, 64 * 150), (129, 64 * 5), (33, 30000)])
+@pytest.mark.parametrize("Cn,T", [(70, 64 * 37), (1, 256), (64, 64 * 150), (129, 64 * 5), (33, 30000), (17, 128), (3, 384), (16, 128 * 5), (40, 128 * 7), (2, 301), (5, 302)])
 def test_correlator_limit_pipeline_and_single_wave_forms(Cn, T):
-    """m17hip_correlator picks the five-wave pipeline for the limit filter when the length is a multiple of 64 (>= 256) and the
-    one-lane-per-channel kernel otherwise: both against the oracle, channel counts that do and do not fill a workgroup, incl. a
-    burst that decays through the subnormal range."""
+    """m17hip_correlator runs the limit filter as the relayed recurrence (limit_relay_kernel: tiles of 128 samples handed from one recurrence
+    wave to the other) when the length is a multiple of 128 and as the one-lane-per-channel kernel otherwise, the correlations four samples
+    per lane when the length is a multiple of 4 and one per lane otherwise: against the oracle — one tile (the first wave alone), an odd
+    number of tiles (the end state comes from the first wave), an even one, channel counts that do and do not fill a workgroup of sixteen,
+    a burst that decays through the subnormal range."""
     p = ol.gen_params(seed=900 + Cn, kind=-1, n_frames=max(1, T // 1920 - 2), lead_in=500, noise_sigma=800.0, tail_sigma=800.0, lead_sigma=30000.0, total=T)
     x = ol.generate_batch(p, Cn, T, threads=8)
     x[0, min(300, T // 2):] = 0                      # channel 0: exact zeros after a burst -> denormal decay of the IIR
@@ -112,7 +114,7 @@ def test_fir_ragged_tiles_short_runs_extreme_inputs(Cn, T):
     ctx.close()
 
 
-@pytest.mark.parametrize("Cn,T", [(21, 256 * 200), (16, 256 * 9), (70, 256 * 8), (33, 48000), (5, 256 * 41 + 64), (1, 300)])
+@pytest.mark.parametrize("Cn,T", [(21, 256 * 200), (16, 256 * 9), (70, 256 * 8), (33, 48000), (5, 256 * 41 + 64), (1, 300), (18, 256 * 40 + 128), (7, 256 * 11)])
 def test_fir_correlator_in_one_call_equals_the_two_operators_and_the_oracle(Cn, T):
     """m17hip_fir_correlator (configs[1] as one call, the limit chain cut into pieces in time with its history carried, the matched filter and
     the correlations pipelined beside it) against m17hip_fir_rrc150 + m17hip_correlator and against the oracle, bit for bit: lengths that
