@@ -440,36 +440,37 @@ using core::iir_output;
 // half of the pair the outputs are collected in — the reads two blocks of four ahead, the 16-byte writes left in flight
 // (s_waitcnt lgkmcnt(2): the compiler's form of this loop waited for lgkmcnt(0), i.e. for its own write, once per block, and put a v_mov in
 // the chain and another beside it per block: 23 ns per sample in K2 against 11 here — tools/issue_bench.hip, NOTES 5.9).
-// Registers: v40 row address; v[48:55], v[56:63] the two input blocks; v[64:71] eight outputs (a write has read its data when the next
-// instruction issues); v[80:81], v[82:83] the products of the
-// last even / odd sample; v86 scratch; s[20:21] = (a1, a2).  The row needs 16 bytes of padding behind its 192 samples (two dummy writes
+// Registers: v40 row address; v[48:55], v[56:63] the two blocks of eight samples, each register overwritten by its history value (a write
+// has read its data when the next instruction issues, and the LDS queue is in order: the read that refills a block comes behind the
+// writes that emptied it); v[80:81], v[82:83] the products of the
+// last even / odd sample; s[20:21] = (a1, a2).  The row needs 16 bytes of padding behind its 192 samples (two dummy writes
 // give the first wait its two writes in flight) and readable memory for 32 bytes behind that (the last read-ahead).
-#define M17_IIR_STEP(X, O, PLO, PHI, SEL, RAlo, RBlo, RBhi) \
-    "v_sub_f32_e64 v86, |v" #X "|, v" #RAlo "\n v_sub_f32_e32 v" #O ", v86, v" #RBhi "\n" \
+#define M17_IIR_STEP(X, PLO, PHI, SEL, RAlo, RBlo, RBhi) \
+    "v_sub_f32_e64 v" #X ", |v" #X "|, v" #RAlo "\n v_sub_f32_e32 v" #X ", v" #X ", v" #RBhi "\n" \
     "v_pk_mul_f32 v[" #RBlo ":" #RBhi "], v[" #PLO ":" #PHI "], s[20:21] op_sel:[" #SEL ",0] op_sel_hi:[" #SEL ",1]\n"
-#define M17_IIR_FOUR(X0, X1, X2, X3, O0, O1, O2, O3) \
-    M17_IIR_STEP(X0, O0, O0, O1, 0, 82, 80, 81) M17_IIR_STEP(X1, O1, O0, O1, 1, 80, 82, 83) \
-    M17_IIR_STEP(X2, O2, O2, O3, 0, 82, 80, 81) M17_IIR_STEP(X3, O3, O2, O3, 1, 80, 82, 83)
+#define M17_IIR_FOUR(X0, X1, X2, X3) \
+    M17_IIR_STEP(X0, X0, X1, 0, 82, 80, 81) M17_IIR_STEP(X1, X0, X1, 1, 80, 82, 83) \
+    M17_IIR_STEP(X2, X2, X3, 0, 82, 80, 81) M17_IIR_STEP(X3, X2, X3, 1, 80, 82, 83)
 #define M17_IIR_RD(V0, V1, OFF) "ds_read_b128 v[" #V0 ":" #V1 "], v40 offset:" #OFF "\n"
 #define M17_IIR_WR(V0, V1, OFF) "ds_write_b128 v40, v[" #V0 ":" #V1 "] offset:" #OFF "\n"
 #define M17_IIR_16(RB0, RB1, RA0, RA1, W0, W1, W2, W3) \
     "s_waitcnt lgkmcnt(2)\n" M17_IIR_RD(56, 59, RB0) M17_IIR_RD(60, 63, RB1) \
-    M17_IIR_FOUR(48, 49, 50, 51, 64, 65, 66, 67) M17_IIR_WR(64, 67, W0) M17_IIR_FOUR(52, 53, 54, 55, 68, 69, 70, 71) M17_IIR_WR(68, 71, W1) \
+    M17_IIR_FOUR(48, 49, 50, 51) M17_IIR_WR(48, 51, W0) M17_IIR_FOUR(52, 53, 54, 55) M17_IIR_WR(52, 55, W1) \
     "s_waitcnt lgkmcnt(2)\n" M17_IIR_RD(48, 51, RA0) M17_IIR_RD(52, 55, RA1) \
-    M17_IIR_FOUR(56, 57, 58, 59, 64, 65, 66, 67) M17_IIR_WR(64, 67, W2) M17_IIR_FOUR(60, 61, 62, 63, 68, 69, 70, 71) M17_IIR_WR(68, 71, W3)
+    M17_IIR_FOUR(56, 57, 58, 59) M17_IIR_WR(56, 59, W2) M17_IIR_FOUR(60, 61, 62, 63) M17_IIR_WR(60, 63, W3)
 #define M17_IIR_TICK_ASM \
-    "s_waitcnt lgkmcnt(0)\n v_mov_b32 v40, %[row]\n v_mov_b32 v70, %[ih1]\n v_mov_b32 v71, %[ih0]\n" \
+    "s_waitcnt lgkmcnt(0)\n v_mov_b32 v40, %[row]\n v_mov_b32 v62, %[ih1]\n v_mov_b32 v63, %[ih0]\n" \
     "s_mov_b32 s20, 0xbffda16a\n s_mov_b32 s21, 0x3f7b4df5\n s_mov_b32 s22, 6\n" \
-    "v_pk_mul_f32 v[80:81], v[70:71], s[20:21] op_sel:[0,0] op_sel_hi:[0,1]\n" \
-    "v_pk_mul_f32 v[82:83], v[70:71], s[20:21] op_sel:[1,0] op_sel_hi:[1,1]\n" \
+    "v_pk_mul_f32 v[80:81], v[62:63], s[20:21] op_sel:[0,0] op_sel_hi:[0,1]\n" \
+    "v_pk_mul_f32 v[82:83], v[62:63], s[20:21] op_sel:[1,0] op_sel_hi:[1,1]\n" \
     "ds_read_b128 v[48:51], v40\n ds_read_b128 v[52:55], v40 offset:16\n" \
-    "ds_write_b128 v40, v[64:67] offset:768\n ds_write_b128 v40, v[64:67] offset:768\n" \
+    "ds_write_b128 v40, v[60:63] offset:768\n ds_write_b128 v40, v[60:63] offset:768\n" \
     "1:\n" M17_IIR_16(32, 48, 64, 80, 0, 16, 32, 48) M17_IIR_16(96, 112, 128, 144, 64, 80, 96, 112) \
     "v_add_u32_e32 v40, 128, v40\n s_sub_u32 s22, s22, 1\n s_cmp_lg_u32 s22, 0\n s_cbranch_scc1 1b\n" \
-    "s_waitcnt lgkmcnt(0)\n v_mov_b32 %[h0], v71\n v_mov_b32 %[h1], v70\n v_mov_b32 %[h2], v69\n"
+    "s_waitcnt lgkmcnt(0)\n v_mov_b32 %[h0], v63\n v_mov_b32 %[h1], v62\n v_mov_b32 %[h2], v61\n"
 #define M17_IIR_TICK_CLOBBERS \
-    "v40", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
-    "v68", "v69", "v70", "v71", "v80", "v81", "v82", "v83", "v86", "s20", "s21", "s22", "scc", "memory"
+    "v40", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", \
+    "v80", "v81", "v82", "v83", "s20", "s21", "s22", "scc", "memory"
 static_assert(TICK == 192, "M17_IIR_TICK_ASM: six passes of 32 samples");
 // h0, h1, h2: the filter history (newest first) before / after the tick whose samples lie at LDS byte address `row`
 __device__ __forceinline__ void iir_tick_in_place(uint32_t row, float& h0, float& h1, float& h2)
