@@ -32,7 +32,7 @@ def worker(single):
         return h
     for f in range(2):
         placeholders += [hip_stream() for _ in range(nph)]
-        c = m17hip.Context(C, T); streams.append(torch.cuda.Stream()); c.set_stream(streams[-1].cuda_stream); c.synth(p, C, T); ctxs.append(c)
+        c = m17hip.Context(C, T); streams.append(torch.cuda.Stream(priority=int(os.environ.get("M17_BISECT_PRIO", "0")))); c.set_stream(streams[-1].cuda_stream); c.synth(p, C, T); ctxs.append(c)
     def groups(n):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for k0 in range(0, n, 2):
@@ -51,7 +51,7 @@ def worker(single):
         try:
             for g in range(G):
                 placeholders += [hip_stream() for _ in range(nph)]
-                c = m17hip.Context(Cg, T); ss.append(torch.cuda.Stream()); c.set_stream(ss[-1].cuda_stream)
+                c = m17hip.Context(Cg, T); ss.append(torch.cuda.Stream(priority=int(os.environ.get("M17_BISECT_PRIO", "0")))); c.set_stream(ss[-1].cuda_stream)
                 c.synth(p, Cg, T, chan0=g * Cg); c.tune(16, 1); c.synth(p, Cg, T, chan0=g * Cg); c.tune(16, 0)
                 c.reset(); c.run(); gs.append(c)
             def stream(n):
