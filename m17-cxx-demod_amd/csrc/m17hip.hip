@@ -766,16 +766,13 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
         if (hipMemcpy(c->level_gain, sched.data(), sched.size() * sizeof(core::Kalman2Gain), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
     }
     c->coef = build_coef();
-    {   // Stream priorities.  The replay stream (K2) outranks the others: its few workgroups must not queue behind K5's thousand.  The matched
-        // filter's stream ranks LOWEST: K1 is bulk work that runs segments ahead of the K2 / K5 chain a run waits for, and its launches are
-        // the ones with thousands of workgroups to hand out.  (A continued stream in a process that had created and closed contexts before:
-        // 24.6 -> 22.8 ms per step, and 24.5 -> 22.8 / 23.0 -> 22.7 / 28.3 -> 27.6 with one / two / three foreign streams created in front of
-        // every context; two batches in flight 20.9 / 21.9 / 21.1 / 21.5 -> 21.0 / 21.6 / 22.2 / 21.4; a fresh process with nothing else in
-        // it — bench.py — measures the same either way: NOTES 5.10.)
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
+    if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
+    {   // the replay stream outranks the others: its few workgroups must not queue behind K5's thousand.  (K1's stream at the LOWEST priority
+        // was tried: a continued stream of 2 x 2048 channels 24.6 -> 22.8 ms in a process with history, but 2 x 1024 channels 11.5 -> 16.1 ms —
+        // K1 starves behind the other group's kernels: NOTES 5.10.)
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return fail(M17HIP_EHIP);
-        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
-        if (hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least) != hipSuccess) return fail(M17HIP_EHIP);
         if (hipStreamCreateWithPriority(&c->side3, hipStreamNonBlocking, greatest) != hipSuccess) return fail(M17HIP_EHIP);
     }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
@@ -1403,8 +1400,7 @@ int m17hip_fir_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags,
     auto& ev_fir = c->ev_fir_[c->slot];
     // (Tried: the chain on compute units of its own — hipExtStreamCreateWithCUMask, a quarter of the chip — with the two throughput kernels on
     //  the rest: the chain's pieces 0.79 -> 0.74 ms, the call 8.2 -> 9.0 ms.  What stretches the chain beside them is not its SIMD: NOTES 5.4.)
-    // (the correlations — the bulk work nothing here waits for until the end — on the lowest-priority stream, the matched filter, which the chain waits for, on the normal one)
-    const hipStream_t st_chain = c->stream, st_fir = c->side, st_corr = c->side2;
+    const hipStream_t st_chain = c->stream, st_fir = c->side2, st_corr = c->side;
     const uint32_t chain_wgs = (C + LP_CH - 1) / LP_CH;
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     for (hipStream_t st : {st_chain, st_fir, st_corr})
