@@ -158,8 +158,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="independent batches (contexts) whose steps overlap: the tail of one step (K2/K5 "
                     "alternation, chip half idle) runs beside the front end of the next; 1 = one step after the other")
     ap.add_argument("--prewarm", type=int, default=48, help="untimed steps before the --warmup steps (clock ramp of an idle GPU: about 1.3 s)")
-    ap.add_argument("--stagger", action="store_true", help="with --in-flight > 1: queue step k + 1 before waiting for step k (a pipeline) instead of "
-                    "launching the batches of a group together and waiting for them together (default)")
+    ap.add_argument("--stagger", type=int, default=1, help="with --in-flight > 1: 1 (default) = queue step k + 1 before waiting for step k (a pipeline, what a host loop that "
+                    "feeds several independent batches does); 0 = launch the batches of a group together and wait for them together (the default up to round 5: 1.1-1.8 %% slower now, "
+                    "6 %% faster in round 2)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="m17hip_tune knob for experiments (e.g. 10=1: K3 as the four-wave pipeline); reported in config")
     ap.add_argument("--single-stream", type=int, default=1, help="1 = also time the single-stream regime (ONE context, state carried from run to run, no "
                     "reset: a live feed; the front end of run k + 1 is queued through m17hip_demod_front while run k's K2/K5 chain drains) -> value_single_stream")
@@ -326,7 +327,7 @@ def main():
                 total = finish(k - 1)
             return finish(n_steps - 1)
         for k0 in range(0, n_steps, F):   # groups of F steps queued together and waited for together: the batches go through the same
-            ks = range(k0, min(k0 + F, n_steps))   # phases side by side (measured 6 % faster than half a step apart, tools/regime_bench.py)
+            ks = range(k0, min(k0 + F, n_steps))   # phases side by side (round 2: 6 % faster than half a step apart, tools/regime_bench.py; round 5: 1.1-1.8 % slower, NOTES 5.12)
             for k in ks:
                 launch(k)
             for k in ks:
