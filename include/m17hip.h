@@ -75,7 +75,10 @@ int m17hip_last_hip_error(const m17hip_ctx* ctx);
 int m17hip_version(void);
 
 /* Context: device slabs for `max_channels` x `max_samples` (per run).  Replaces constructing one
- * M17Demodulator<float> per channel (apps/m17-demod.cpp:455, M17Demodulator.h:180-182). */
+ * M17Demodulator<float> per channel (apps/m17-demod.cpp:455, M17Demodulator.h:180-182).
+ * max_samples <= M17HIP_MAX_SAMPLES_PER_RUN (11.6 minutes of 48 kSPS in ONE run; a stream of any length is continued run after run):
+ * the kernels address a channel row — sixteen rows in the limit-filter replay — with 32-bit byte offsets.  Beyond it: M17HIP_EINVAL. */
+#define M17HIP_MAX_SAMPLES_PER_RUN 33553152u
 int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out);
 void m17hip_ctx_destroy(m17hip_ctx* ctx);
 /* Deployment advice (bit set; 0 = nothing to say).  Bit 0 (M17HIP_ADVICE_HW_QUEUES): the process runs with fewer than 8 hardware
@@ -292,7 +295,13 @@ int m17hip_set_channel_base(m17hip_ctx* ctx, uint32_t channel_base);
  * records on the device, the counts are all-gathered, the records travel to `root` with their exact sizes (grouped
  * ncclSend / ncclRecv) and land in recs_host[capacity] rank after rank — with contiguous shards and channel bases set that is
  * global (channel, seq) order.  counts[nranks] (optional) and *total are filled on every rank; recs_host is only used on
- * `root`.  M17HIP_ETRUNC if total > capacity, M17HIP_ECOMM if RCCL is missing or fails (m17hip_comm_last_error). */
+ * `root`.  M17HIP_ETRUNC if total > capacity, M17HIP_ECOMM if RCCL is missing or fails (m17hip_comm_last_error).
+ * Failure behaviour: a rank-local failure (its compaction, an allocation, a word it cannot write or read) travels inside the two
+ * all-gathers every call makes before any record moves — the failing rank returns its own code, every other rank M17HIP_ECOMM, all of
+ * them from the same call, and the communicator stays usable.  What words cannot settle (a peer that died, a rank that lost its device
+ * between the second all-gather and the records) is bounded in time: every wait of the call has a deadline (m17hip_tune key 31, default
+ * 120 s); when it passes the communicator is given up (ncclCommAbort), the call and every later call through it return M17HIP_ECOMM,
+ * and the ranks create a new communicator to go on. */
 typedef struct m17hip_comm m17hip_comm;
 #define M17HIP_COMM_ID_BYTES 128
 int m17hip_comm_get_id(void* id128);
@@ -349,8 +358,10 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  * key 16: 1 = m17hip_upload_i16, m17hip_upload_i16_device and m17hip_synth_i16 write the context's STAGING slab (as
  *        m17hip_upload_i16_async does, but complete when they return) and stage it for the next run; 0 (default) = the current slab.
  * key 30 (tests): fault injection for m17hip_gather_frames*: 1 = this rank's compaction fails inside the call, 2 = the root's staging
- *        allocation fails, 3 = the root claims no room and this rank's word of the second exchange cannot be written; 0 = none.  Every rank
- *        still makes all its collective calls and returns the failure.
+ *        allocation fails, 3 = this rank's word of the second exchange cannot be written (and, on the root, the staging is grown whether
+ *        it has to be or not), 4 = this rank cannot read the first exchange, 5 = this rank cannot read the second exchange; 0 = none.
+ *        Under 1-4 every rank makes all its collective calls and all return from the same call; 5 is the case key 31 bounds.
+ * key 31: deadline in milliseconds of every wait inside m17hip_gather_frames* (default 120000, 0 = none).
  * The measurement build of the library (make -C m17-cxx-demod_amd/csrc tools -> libm17hip_tools.so, -DM17_TOOLS; tools/ only) adds
  * key 1 / key 19 (section timers / per-wave working times of the sequential kernel -> m17hip_debug_counters) and the schedule
  * experiments 4, 5, 12, 14, 21, 25 (csrc/m17hip.hip, m17hip_tune). */

@@ -21,6 +21,7 @@ struct Rccl {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;   // optional: a communicator whose exchange did not end in time is given up through it
     bool ok = false;
 };
 
@@ -44,6 +45,7 @@ inline const Rccl& rccl()
         M17_RCCL_SYM(Recv, ncclRecv);
         M17_RCCL_SYM(GroupStart, ncclGroupStart);
         M17_RCCL_SYM(GroupEnd, ncclGroupEnd);
+        M17_RCCL_SYM(CommAbort, ncclCommAbort);
 #undef M17_RCCL_SYM
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
     });

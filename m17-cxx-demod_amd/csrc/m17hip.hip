@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -98,7 +99,9 @@ struct m17hip_ctx {
     uint32_t* diag_count = nullptr;   // [maxC]
     uint32_t diag_cap = 0;
     uint32_t kalman_order = 3;        // evaluation order of the Kalman updates (m17hip_set_kalman_order)
-    int gather_fault = 0;             // tuning knob 30 (tests): 1 = this rank's compaction fails inside the gather, 2 = the root's staging allocation fails, 3 = its word of exchange 2 is not written
+    int gather_fault = 0;             // tuning knob 30 (tests): 1 = this rank's compaction fails inside the gather, 2 = the root's staging allocation fails, 3 = its word of exchange 2 is not written,
+                                      // 4 = it cannot read exchange 1, 5 = it cannot read exchange 2
+    uint32_t gather_timeout_ms = 120000;   // tuning knob 31: bound of every wait inside m17hip_gather_frames (0 = none)
     uint32_t channel_base = 0;        // global id of channel 0 (m17hip_set_channel_base): records carry channel_base + c
     uint32_t front_first = 0;         // tuning knob 12: segments of K1 that must be complete before the first K5 starts (0 = its own only)
     int redo_form = 0;                // tuning knob 20: the replay's redo beside K5, state only (0, default), or in front of K5 with the history stored (1)
@@ -167,9 +170,12 @@ struct m17hip_comm {
     int rank = 0, nranks = 1;
     int last_rccl = 0;
     uint64_t* counts_dev = nullptr;   // [2 * nranks] words of the status / count exchanges
+    uint64_t* words_host = nullptr;   // pinned, [2 + 2 * nranks]: this rank's word pair on its way out, every rank's on the way in — no copy of an exchange ever
+                                      // targets memory that a call which ran out of time has already given back
     uint32_t serial = 0;              // gather calls made through this communicator (every rank counts the same)
     FrameRec* gathered = nullptr;     // root: every rank's records, rank after rank
     uint64_t gathered_cap = 0;
+    bool dead = false;                // an exchange did not end in time or a collective call failed: given up, every later call returns M17HIP_ECOMM
 };
 
 namespace {
@@ -691,11 +697,11 @@ int m17hip_advice(const m17hip_ctx* ctx)
     const char* q = std::getenv("GPU_MAX_HW_QUEUES");
     return (!q || std::atoi(q) < 8) ? M17HIP_ADVICE_HW_QUEUES : 0;
 }
-int m17hip_version(void) { return 500; }
+int m17hip_version(void) { return 600; }
 
 int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out)
 {
-    if (!out || max_channels == 0 || max_samples == 0) return M17HIP_EINVAL;
+    if (!out || max_channels == 0 || max_samples == 0 || max_samples > M17HIP_MAX_SAMPLES_PER_RUN) return M17HIP_EINVAL;   // (argument checks: before any HIP call)
     m17hip_ctx* c = new (std::nothrow) m17hip_ctx();
     if (!c) return M17HIP_ENOMEM;
     c->device = device;
@@ -706,6 +712,10 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     if (!guard_.ok) return fail(M17HIP_EHIP);
     c->xpitch = round_up((size_t)XPRE + max_samples + 8, 8);
     c->ypitch = round_up((size_t)YPRE + max_samples + 4, 4);
+    // K2 stores the limit-filter history of a workgroup's GT_CPW channel rows through ONE buffer descriptor with 32-bit byte offsets
+    // (m17_gate_kernel.hpp, limit_track_pass): the rows of a workgroup must fit below the offset that stands for "no store"
+    static_assert(M17HIP_MAX_SAMPLES_PER_RUN == (0x7FFF0000u / (4u * GT_CPW)) - 256u, "include/m17hip.h: M17HIP_MAX_SAMPLES_PER_RUN");
+    if ((size_t)GT_CPW * c->ypitch * 4u > (size_t)0x7FFF0000u) return fail(M17HIP_EINVAL);
     c->ticks_cap = max_samples / TICK + 2;
     c->rec_cap = c->rec_cap_alloc = 2 * (max_samples / 1920 + 2) + 4;  // <= 2 callbacks per 1920-sample frame
     const size_t C = max_channels;
@@ -1902,7 +1912,8 @@ int m17hip_comm_create(m17hip_ctx* c, const void* id128, int rank, int nranks, m
     if (r != ncclSuccess) { c->last_hip = 0x10000 | (int)r; delete m; return M17HIP_ECOMM; }   // (no communicator to ask: the ncclResult_t is left in m17hip_last_hip_error, | 0x10000)
     hipError_t e = hipMalloc((void**)&m->counts_dev, 2 * (size_t)nranks * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMemset(m->counts_dev, 0xFF, 2 * (size_t)nranks * sizeof(uint64_t));   // (no slot looks like a word of call 1)
-    if (e != hipSuccess) { c->last_hip = (int)e; R.CommDestroy(m->comm); delete m; return M17HIP_ENOMEM; }
+    if (e == hipSuccess) e = hipHostMalloc((void**)&m->words_host, (2 + 2 * (size_t)nranks) * sizeof(uint64_t), hipHostMallocDefault);
+    if (e != hipSuccess) { c->last_hip = (int)e; free_dev(m->counts_dev); R.CommDestroy(m->comm); delete m; return M17HIP_ENOMEM; }
     *out = m;
     return M17HIP_OK;
 }
@@ -1915,7 +1926,8 @@ void m17hip_comm_destroy(m17hip_comm* m)
     hipSetDevice(m->device);
     free_dev(m->counts_dev);
     free_dev(m->gathered);
-    if (m->comm) rccl().CommDestroy(m->comm);
+    if (m->words_host) { (void)hipHostFree(m->words_host); m->words_host = nullptr; }
+    if (m->comm && !m->dead) rccl().CommDestroy(m->comm);   // (a communicator that was given up is not waited for)
     if (prev >= 0) hipSetDevice(prev);
     delete m;
 }
@@ -1926,20 +1938,60 @@ void m17hip_comm_destroy(m17hip_comm* m)
 //                                                 [1] = the ROOT's staging capacity in records (0 from the other ranks)
 //       the serial makes a stale word recognisable: a rank whose own word could not be written to the device (its HIP calls fail)
 //       still joins the all-gather, and what its peers then read in its slot is a word of an EARLIER exchange
-//   exchange 2 (all-gather, one word per rank) only if the gathered set does not fit the root's staging: the root grows it and says
-//       whether that worked (the others say "ok"); every rank knows from exchange 1 that this exchange is due.  Its words carry a
-//       phase tag in the status byte's place (0xA5: no status of exchange 1 looks like it, and read as one it is an error) and the
-//       serial again; EVERY rank looks at EVERY slot — a slot without the tag and this call's serial is a word that could not be
-//       written, whoever's it is — so that all ranks leave together or go on together
-//   exchange 3: grouped ncclSend / ncclRecv of the exact record sets, rank after rank = global (channel, seq) order
+//   exchange 2 (all-gather, one word per rank), ALWAYS: "I have read exchange 1 and am ready for the records" — the root grows its
+//       staging first when the gathered set does not fit and says whether that worked; a rank that could NOT read exchange 1 (it does
+//       not know the counts and cannot take part in exchange 3) says so here, where up to round 5 it returned and left its peers
+//       waiting in exchange 3.  The words carry a phase tag in the status byte's place (0xA5: no status of exchange 1 looks like it,
+//       and read as one it is an error) and the serial again; EVERY rank looks at EVERY slot — a slot without the tag and this call's
+//       serial is a word that could not be written, whoever's it is — so that all ranks leave together or go on together
+//   exchange 3: grouped ncclSend / ncclRecv of the exact record sets, rank after rank = global (channel, seq) order; ranks without
+//       records are skipped on both sides
+// What no exchange of words can close (a rank that reads exchange 1 but not exchange 2; a peer process that died) is bounded in TIME:
+// every wait of this function is a bounded one (m17hip_tune key 31, default 120 s); a wait that runs out gives the communicator up
+// (ncclCommAbort where the library has it) and the call — and every later call through that communicator — returns M17HIP_ECOMM.
+static void comm_give_up(m17hip_comm* m, int code)
+{
+    m->last_rccl = code;
+    if (m->dead) return;
+    m->dead = true;
+    const Rccl& R = rccl();
+    if (m->comm && R.CommAbort) { R.CommAbort(m->comm); m->comm = nullptr; }   // (without it the communicator is left alone: destroying it would wait for the exchange)
+}
+// hipStreamSynchronize with a deadline: 0 = done, M17HIP_ECOMM = not in time (communicator given up), M17HIP_EHIP = the stream reports an error
+static int comm_wait(m17hip_ctx* c, m17hip_comm* m)
+{
+    if (c->gather_timeout_ms == 0) {
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->last_hip = (int)e; return M17HIP_EHIP; }
+        return M17HIP_OK;
+    }
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint64_t spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) return M17HIP_OK;
+        if (e != hipErrorNotReady) { c->last_hip = (int)e; return M17HIP_EHIP; }
+        (void)hipGetLastError();
+        if ((spins & 63) == 63) {
+            timespec t;
+            clock_gettime(CLOCK_MONOTONIC, &t);
+            const double ms = (t.tv_sec - t0.tv_sec) * 1e3 + (t.tv_nsec - t0.tv_nsec) * 1e-6;
+            if (ms > (double)c->gather_timeout_ms) { comm_give_up(m, (int)ncclSystemError); return M17HIP_ECOMM; }
+            if (ms > 2.0) { timespec nap{0, 50000}; nanosleep(&nap, nullptr); }   // (a gather is through in well under that: only a stuck one gets here)
+        }
+    }
+}
+
 static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* counts_host,
                               uint64_t* total_out, bool dest_is_device)
 {
     if (!c || !m || m->device != c->device || root < 0 || root >= m->nranks || (m->rank == root && capacity && !recs_host)) return M17HIP_EINVAL;
     GUARD(c);
+    if (m->dead) return M17HIP_ECOMM;
     const Rccl& R = rccl();
     const bool is_root = m->rank == root;
     auto hip_code = [&](hipError_t e) { c->last_hip = (int)e; return e == hipErrorOutOfMemory ? M17HIP_ENOMEM : M17HIP_EHIP; };
+    auto comm_failed = [&](ncclResult_t q) { comm_give_up(m, (int)q); return M17HIP_ECOMM; };   // a collective call itself failed: nothing more can be agreed on
     // 1. this rank's records, dense and (channel, seq)-ordered, in the context's compaction buffer
     uint64_t mine = 0;
     int local = c->recs_valid ? M17HIP_OK : M17HIP_ESTATE;
@@ -1967,59 +2019,72 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
     const uint64_t serial = (uint64_t)(++m->serial & 0xFFFFu);
     constexpr uint64_t COUNT_MASK = (1ull << 40) - 1;
     if (mine > COUNT_MASK && !local) { local = M17HIP_EINVAL; mine = 0; }   // (2^40 records: not a real case, but the word has no room for more)
-    uint64_t word[2] = {(mine & COUNT_MASK) | (serial << 40) | ((uint64_t)(uint8_t)(-local) << 56),
-                        is_root ? (c->gather_fault == 3 ? 0ull : m->gathered_cap) : 0ull};   // (fault 3: the root claims no room, so that exchange 2 takes place)
-    std::vector<uint64_t> words(2 * (size_t)m->nranks, 0);
+    uint64_t* const word = m->words_host;        // (pinned, owned by the communicator: see there)
+    uint64_t* const words = m->words_host + 2;
+    word[0] = (mine & COUNT_MASK) | (serial << 40) | ((uint64_t)(uint8_t)(-local) << 56);
+    word[1] = is_root ? m->gathered_cap : 0ull;
+    const size_t words_n = 2 * (size_t)m->nranks;
+    int unread = M17HIP_OK;   // this rank could not read exchange 1
     {
         hipError_t e = hipMemcpyAsync(m->counts_dev + 2 * m->rank, word, 16, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess && !local) local = hip_code(e);     // (our slot keeps the previous call's word: its serial gives it away)
         const ncclResult_t q = R.AllGather(m->counts_dev + 2 * m->rank, m->counts_dev, 2, ncclUint64, m->comm, c->stream);
-        if (q != ncclSuccess) { m->last_rccl = (int)q; return M17HIP_ECOMM; }   // (the collective itself failed: nothing more can be agreed on)
-        e = hipMemcpyAsync(words.data(), m->counts_dev, words.size() * 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return hip_code(e);   // (this rank cannot read what was agreed on: it cannot take part in the rest; its peers' calls fail with it)
+        if (q != ncclSuccess) return comm_failed(q);
+        e = c->gather_fault == 4 ? hipErrorUnknown : hipMemcpyAsync(words, m->counts_dev, words_n * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) unread = hip_code(e);
+        const int w = comm_wait(c, m);
+        if (w == M17HIP_ECOMM) return w;     // not in time: the communicator is given up
+        if (w && !unread) unread = w;
     }
     std::vector<uint64_t> counts((size_t)m->nranks, 0);
     uint64_t total = 0;
     int remote = M17HIP_OK;
-    for (int k = 0; k < m->nranks; ++k) {
-        const uint64_t w = words[2 * (size_t)k];
-        int code = -(int)(w >> 56);
-        if (((w >> 40) & 0xFFFFu) != serial) code = M17HIP_ECOMM;   // a stale word: that rank could not deliver this call's
-        counts[k] = code ? 0 : (w & COUNT_MASK);
-        total += counts[k];
-        if (code && !remote) remote = code;
-    }
-    if (counts_host) std::memcpy(counts_host, counts.data(), counts.size() * 8);
-    if (total_out) *total_out = total;
-    if (local) return local;
-    if (remote) return M17HIP_ECOMM;   // some other rank could not deliver its records: nobody sends, everybody returns
-    // 3. exchange 2, only if the root's staging is too small (every rank sees that in the root's second word)
-    if (total > words[2 * (size_t)root + 1]) {
-        int rc = M17HIP_OK;
-        if (is_root) {
-            free_dev(m->gathered, &c->last_hip); m->gathered_cap = 0;
-            const uint64_t want = std::max<uint64_t>(total + total / 8, 1024);
-            const hipError_t e = c->gather_fault == 2 ? hipErrorOutOfMemory : hipMalloc((void**)&m->gathered, (size_t)want * sizeof(FrameRec));
-            if (e != hipSuccess) rc = hip_code(e); else m->gathered_cap = want;
-        }
-        constexpr uint64_t PHASE2 = 0xA5ull << 56;
-        const uint64_t st = PHASE2 | (serial << 40) | (uint64_t)(uint8_t)(-rc);
-        const hipError_t ew = c->gather_fault == 3 ? hipErrorUnknown : hipMemcpyAsync(m->counts_dev + 2 * m->rank, &st, 8, hipMemcpyHostToDevice, c->stream);
-        if (ew != hipSuccess && !rc) rc = hip_code(ew);          // (our slot keeps a word of exchange 1: no tag — every rank sees that)
-        const ncclResult_t q = R.AllGather(m->counts_dev + 2 * m->rank, m->counts_dev, 2, ncclUint64, m->comm, c->stream);
-        if (q != ncclSuccess) { m->last_rccl = (int)q; return M17HIP_ECOMM; }
-        hipError_t e = hipMemcpyAsync(words.data(), m->counts_dev, words.size() * 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return hip_code(e);   // (this rank cannot read what was agreed on: as in exchange 1)
-        bool all_ok = true;
+    if (!unread) {
         for (int k = 0; k < m->nranks; ++k) {
             const uint64_t w = words[2 * (size_t)k];
-            if ((w & (0xFFull << 56)) != PHASE2 || ((w >> 40) & 0xFFFFu) != serial || (w & 0xFFu)) all_ok = false;
+            int code = -(int)(w >> 56);
+            if (((w >> 40) & 0xFFFFu) != serial) code = M17HIP_ECOMM;   // a stale word: that rank could not deliver this call's
+            counts[k] = code ? 0 : (w & COUNT_MASK);
+            total += counts[k];
+            if (code && !remote) remote = code;
         }
-        if (rc) return rc;
-        if (!all_ok) return M17HIP_ECOMM;   // the root has no room for the gathered set, or some rank's word did not arrive: nobody sends
+        if (counts_host) std::memcpy(counts_host, counts.data(), counts.size() * 8);
+        if (total_out) *total_out = total;
     }
+    // 3. exchange 2: every rank, whatever it knows by now.  The root grows its staging when the gathered set does not fit it
+    //    (only when the records are going to travel: every rank that read exchange 1 comes to the same conclusion about that)
+    int rc = unread;
+    if (!unread && !local && !remote && is_root && (total > m->gathered_cap || c->gather_fault == 3)) {   // (fault 3 on the root: grown in any case)
+        free_dev(m->gathered, &c->last_hip); m->gathered_cap = 0;
+        const uint64_t want = std::max<uint64_t>(total + total / 8, 1024);
+        const hipError_t e = c->gather_fault == 2 ? hipErrorOutOfMemory : hipMalloc((void**)&m->gathered, (size_t)want * sizeof(FrameRec));
+        if (e != hipSuccess) rc = hip_code(e); else m->gathered_cap = want;
+    }
+    constexpr uint64_t PHASE2 = 0xA5ull << 56;
+    {
+        word[0] = PHASE2 | (serial << 40) | (uint64_t)(uint8_t)(-rc);
+        const hipError_t ew = c->gather_fault == 3 ? hipErrorUnknown : hipMemcpyAsync(m->counts_dev + 2 * m->rank, word, 8, hipMemcpyHostToDevice, c->stream);
+        if (ew != hipSuccess && !rc) rc = hip_code(ew);          // (our slot keeps a word of exchange 1: no tag — every rank sees that)
+        const ncclResult_t q = R.AllGather(m->counts_dev + 2 * m->rank, m->counts_dev, 2, ncclUint64, m->comm, c->stream);
+        if (q != ncclSuccess) return comm_failed(q);
+        hipError_t e = c->gather_fault == 5 ? hipErrorUnknown : hipMemcpyAsync(words, m->counts_dev, words_n * 8, hipMemcpyDeviceToHost, c->stream);
+        const int w = comm_wait(c, m);
+        if (w == M17HIP_ECOMM) return w;
+        // this rank cannot read what was agreed on: it cannot know whether the records travel, so it takes no part in exchange 3.  If they
+        // do, its peers' waits run out (comm_wait) — the one case that costs them the communicator
+        if (e != hipSuccess) return hip_code(e);
+        if (w) return w;
+    }
+    if (unread) return unread;
+    if (local) return local;
+    if (remote) return M17HIP_ECOMM;   // some other rank could not deliver its records: nobody sends, everybody returns
+    bool all_ok = true;
+    for (int k = 0; k < m->nranks; ++k) {
+        const uint64_t w = words[2 * (size_t)k];
+        if ((w & (0xFFull << 56)) != PHASE2 || ((w >> 40) & 0xFFFFu) != serial || (w & 0xFFu)) all_ok = false;
+    }
+    if (rc) return rc;
+    if (!all_ok) return M17HIP_ECOMM;   // the root has no room for the gathered set, a rank could not read the counts, or some rank's word did not arrive: nobody sends
     // 4. the records travel to the root with their exact sizes, rank after rank = global channel order
     if (is_root) {
         ncclResult_t q = R.GroupStart();
@@ -2030,7 +2095,7 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
         }
         const ncclResult_t qe = R.GroupEnd();   // the group is closed whatever happened inside it
         if (q == ncclSuccess) q = qe;
-        if (q != ncclSuccess) { m->last_rccl = (int)q; return M17HIP_ECOMM; }
+        if (q != ncclSuccess) return comm_failed(q);
         off = 0;
         hipError_t he = hipSuccess;
         for (int k = 0; k < m->nranks; ++k) {   // the root's own share: a plain copy, outside the group
@@ -2038,9 +2103,14 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
             off += counts[k];
         }
         if (he != hipSuccess) return hip_code(he);
+        if (const int w = comm_wait(c, m)) return w;
+        // the caller's buffer is written only now, when nothing on the stream depends on a peer any more: a call that ran out of time
+        // never leaves a copy into the caller's memory behind
         const uint64_t n = std::min(total, capacity);
-        if (n) HIPCHK(c, hipMemcpyAsync(recs_host, m->gathered, (size_t)n * sizeof(FrameRec), dest_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n) {
+            HIPCHK(c, hipMemcpyAsync(recs_host, m->gathered, (size_t)n * sizeof(FrameRec), dest_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
         if (overflow) return M17HIP_EOVERFLOW;
         return total > capacity ? M17HIP_ETRUNC : M17HIP_OK;
     }
@@ -2049,9 +2119,9 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
         if (q == ncclSuccess) q = R.Send(c->compact, (size_t)mine * sizeof(FrameRec), ncclUint8, root, m->comm, c->stream);
         const ncclResult_t qe = R.GroupEnd();
         if (q == ncclSuccess) q = qe;
-        if (q != ncclSuccess) { m->last_rccl = (int)q; return M17HIP_ECOMM; }
+        if (q != ncclSuccess) return comm_failed(q);
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (const int w = comm_wait(c, m)) return w;
     return overflow ? M17HIP_EOVERFLOW : M17HIP_OK;
 }
 
@@ -2154,9 +2224,15 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         }
         return M17HIP_OK;
     case 30:  // fault injection for m17hip_gather_frames (tests): 0 = none, 1 = this rank's compaction fails, 2 = the root's staging allocation fails,
-              // 3 = this rank's word of exchange 2 cannot be written (its slot keeps the word of exchange 1)
-        if (value < 0 || value > 3) return M17HIP_EINVAL;
+              // 3 = this rank's word of exchange 2 cannot be written (its slot keeps the word of exchange 1) and the root's staging is grown,
+              // 4 = this rank cannot read exchange 1, 5 = this rank cannot read exchange 2
+        if (value < 0 || value > 5) return M17HIP_EINVAL;
         c->gather_fault = (int)value;
+        return M17HIP_OK;
+    case 31:  // bound, in milliseconds, of every wait inside m17hip_gather_frames[_device] (default 120000; 0 = wait for ever): a wait that runs out
+              // gives the communicator up (ncclCommAbort) and the call returns M17HIP_ECOMM, as does every later call through that communicator
+        if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
+        c->gather_timeout_ms = (uint32_t)value;
         return M17HIP_OK;
     case 16:  // the in-place producers (m17hip_upload_i16, m17hip_upload_i16_device, m17hip_synth_i16) write the STAGING slab instead
         c->stage_inputs = value != 0;

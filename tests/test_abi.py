@@ -47,3 +47,35 @@ def test_product_never_touches_the_oracle():
                     s = line.strip()
                     if s.startswith(("#include", "import ", "from ")) or "CDLL" in s or "dlopen" in s:
                         assert "oracle" not in s, (f, s)
+
+
+def test_ctx_create_refuses_a_run_length_the_kernels_cannot_address():
+    """the limit-filter replay stores sixteen channel rows through one descriptor with 32-bit byte offsets; a max_samples beyond
+    M17HIP_MAX_SAMPLES_PER_RUN is an argument error (checked before any HIP call: no GPU needed here), not silently dropped stores."""
+    import ctypes as C
+    hdr = open(os.path.join(ROOT, "include", "m17hip.h")).read()
+    lim = int(re.search(r"#define M17HIP_MAX_SAMPLES_PER_RUN (\d+)u", hdr).group(1))
+    assert 16 * 4 * (lim + 104) <= 0x7FFF0000 < 16 * 4 * (lim + 104 + 256)
+    lib = m17hip.load_library()
+    h = C.c_void_p()
+    assert lib.m17hip_ctx_create(C.c_int(0), C.c_uint32(16), C.c_uint32(lim + 1), C.byref(h)) == -1 and not h.value
+    assert lib.m17hip_ctx_create(C.c_int(0), C.c_uint32(0), C.c_uint32(100), C.byref(h)) == -1
+
+
+def test_fake_rccl_exports_what_the_product_binds():
+    """The test double of librccl (tests/fake_rccl, used by tests/test_gpu_gather_ranks.py only) defines every symbol m17_gather.hpp binds."""
+    import subprocess
+    so = os.path.join(ROOT, "tests", "fake_rccl", "librccl.so.1")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(so)], check=True)
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    gather = open(os.path.join(ROOT, "m17-cxx-demod_amd", "csrc", "m17_gather.hpp")).read()
+    bound = re.findall(r"M17_RCCL_SYM\(\w+, (nccl\w+)\)", gather)
+    assert len(bound) >= 9
+    for name in bound:
+        assert re.search(rf"\bT {name}\b", out), name
+    # ... and nothing of the product names it
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "m17-cxx-demod_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", "Makefile")):
+                assert "fake_rccl" not in open(os.path.join(dirpath, f), errors="ignore").read(), f
