@@ -34,8 +34,21 @@ CHAIN_BYTES = 2.0 + 64.0 / 1920.0          # full chain: 2 B read per sample + o
 FRONT_BYTES = 2.0 + 4.0 + 4.0 + 4 * 4.0    # config 2: int16 in, FIR out, limit out, four correlations out
 # what each kernel of the four-pass structure moves per input sample BY DESIGN (intermediates ybuf / hbuf / DCD
 # table included) — reported separately as `kernel_design_*`, never as the roofline fraction
+FRONT_OWN_BYTES = {"fir_rrc150": 6.0, "limit_track": 8.0, "correlator": 20.0}   # config 2: what each of its three kernels moves itself
 DESIGN_BYTES = {"fir_rrc150": 6.0, "dcd": 2.0 + 48.0 / 192.0, "limit_track": 8.0 + 48.0 / 192.0, "demod_seq": 4.0 + 48.0 / 192.0 + 64.0 / 1920.0,
                 "compact": 2 * 64.0 / 1920.0, "correlator": 4.0 + 20.0}
+
+
+def kernel_source_sha16():
+    """First 16 hex digits of the sha256 over the device sources of the library (tools/make_valu.py stamps profiles/valu.json with it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "m17-cxx-demod_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(csrc, "*.hip")) +
+                    [os.path.join(ROOT, "m17-cxx-demod_amd", "include", "m17cxx", "detail", "core.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def usable_cpus():
@@ -76,7 +89,7 @@ def rank_commands(n, argv, port):
     out = []
     for r in range(n):
         env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "GROUP_RANK": "0",
-               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "M17_BENCH_LAUNCHED": "1"}
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
         out.append(([sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"], env))
     return out
 
@@ -118,6 +131,17 @@ def launch_ranks(args, argv):
     for t in threads:
         t.start()
     worst, alive, stopped = 0, set(range(n)), set()
+    t_start, t_stop = time.time(), None
+    limit = float(getattr(args, "launch_timeout", 3600.0))
+
+    def stop_others(why):      # exactly the processes started above: SIGTERM now, SIGKILL to whoever is still there ten seconds later
+        nonlocal t_stop
+        print(f"bench.py: {why}; stopping the other ranks", file=sys.stderr)
+        for q in alive:
+            procs[q].terminate()
+            stopped.add(q)
+        t_stop = t_stop or time.time()
+
     while alive:
         for r in sorted(alive):
             code = procs[r].poll()
@@ -126,10 +150,13 @@ def launch_ranks(args, argv):
             alive.discard(r)
             if code != 0 and r not in stopped:   # (a rank stopped from here reports the signal: not its own failure)
                 worst = max(worst, code if code > 0 else 128 - code)
-                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
-                for q in alive:      # exactly the processes started above
-                    procs[q].terminate()
-                    stopped.add(q)
+                stop_others(f"rank {r} exited with code {code}")
+        if alive and t_stop is None and time.time() - t_start > limit:   # a rank stuck in a collective or a HIP call: nobody waits for ever
+            worst = max(worst, 124)
+            stop_others(f"still running after --launch-timeout {limit:.0f} s")
+        if alive and t_stop is not None and time.time() - t_stop > 10.0:
+            for q in alive:
+                procs[q].kill()
         time.sleep(0.2)
     for t in threads:
         t.join(timeout=5)
@@ -173,6 +200,7 @@ def main():
                     "always-on workload; the `bursty` leg of the default line is 0.2)")
     ap.add_argument("--bursty-steps", type=int, default=6, help="N = 1: steps of the bursty leg (the same 4096 x 480 000, every channel ONE transmission of a fifth of the run, "
                     "loud noise for the rest: the carrier detect is off 80 % of the time) reported as `bursty`; 0 = skip")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="with --gpus N > 1 and no launcher: seconds after which the ranks are stopped (exit code 124)")
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 code path (process group, communicators, gather per step) with WORLD_SIZE = 1")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # no launcher around us: be the launcher (before torch / the GPU are touched)
@@ -601,7 +629,10 @@ def main():
     vpath = os.path.join(ROOT, "profiles", "valu.json")
     if os.path.exists(vpath):
         vj = json.load(open(vpath))
-        if vj.get("channels") == C and vj.get("samples") == T:
+        stale = vj.get("kernel_source_sha16") not in (None, kernel_source_sha16())   # counted on other kernels than the ones that just ran: not this build's figure
+        if stale:
+            valu["note"] = "profiles/valu.json was made from other kernel sources than this build's: instruction counts and issue_util left out"
+        if vj.get("channels") == C and vj.get("samples") == T and not stale:
             mix = vj.get("clock_in_mix") if isinstance(vj.get("clock_in_mix"), dict) else {}
             clk_mhz = mix.get("busy_mean_mhz") or 2100.0
             n_simd = 4 * int(torch.cuda.get_device_properties(dev).multi_processor_count)
@@ -659,7 +690,7 @@ def main():
         dt2 = (time.perf_counter() - t2) / args.config2_steps
         c2.timing(False)
         k2 = {}
-        for name in ("fir_rrc150", "correlator"):
+        for name in ("fir_rrc150", "limit_track", "correlator"):   # (matched filter, the limit filter's chain, the four correlations: each on its own stream)
             ms, n = c2.timing_get(name)
             k2[name] = {"ms_avg": (ms / n) if n else None, "ms_per_step": ms / args.config2_steps}
         dom2 = max(k2, key=lambda k: k2[k]["ms_per_step"])
@@ -669,12 +700,45 @@ def main():
                    "roofline": {"bound": "hbm", "kernel": dom2, "achieved": round(ach2, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach2 / HBM_PEAK_GBS, 5),
                                 "traffic": None, "alg_bytes_per_sample": FRONT_BYTES, "kernel_ms": {k: round(v["ms_per_step"], 4) for k, v in k2.items()},
                                 "chain_achieved_GBs": round(FRONT_BYTES * C2 * T / dt2 / 1e9, 2), "chain_frac": round(FRONT_BYTES * C2 * T / dt2 / 1e9 / HBM_PEAK_GBS, 6),
-                                # each kernel on the bytes IT moves (K1: int16 in + f32 out; the limit chain, which the `correlator` timer brackets: f32 in + f32 out)
-                                "kernel_own_bytes_per_sample": {"fir_rrc150": 6.0, "correlator": 8.0},
-                                "kernel_own_frac": {k: round(ob * C2 * T / (k2[k]["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS, 5) for k, ob in (("fir_rrc150", 6.0), ("correlator", 8.0)) if k2[k]["ms_per_step"]}}}
+                                # each kernel on the bytes IT moves (K1: int16 in + f32 out; the limit chain: f32 in + f32 out; the correlations: f32 in + 4 x f32 out)
+                                "kernel_own_bytes_per_sample": dict(FRONT_OWN_BYTES),
+                                "kernel_own_frac": {k: round(ob * C2 * T / (k2[k]["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS, 5) for k, ob in FRONT_OWN_BYTES.items() if k2[k]["ms_per_step"]}}}
         c2.close()
+        if args.parity_channels > 0:   # soft outputs: the north star asks 1e-5 relative; they are bit-exact (4 channels x 48 000 samples, one call)
+            import ctypes as Ct
+            k, n = 4, min(T, 48000)
+            c3 = m17hip.Context(k, n, device=local_rank)
+            c3.upload(x[:k, :n])
+            y, lim, corr = c3.fir_correlator()
+            c3.close()
+            ok2, against = True, "oracle"
+            for c in range(k):
+                ye = ol.fir_i16(x[c, :n]); le, ce = ol.correlator(ye)
+                ok2 = ok2 and np.array_equal(y[c], ye) and np.array_equal(lim[c], le) and np.array_equal(corr[:, c, :], ce)
+                if ol.ref() is not None:   # ... and against the reference's own classes where their build travelled
+                    against = "oracle and the reference's BaseFirFilter / Correlator (oracle/_ref)"
+                    yr = np.zeros(n, np.float32)
+                    ol.ref().ref_fir_f32(ol._p(ol.taps()), ol._p(ol.scale(x[c, :n])), Ct.c_size_t(n), ol._p(yr))
+                    lr, cr = ol.correlator(yr, lib=ol.ref(), prefix="ref_")
+                    ok2 = ok2 and np.array_equal(y[c], yr) and np.array_equal(lim[c], lr) and np.array_equal(corr[:, c, :], cr)
+            config2["outputs_bit_exact_first_channels"] = bool(ok2)
+            config2["outputs_checked_against"] = against
+        if args.cpu_seconds > 0:
+            a2 = argparse.Namespace(cpu_seconds=min(args.cpu_seconds, 1.0))
+            config2["cpu_baseline"] = cpu_baseline(a2, ol, x[:C2], C2, T, ncpu, ncpu_affinity, cpu_quota, chain=False)
 
-    cpu = cpu_baseline(args, ol, x, C, T, ncpu, ncpu_affinity, cpu_quota, chain=True) if (args.cpu_seconds > 0 and not multi) else None
+    # the oracle over (as many as fit the time of) the channels of the step: its throughput is the cpu_baseline, its RECORDS are compared, all of
+    # them, with the last timed step's — a mismatch is printed in the line and is the exit code
+    kept, parity_all, parity_all_channels = {}, None, 0
+    cpu = cpu_baseline(args, ol, x, C, T, ncpu, ncpu_affinity, cpu_quota, chain=True, keep=kept) if (args.cpu_seconds > 0 and not multi) else None
+    if kept:
+        parity_all_channels = int(kept["channels"])
+        got = recs[recs["channel"] < parity_all_channels]
+        parity_all = bool(got.tobytes() == kept["recs"].tobytes())
+        if not parity_all:
+            nbad = len(set(np.unique(got["channel"]).tolist()) ^ set(np.unique(kept["recs"]["channel"]).tolist()))
+            print(f"bench.py: PARITY FAILURE: the GPU's records of the last timed step differ from the oracle's on the first {parity_all_channels} channels "
+                  f"({got.size} against {kept['recs'].size} records, {nbad} channels present on one side only)", file=sys.stderr)
 
     out = {
         "metric": "Msamples/s demodulated (48 kSPS 4-FSK in -> decoded frames)",
@@ -686,7 +750,10 @@ def main():
                                "`value`: %d INDEPENDENT batches of that size resident and in flight per GPU (fresh demodulators every step); "
                                "`value_single_stream`: one batch, the same channels continued run after run" % (C, T, F),
                    "channels_per_gpu": C, "channels_resident_per_gpu": C * F, "samples_per_channel": T, "awgn_sigma_lsb": args.sigma, "frames_decoded_per_step": total_frames,
-                   "frames_cost_lt_10": good, "parity_vs_oracle_first_channels": parity, "parity_channels": args.parity_channels,
+                   "frames_cost_lt_10": good, "parity_vs_oracle_first_channels": parity, "parity_first_channels": args.parity_channels,
+                   "parity_channels": parity_all_channels if kept else args.parity_channels,
+                   "parity_vs_oracle_all_channels": (parity_all and parity_all_channels == C) if kept else None,
+                   "parity_vs_oracle_compared_channels": parity_all,
                    "realtime_factor_per_channel": round(value * 1e6 / (C * world) / 48000.0, 1), "input_gen_s": round(t_gen, 1),
                    "parallelism": f"channels sharded contiguously over {world} GPU(s), global channel ids", "gather": gather_kind,
                    "steps_in_flight": F, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "hw_queue_advice": int(ctx.lib.m17hip_advice(ctx.h)), "prewarm_steps": args.prewarm, "batches": "pipelined" if args.stagger else "launched and waited for in groups",
@@ -706,49 +773,81 @@ def main():
     except Exception:   # noqa: BLE001
         pass
     print(json.dumps(out), flush=True)
+    if parity is False or parity_all is False or (single and single.get("parity_vs_oracle_3_runs_first_channels") is False) or \
+            (bursty and bursty.get("parity_vs_oracle_first_channels") is False) or (config2 and config2.get("outputs_bit_exact_first_channels") is False):
+        sys.exit(3)   # a fast result that differs from the reference's is not a result
 
 
-def cpu_baseline(args, ol, x, C, T, ncpu, ncpu_affinity, cpu_quota, chain):
-    """The oracle (scalar C++ restatement, g++ -O3) on the host cores this process may use, one channel per thread, on a bounded
-    sample of the same workload; plus the same binary on ONE thread.  kind "port": the reference's chain cannot be built here
-    (blaze absent), so the baseline is the oracle."""
+def cpu_baseline(args, ol, x, C, T, ncpu, ncpu_affinity, cpu_quota, chain, keep=None):
+    """The CPU side of the line, on the host cores this process may use, one channel per thread, on a bounded sample of the same workload;
+    plus the same binary on ONE thread.
+    chain=True  (configs[2]): the oracle (scalar C++ restatement, g++ -O3) — kind "port": the reference's chain cannot be built here (blaze
+                absent).  The records it computes are KEPT (keep["recs"], keep["channels"]): the caller compares every one of them with the GPU's.
+    chain=False (configs[1]): FIR + correlator, outputs materialised.  The reference's OWN BaseFirFilter<float,150> and Correlator<float>
+                (oracle/_ref/libm17ref.so = its headers compiled where they lay, FirFilter.h:28-43, Correlator.h:43-64) when that build
+                travelled with the repository — kind "reference" — with the oracle's figure beside it; the oracle alone otherwise."""
+    import concurrent.futures as cf
     import ctypes as Ct
 
-    def run(xs, threads):
-        t = time.perf_counter()
-        if chain:
-            ol.demod_batch(xs, cap=2 * (T // 1920 + 2) + 4, threads=threads)
-        else:   # config 2: scaling + FIR + correlator, materialised
-            n = xs.shape[1]
-            lim = np.zeros(n, np.float32); corr = np.zeros((4, n), np.float32)
-            for c in range(xs.shape[0]):   # (single-threaded per call; threads handled below)
-                y = ol.fir_i16(xs[c])
-                ol.oracle().m17o_correlator(ol._p(y), Ct.c_size_t(n), ol._p(lim), ol._p(corr))
-        return time.perf_counter() - t
-
+    cap = 2 * (T // 1920 + 2) + 4
     if chain:
-        t1 = run(x[:2], 1)                                     # one thread, two channels (one BERT, one voice-like)
+        def run(xs, threads):
+            t = time.perf_counter()
+            out = ol.demod_batch(xs, cap=cap, threads=threads)
+            return time.perf_counter() - t, out
+
+        t1, _ = run(x[:2], 1)                                     # one thread, two channels (one BERT, one voice-like)
         one_core = 2 * T / t1 / 1e6
-        probe = run(x[: min(C, ncpu)], ncpu)
+        probe, _ = run(x[: min(C, ncpu)], ncpu)
         rate = min(C, ncpu) * T / max(probe, 1e-6)
         nch = int(min(C, max(ncpu, rate * args.cpu_seconds / T)))
         nch = min(C, max(ncpu, nch // ncpu * ncpu))
-        tc = run(x[:nch], ncpu)
-        value, sample = nch * T / tc / 1e6, f"{nch} of the {C} channels x {T} samples, one channel per thread"
-    else:
-        t1 = run(x[:1], 1)
-        one_core = T / t1 / 1e6
-        import concurrent.futures as cf
-        nch = int(min(C, max(ncpu, one_core * 1e6 * ncpu * args.cpu_seconds / T)))
+        tc, (er, ec, _) = run(x[:nch], ncpu)
+        if keep is not None:
+            keep["recs"] = np.concatenate([er[c, : ec[c]] for c in range(nch)]) if int(ec[:nch].sum()) else er[0, :0]
+            keep["channels"] = nch
+        return {"value": round(nch * T / tc / 1e6, 3), "unit": "Msamples/s", "cores": ncpu, "kind": "port", "one_core": round(one_core, 3),
+                "cores_affinity": ncpu_affinity, "cgroup_cpu_quota": cpu_quota,
+                "sample": f"{nch} of the {C} channels x {T} samples, one channel per thread, oracle/libm17oracle.so (g++ -O3 -ffp-contract=off)"}
+
+    n = x.shape[1]
+    taps = ol.taps()
+
+    def port_channel(c):        # scaling + BaseFirFilter + Correlator::sample / limit / 4 x correlate, every output materialised
+        lim = np.zeros(n, np.float32); corr = np.zeros((4, n), np.float32)
+        y = ol.fir_i16(x[c])
+        ol.oracle().m17o_correlator(ol._p(y), Ct.c_size_t(n), ol._p(lim), ol._p(corr))
+        return y, lim, corr
+
+    def ref_channel(c):         # the same with the reference's classes (the int16 -> float scaling is the application's one divide: the oracle's)
+        lim = np.zeros(n, np.float32); corr = np.zeros((4, n), np.float32); y = np.zeros(n, np.float32)
+        xs = ol.scale(x[c])
+        ol.ref().ref_fir_f32(ol._p(taps), ol._p(xs), Ct.c_size_t(n), ol._p(y))
+        ol.ref().ref_correlator(ol._p(y), Ct.c_size_t(n), ol._p(lim), ol._p(corr))
+        return y, lim, corr
+
+    def timed(fn):
+        t = time.perf_counter(); fn(0); t1 = time.perf_counter() - t
+        nch = int(min(C, max(ncpu, ncpu * args.cpu_seconds / max(t1, 1e-6))))
         nch = min(C, max(ncpu, nch // ncpu * ncpu))
         t = time.perf_counter()
         with cf.ThreadPoolExecutor(ncpu) as ex:   # the ctypes calls release the GIL
-            list(ex.map(lambda c: run(x[c:c + 1], 1), range(nch)))
-        tc = time.perf_counter() - t
-        value, sample = nch * T / tc / 1e6, f"{nch} of the {C} channels x {T} samples (scaling + FIR + correlator outputs), one channel per thread"
-    return {"value": round(value, 3), "unit": "Msamples/s", "cores": ncpu, "kind": "port", "one_core": round(one_core, 3),
+            list(ex.map(lambda c: fn(c)[0][0], range(nch)))
+        return n / t1 / 1e6, nch * n / (time.perf_counter() - t) / 1e6, nch
+
+    one_p, val_p, nch_p = timed(port_channel)
+    port = {"value": round(val_p, 3), "unit": "Msamples/s", "cores": ncpu, "kind": "port", "one_core": round(one_p, 3),
+            "sample": f"{nch_p} of the {C} channels x {n} samples (scaling + FIR + limit + 4 correlations materialised), one channel per thread, oracle/libm17oracle.so"}
+    if ol.ref() is None:
+        port.update({"cores_affinity": ncpu_affinity, "cgroup_cpu_quota": cpu_quota})
+        return port
+    one_r, val_r, nch_r = timed(ref_channel)
+    same = all(np.array_equal(a_, b_) for a_, b_ in zip(port_channel(1 % C), ref_channel(1 % C)))
+    return {"value": round(val_r, 3), "unit": "Msamples/s", "cores": ncpu, "kind": "reference", "one_core": round(one_r, 3),
             "cores_affinity": ncpu_affinity, "cgroup_cpu_quota": cpu_quota,
-            "sample": sample + ", oracle/libm17oracle.so (g++ -O3 -ffp-contract=off)"}
+            "sample": f"{nch_r} of the {C} channels x {n} samples, one channel per thread: the reference's BaseFirFilter<float,150> and Correlator<float> "
+                      "(sample / limit / correlate x 4 sync words), every output materialised — oracle/_ref/libm17ref.so, its headers compiled where they lay (g++ -O3)",
+            "port": port, "port_outputs_equal_reference": bool(same)}
 
 
 def bench_front(args, ctx, ol, x, C, T, rank, world, dev, sync, ncpu, ncpu_affinity, cpu_quota, t_gen):
@@ -774,7 +873,7 @@ def bench_front(args, ctx, ol, x, C, T, rank, world, dev, sync, ncpu, ncpu_affin
         dt = float(tmax.item())
     ctx.timing(False)
     kern = {}
-    for name in ("fir_rrc150", "correlator"):
+    for name in ("fir_rrc150", "limit_track", "correlator"):
         ms, n = ctx.timing_get(name)
         kern[name] = {"ms_avg": (ms / n) if n else None, "launches": n, "ms_per_step": ms / args.steps}
     parity = None

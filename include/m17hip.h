@@ -378,7 +378,7 @@ int m17hip_debug_counters(m17hip_ctx* ctx, uint64_t* host, uint32_t max_waves, u
 int m17hip_timing_enable(m17hip_ctx* ctx, int on);
 /* Accumulated device time (ms) and launch count per kernel since the last m17hip_timing_reset:
  * which: 0 = fir_rrc150, 1 = dcd, 2 = demod_seq, 3 = viterbi/decode_frames, 4 = correlator, 5 = compaction,
- * 6 = limit_track (the limit filter run ahead of demod_seq). */
+ * 6 = limit_track (the limit filter run ahead of demod_seq; in m17hip_fir_correlator the limit filter's chain, 4 = its correlations). */
 int m17hip_timing_get(m17hip_ctx* ctx, int which, double* total_ms, uint64_t* launches);
 int m17hip_timing_reset(m17hip_ctx* ctx);
 

@@ -1422,11 +1422,14 @@ int m17hip_fir_correlator(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags,
         HIPCHK(c, hipEventRecord(ev_fir[k], st_fir));
         HIPCHK(c, hipStreamWaitEvent(st_corr, ev_fir[k], 0));
         HIPCHK(c, hipStreamWaitEvent(st_chain, ev_fir[k], 0));
-        Timed tm(c, KT_CORR, st_chain);
-        if (T % 4 == 0 && t0 % 4 == 0 && len % 4 == 0)
-            hipLaunchKernelGGL(correlate4_kernel, dim3((len / 4 + 255) / 256, C), dim3(256), 0, st_corr, c->ybuf, c->ypitch, corr, C, len, t0, T);
-        else
-            hipLaunchKernelGGL(correlate_kernel, dim3((len + 255) / 256, C), dim3(256), 0, st_corr, c->ybuf, c->ypitch, corr, C, len, t0, T);
+        {   // each kernel timed on the stream it runs on, under its own key: the correlations as "correlator", the limit chain as "limit_track"
+            Timed tc(c, KT_CORR, st_corr);
+            if (T % 4 == 0 && t0 % 4 == 0 && len % 4 == 0)
+                hipLaunchKernelGGL(correlate4_kernel, dim3((len / 4 + 255) / 256, C), dim3(256), 0, st_corr, c->ybuf, c->ypitch, corr, C, len, t0, T);
+            else
+                hipLaunchKernelGGL(correlate_kernel, dim3((len + 255) / 256, C), dim3(256), 0, st_corr, c->ybuf, c->ypitch, corr, C, len, t0, T);
+        }
+        Timed tm(c, KT_GATE, st_chain);
 #ifdef M17_TOOLS
         if (tiled && c->limit_form == 0)
             hipLaunchKernelGGL(limit_pipe_kernel, dim3(chain_wgs), dim3(320), 0, st_chain, c->ybuf + t0, c->ypitch, limit + t0, (size_t)T, C, len,

@@ -98,3 +98,16 @@ def test_no_result_line_is_an_error(capfd, monkeypatch):
     assert b.launch_ranks(types.SimpleNamespace(gpus=2, dry_launch=False), []) == 1
     out, _ = capfd.readouterr()
     assert out == ""
+
+
+def test_ranks_that_never_end_are_stopped_after_the_launch_timeout_and_killed_if_they_ignore_it(capfd, monkeypatch):
+    """a rank stuck in a collective that ignores SIGTERM must not hang the launcher — overall limit, then SIGKILL ten seconds after SIGTERM."""
+    b = _bench_module()
+    scripts = ["import signal,time; signal.signal(signal.SIGTERM, signal.SIG_IGN); print('deaf', flush=True); time.sleep(600)", "import time; time.sleep(600)"]
+    monkeypatch.setattr(b, "rank_commands", lambda n, argv, port: [(_fake(s), {}) for s in scripts])
+    monkeypatch.setattr(b, "visible_gpus", lambda: 2)
+    t0 = time.time()
+    code = b.launch_ranks(types.SimpleNamespace(gpus=2, dry_launch=False, launch_timeout=2.0), [])
+    out, err = capfd.readouterr()
+    assert code == 124 and out == "" and 11 < time.time() - t0 < 40
+    assert "still running after --launch-timeout 2 s" in err

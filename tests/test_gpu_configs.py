@@ -63,7 +63,7 @@ def test_correlator_limit_pipeline_and_single_wave_forms(Cn, T):
     ctx.close()
 
 
-@pytest.mark.parametrize("dc,gain", [(0.0, 1.0), (1000.0, 1.0), (-2500.0, 0.7)])
+@pytest.mark.parametrize("dc,gain", [(0.0, 1.0), (1000.0, 1.0), (-1000.0, 1.3), (2500.0, 0.85), (-2500.0, 0.7)])   # DC in {0, +-1000, +-2500}
 def test_config5_impairment_sweep_ber_and_evm_equal_the_cpu_path(dc, gain):
     """BASELINE configs[4] (EVM + BER vs CPU reference), one GPU's share: 512 BERT channels x 96 000 samples per point, six AWGN
     levels.  Per channel: PRBS9 bits / errors / sync / frames from m17hip_bert_stats == the oracle's PRBS9 receiver over the

@@ -60,5 +60,9 @@ try:   # the two-batch regime of the default command with the probe beside it: t
                                    'of `bench.py --steps 200` (two batches in flight)'}
 except Exception as e:   # noqa: BLE001
     j['clock_in_mix'] = str(e)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench   # (kernel_source_sha16: the stamp bench.py compares with the sources of the build it runs)
+j['kernel_source_sha16'] = bench.kernel_source_sha16()
 json.dump(j, open(out, 'w'), indent=1)
 print(json.dumps({k: (round(v['valu_insts_per_step'] / 1e9, 3), round(v['clock_ghz_alone'], 3)) for k, v in j['kernels'].items()}), 'total G', round(tot / 1e9, 3), j.get('clock_in_mix'))
