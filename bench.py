@@ -194,6 +194,8 @@ def main():
     ap.add_argument("--one-at-a-time", type=int, default=1, help="1 = also run 2 steps strictly one after the other (no overlap of any kind): the per-launch kernel "
                     "durations the roofline object is computed from (the regime in which HIP events and rocprofv3 agree)")
     ap.add_argument("--one-at-a-time-steps", type=int, default=2)
+    ap.add_argument("--stream-order", choices=("run_then_fetch", "fetch_then_run"), default="run_then_fetch", help="single-stream regime: queue run k + 1's state-machine half "
+                    "before run k's records are collected (m17hip_frames_select(1); default) or after (the order of rounds 3-5)")
     ap.add_argument("--stream-groups", type=int, default=2, help="contexts the channels of the single-stream regime are split into (independent chains)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no launcher: print the N command lines / environments bench.py would start, and exit")
     ap.add_argument("--duty", type=float, default=1.0, help="experiments: every channel's transmission covers this fraction of a run, loud noise for the rest (1 = BASELINE's "
@@ -469,16 +471,25 @@ def main():
             allrecs, _ = mdist.gather_records(buf[: cap_g * 64], n)
             return int(allrecs.shape[0])
 
-        def stream_steps(n_steps):
+        def stream_steps(n_steps):   # the call sequence of a live feed (include/m17hip.h, m17hip_demod_front)
             tot = 0
             for k in range(n_steps):
                 for c_ in sctx:
                     c_.input_alternate(Cg, T)
                     c_.front()                       # K1 / K3 of the next run: queued now, beside the tail of the run in flight
-                tot = 0
-                for g, c_ in enumerate(sctx):
-                    tot += sfinish(g)
-                    c_.run()                         # K2 / K5 chain of the next run
+                if args.stream_order == "run_then_fetch":
+                    for c_ in sctx:
+                        c_.run()                     # K2 / K5 chain of the next run: queued behind the chain in flight — nothing of it waits for the
+                    tot = 0                          # payload work of the run before (deferred decode, compaction) or for the host
+                    for g, c_ in enumerate(sctx):
+                        c_.frames_select(1)          # the records of the run BEFORE the one just queued
+                        tot += sfinish(g)
+                        c_.frames_select(0)
+                else:                                # (up to round 5: the records collected first, then the next chain queued)
+                    tot = 0
+                    for g, c_ in enumerate(sctx):
+                        tot += sfinish(g)
+                        c_.run()
             return tot
 
         stream_steps(max(2, args.warmup))
@@ -504,8 +515,14 @@ def main():
                     c_.input_alternate(Cg, T)
                     if r_:
                         c_.front()
+                        if args.stream_order == "run_then_fetch":   # (the order the timed loop uses)
+                            c_.run()
+                            c_.frames_select(1)
                         q = c_.frames()
                         parts.append(q[q["channel"] < g * Cg + k])
+                        if args.stream_order == "run_then_fetch":
+                            c_.frames_select(0)
+                            continue
                     c_.run()
                 q = c_.frames()
                 parts.append(q[q["channel"] < g * Cg + k])
@@ -517,10 +534,10 @@ def main():
             exp["channel"] = np.concatenate([np.full(int(exp_counts[i]), rows[i], dtype=np.uint32) for i in range(len(rows))])
             sparity = bool(got.tobytes() == exp.tobytes())
         single = {"value": round(C * T * world * args.steps / dts / 1e6, 2), "ms_per_step": round(dts / args.steps * 1e3, 3), "steps": args.steps,
-                  "channel_groups": G,
+                  "channel_groups": G, "order": args.stream_order,
                   "what": "the same %d channels per GPU continued run after run (state carried, no reset) as %d contexts of %d channels, two resident "
                           "input slabs alternating, front end of run k + 1 queued by m17hip_demod_front beside run k's K2/K5 chain, records of every "
-                          "run compacted" % (C, G, Cg) + (" and gathered" if multi else ""),
+                          "run compacted (those of run k after run k + 1's chain was queued: m17hip_frames_select)" % (C, G, Cg) + (" and gathered" if multi else ""),
                   "kernel_ms": {k_: round(v["ms_per_step"], 4) for k_, v in skern.items()},
                   "parity_vs_oracle_3_runs_first_channels": sparity}
         for c_ in sctx:

@@ -170,22 +170,37 @@ int m17hip_demod_run(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint3
  * and queues that front end at once, on the context's side streams — while the state-machine half of the latest run (limit
  * filter, clock recovery, slicer, Viterbi: everything that waits for M17Demodulator's state) is still at work.  The call
  * sequence of a live feed:
- *     stage(k + 1); m17hip_demod_front(k + 1);  m17hip_frames_fetch / _compact_device / m17hip_gather_frames (run k);
- *     m17hip_demod_run(k + 1);  ...
- * The m17hip_demod_run that follows must name the same channels / samples / flags (M17HIP_ESTATE otherwise) and queues the rest.
- * Between the two calls the context's results are still those of run k; in-place uploads, per-operator entry points and
+ *     stage(k + 1); m17hip_demod_front(k + 1); m17hip_demod_run(k + 1);
+ *     m17hip_frames_select(ctx, 1); m17hip_frames_fetch / _compact_device / m17hip_gather_frames (run k);  ...
+ * i.e. the state-machine half of run k + 1 is queued BEFORE the host collects run k's records: nothing of run k + 1 waits for what only
+ * run k's consumers need.  A run ends, on the context's main stream, with its demodulator state settled (M17Demodulator.h:146-176:
+ * everything operator() reads the next time); the payload frames whose Viterbi decode K5 deferred, the payload consumers (BERT
+ * statistics, packet reassembly), the compaction of the records and the gather work on the context's PAYLOAD stream, beside the next
+ * run, on the record set of their own run — two record sets alternate run by run, so a run's records stay fetchable until the run
+ * after the next is queued.  (The older order — fetch run k between m17hip_demod_front(k + 1) and m17hip_demod_run(k + 1) — works as
+ * before; the next run's chain then starts a host round trip and the deferred decode, 2 ms per 4096 x 480 000, later.)
+ * The m17hip_demod_run that follows m17hip_demod_front must name the same channels / samples / flags (M17HIP_ESTATE otherwise) and
+ * queues the rest.  Between the two calls the context's results are still those of run k; in-place uploads, per-operator entry points and
  * m17hip_tune return M17HIP_ESTATE; m17hip_demod_reset abandons the queued front end.  Results are bit-identical to the same runs
  * made one after the other (tests/test_gpu_streaming.py).  M17HIP_ESTATE if nothing is staged.
  * (m17hip_demod_run on staged input without this call queues the same front end itself — then nothing is gained unless the host
  * calls it before it has fetched the previous run's records, which it thereby gives up.) */
 int m17hip_demod_front(m17hip_ctx* ctx, uint32_t channels, uint32_t samples, uint32_t flags);
-/* Number of records produced by the last run (all channels). */
+/* Which run's records m17hip_frames_count / _fetch / _compact_device and m17hip_gather_frames[_device] name: back = 0 the latest run
+ * (the default; every m17hip_demod_run selects it again), back = 1 the run before it — what a live feed asks for after it has queued
+ * the next run (above).  M17HIP_ESTATE if that run's records are not there (no such run since the last reset). */
+int m17hip_frames_select(m17hip_ctx* ctx, uint32_t back);
+/* Number of records produced by the selected run (all channels).  The calls of this family wait for the run's payload work only —
+ * not for anything queued after it. */
 int m17hip_frames_count(m17hip_ctx* ctx, uint64_t* total);
 /* Records of the last run, ordered by (channel, seq).  Host destination.  *count = records the run produced; when that is
  * more than `capacity` only `capacity` are written and M17HIP_ETRUNC is returned. */
 int m17hip_frames_fetch(m17hip_ctx* ctx, m17_frame_rec* recs_host, uint64_t capacity, uint64_t* count);
 /* Same, compacted into caller-provided DEVICE memory (so a collective can ship it without a host hop); same
- * truncation rule. */
+ * truncation rule.  The copy is made on the context's payload stream and is complete when the call returns.  For the latest run it is
+ * ordered behind whatever the caller has queued on the context's main stream so far (a fill of the destination, say); with a newer run
+ * queued (m17hip_frames_select(ctx, 1)) it waits for nothing but the selected run: the destination must be ready when the call is made.
+ * The same holds for the device destination of m17hip_gather_frames_device. */
 int m17hip_frames_compact_device(m17hip_ctx* ctx, m17_frame_rec* recs_dev, uint64_t capacity, uint64_t* count);
 /* Per-channel diagnostics after the last run: diag_host[C]. */
 int m17hip_diag_fetch(m17hip_ctx* ctx, m17_diag* diag_host, uint32_t channels);

@@ -157,8 +157,9 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeFramesParams P)
 // Deferred frame decode (m17_wave_kernel.hpp hands payload frames of running stream / BERT transmissions over instead of decoding
 // them in the channel's wave): one workgroup per channel, one LANE per frame record — viterbi_decode, the lane-per-frame form of
 // Viterbi<Trellis<4,2>,4>::decode (Viterbi.h:162-239) with the same source maps — cost and payload go into the record the wave
-// reserved.  Then the tags that stood for those costs are replaced wherever the wave left one: the channel's saved viterbi_cost,
-// its last diagnostic callback, and the entries of its diagnostic log.
+// reserved.  Then the tags that stood for those costs are replaced in the entries of the channel's diagnostic log (the two places of the
+// demodulator STATE that can hold a tag at the end of a run are settled before, by settle_tail_kernel: this kernel runs on a stream of
+// its own, beside the next run of a continued stream, and works on the record set of its run only).
 struct DeferParams {
     FrameRec* recs;               // [C][rec_cap]
     uint32_t rec_cap;
@@ -216,17 +217,66 @@ __global__ __launch_bounds__(64) void decode_deferred_kernel(DeferParams P)
         const uint32_t u = (uint32_t)v;
         if (cost_is_deferred(u)) v = recs[u & ~DEFER_TAG].cost;
     };
-    SeqState* st = P.state + c;
-    if (lane == 0) {
-        int32_t v = (int32_t)st->hot.viterbi_cost;
-        settle(v);
-        st->hot.viterbi_cost = (uint32_t)v;
-        settle(st->cold.diag.viterbi_cost);
-    }
+    // (the channel's saved viterbi_cost and its last diagnostic callback carry no tag any more when this kernel runs: settle_tail_kernel
+    //  below has decoded the one or two frames they stood for — the demodulator state is the NEXT run's by now and is not touched here)
     if (P.diag_log) {
         const uint32_t nd = min(P.diag_count[c], P.diag_cap);
         Diag* log = P.diag_log + (size_t)c * P.diag_cap;
         for (uint32_t e = lane; e < nd; e += 64) settle(log[e].viterbi_cost);
+    }
+}
+
+// The end of a run on the MAIN stream, so that nothing of the demodulator state waits for the deferred decode (2 ms per 4096 x 480 000,
+// which then runs beside the next run's chain, on the payload stream).  At the end of a run a channel's state can hold a deferred-cost tag
+// in exactly two places: the saved viterbi_cost (M17Demodulator.h:146 `viterbi_cost`: the last frame's, consulted by the missed-sync branches
+// :453,508,555 of the NEXT run) and the viterbi_cost argument of its last diagnostic callback (m17_diag) — the last frame, and the one before
+// it when a frame completed after that callback.  One WAVE per channel decodes those one or two frames with the wave decoder (16 lanes = 16
+// states) from the deferred-frame store, completes their records (decode_deferred_kernel then skips them) and puts the costs in place.
+// The blocks behind the first C fold the rest of the run's deferred EVM operations (evm_fold_pass, the last pass of a run).
+struct SettleParams {
+    FrameRec* recs; uint32_t rec_cap; const uint32_t* defer; const DecodeTables* tables; SeqState* state; uint32_t C;
+    EvParams ev;   // ops == nullptr: no fold blocks in the launch
+};
+constexpr int SETTLE_LDS_BYTES = (92 + 122 + 8 + 488) * 4 > EV_TILE_FLOATS * 4 ? (92 + 122 + 8 + 488) * 4 : EV_TILE_FLOATS * 4;
+__global__ __launch_bounds__(64) void settle_tail_kernel(SettleParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (blockIdx.x >= P.C) {
+        evm_fold_pass(P.ev, blockIdx.x - P.C, reinterpret_cast<float*>(lds));
+        return;
+    }
+    const int wl = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    SeqState* st = P.state + c;
+    const uint32_t th = (uint32_t)__builtin_amdgcn_readfirstlane((int)st->hot.viterbi_cost);
+    const uint32_t td = (uint32_t)__builtin_amdgcn_readfirstlane(st->cold.diag.viterbi_cost);
+    if (!cost_is_deferred(th) && !cost_is_deferred(td)) return;
+    DecodeLds L;
+    L.llr = lds; L.hist = lds + 92; L.outb = lds + 92 + 122; L.soft = reinterpret_cast<int32_t*>(lds + 92 + 122 + 8);
+    L.lsf = nullptr; L.prof = nullptr; L.stride = 1;
+    L.src = &P.tables->src[0][0]; L.lich_src = P.tables->lich_src;
+    auto resolve = [&](uint32_t tag) -> uint32_t {
+        const uint32_t slot = tag & ~DEFER_TAG;
+        uint32_t* w = reinterpret_cast<uint32_t*>(P.recs + (size_t)c * P.rec_cap + slot);
+        const uint32_t have = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[4]);
+        if (!cost_is_deferred(have) || slot >= P.rec_cap) return have;   // the wave decoded it after all (a missed sync word asked for its cost)
+        const int kind = kind_of_frame_type(w[5] & 0xFFu);
+        int stale = (int)w[14];
+        const uint32_t* src = P.defer + ((size_t)c * P.rec_cap + slot) * 46;
+        for (int k = wl; k < 92; k += 64) as_lds(L.llr)[k] = unpack_llr_nibbles(src[k >> 1], k & 1);
+        wave_lds_sync();
+        const uint32_t cost = viterbi_decode_wave(L, wl, kind, stale);
+        wave_lds_sync();
+        if (wl == 0) complete_record(w, cost, L.outb, 1, 0, len_of_kind(kind));
+        wave_lds_sync();
+        return cost;
+    };
+    uint32_t ch = th, cd = td;
+    if (cost_is_deferred(th)) ch = resolve(th);
+    if (cost_is_deferred(td)) cd = (td == th) ? ch : resolve(td);
+    if (wl == 0) {
+        st->hot.viterbi_cost = ch;
+        st->cold.diag.viterbi_cost = (int32_t)cd;
     }
 }
 

@@ -179,7 +179,8 @@ struct EvParams {
     uint32_t diag_cap;
     SeqState* state;      // cold.ev_cursor = operations of the run; cold.diag.evm = EVM_PENDING where the last callback waits for its value
     uint32_t C;
-    const uint32_t* upto; // [C] fold the operations below this cursor (K5's at the end of a segment); nullptr: all of the run's, and settle m17_diag (the last pass of a run)
+    const uint32_t* upto; // [C] fold the operations below this cursor (K5's at the end of a segment)
+    uint32_t last;        // the last pass of a run (upto = K5's cursor at the end of its last segment): the next run's operations start at 0, m17_diag is settled
 };
 constexpr int EV_CPB = 16;                        // channels per workgroup (one wave) of a fold pass
 constexpr int EV_TILE_FLOATS = EV_CPB * 68;       // its LDS: 16 channels x 64 operations, rows of 68 words
@@ -198,7 +199,7 @@ __device__ __forceinline__ void evm_fold_pass(const EvParams& E, uint32_t blk, f
     const uint32_t cc = min(c, E.C - 1u);
     EvState e = E.es[cc];
     const uint32_t from = valid ? min(e.pos, E.pitch) : 0u;
-    const uint32_t upto = valid ? min(E.upto ? E.upto[cc] : E.state[cc].cold.ev_cursor, E.pitch) : 0u;
+    const uint32_t upto = valid ? min(E.upto[cc], E.pitch) : 0u;   // (never the state's own cursor: by now that may be the NEXT run's)
     const uint32_t n = upto > from ? upto - from : 0u;   // operations of this lane's row in this pass
     uint32_t nmax = n;
 #pragma unroll
@@ -252,9 +253,9 @@ __device__ __forceinline__ void evm_fold_pass(const EvParams& E, uint32_t blk, f
         lds_sync();
     }
     if (valid) {
-        e.pos = E.upto ? upto : 0u;   // (the last pass of a run: the next run's operations start at 0)
+        e.pos = E.last ? 0u : upto;   // (the last pass of a run: the next run's operations start at 0)
         E.es[c] = e;
-        if (!E.upto) {
+        if (E.last) {
             uint32_t* w = reinterpret_cast<uint32_t*>(&E.state[c].cold.diag.evm);
             if (*w == EVM_PENDING) *w = __float_as_uint(e.last);
         }

@@ -91,8 +91,9 @@ struct m17hip_ctx {
     void* bert_state = nullptr;       // [maxC] BertState (tuning knob 6)
     bool bert = false;
     void* pkt_state = nullptr;        // [maxC] PacketState (tuning knob 7)
-    void* pkt_recs = nullptr;         // [pkt_cap] PacketRec: packets completed by the last run
-    uint32_t* pkt_count = nullptr;
+    void* pkt_recs2[2] = {nullptr, nullptr};        // [pkt_cap] PacketRec: packets completed by a run, one store per record set
+    uint32_t* pkt_count2 = nullptr;   // [2]
+    int pkt_fed_set = 0;              // the store m17hip_packets_feed wrote last
     uint32_t pkt_cap = 0;
     bool pkt_fed = false;
     Diag* diag_log = nullptr;         // [maxC][diag_cap] one entry per diagnostic callback of the last run (tuning knob 9)
@@ -114,10 +115,33 @@ struct m17hip_ctx {
     float* dcd_table = nullptr;
     DcdState* dcd_state = nullptr;
     SeqState* seq_state = nullptr;
-    FrameRec* recs = nullptr;
-    uint32_t* rec_count = nullptr;
-    uint32_t* overflow = nullptr;
-    uint64_t* rec_offsets = nullptr;  // exclusive prefix of rec_count (+ total at [C])
+    // Two RECORD SETS that alternate run by run (what a run writes for its consumers: record slots, counts, the deferred-frame store, the
+    // run's overflow words).  The payload work of run k — deferred decode, consumers, compaction, the gather — runs on the PAYLOAD stream
+    // beside the chain of run k + 1, which writes the other set; m17hip_frames_select says which run's records the fetch family names.
+    struct RecSet {
+        FrameRec* recs = nullptr;         // [maxC][rec_cap_alloc]
+        uint32_t* rec_count = nullptr;    // [maxC]
+        uint32_t* defer_llr = nullptr;    // [maxC][rec_cap_alloc][46]: LLR frames (nibbles) K5 leaves for decode_deferred_kernel (tune 15), lazily
+        uint32_t* ovf = nullptr;          // -> overflow + 4 * index: [0] record overflow of the run, [1] channels that left the replay (since reset, this set's runs),
+                                          //    [2] deferred EVM operations dropped (since reset), [3] channel-segments of the run that ended with the carrier off
+        hipEvent_t chain = nullptr;       // the run that wrote this set has left the main stream (state settled): what its payload work waits for
+        hipEvent_t done = nullptr;        // the payload stream is through with the run that wrote this set
+        uint32_t C = 0, rec_cap = 0, nseg = 0;
+        bool valid = false;               // holds a finished run's records in the layout (rec_cap) they were written with
+        bool pending = false;             // its payload work (deferred decode, consumers) is not queued yet (flush_payload)
+        bool bert = false, pkt = false;   // the consumers that were on when the run was made
+    } sets[2];
+    int cur = 0;                      // the set of the latest run
+    uint32_t sel_back = 0;            // m17hip_frames_select: 0 = the latest run's records, 1 = the run's before it
+    // The PAYLOAD stream (deferred decode, consumers, compaction, gather): the copy stream of a context that streams (it exists from the first
+    // staged input on), the main stream otherwise.  Not a stream of its own: one more stream per context moved the continued-stream regime from
+    // 24 to 27-37 ms whatever its place in the creation order (which streams share a hardware pipe: NOTES 4.14, 6.3).  The copy stream also
+    // carries the next run's staged input and prefix copies, which must never wait for a FUTURE event: so a run's payload work is queued
+    // when somebody asks for its results (or needs its record set back), not when the run is queued — flush_payload.
+    hipStream_t pay() const { return copy ? copy : stream; }
+    hipEvent_t ev_dst = nullptr;      // the caller's main-stream work on a device destination is done (a fetch of the LATEST run orders itself behind it)
+    uint32_t* overflow = nullptr;     // [8]: four words per record set
+    uint64_t* rec_offsets = nullptr;  // exclusive prefix of rec_count (+ total at [C]): scratch of a compaction (payload stream)
     FrameRec* compact = nullptr;      // lazily sized
     uint64_t compact_cap = 0;
     DecodeTables* tables = nullptr;
@@ -133,15 +157,17 @@ struct m17hip_ctx {
     uint32_t fir_grid = 0;           // tuning knob 13: workgroups of K1's grid (0 = default: from the items per workgroup below)
     bool fir_latency = false;        // the run being queued is one whose chain of K5 launches decides (= it gets K3's latency form): few items per K1 workgroup
     uint32_t n_cu = 256;
-    uint32_t* defer_llr = nullptr;   // [maxC][rec_cap_alloc][46]: LLR frames (nibbles) K5 leaves for decode_deferred_kernel (tune 15)
-    uint32_t* defer_hist = nullptr;  // [maxC][101][64]: that kernel's decision words
+    uint32_t* defer_hist = nullptr;  // [maxC][101][64]: decode_deferred_kernel's decision words (one launch at a time: payload stream)
     bool defer_decode = true;
     // the running EVM folded outside K5, one lane per channel (m17_state.hpp, evm_fold_pass; tune 17)
     bool defer_evm = true;
     float* ev_ops = nullptr;         // [maxC][ev_pitch] operations of the current run (lazily allocated)
     uint32_t ev_pitch = 0;
     uint32_t ev_pitch_override = 0;  // tuning knob 18 (tests): floats per operation row instead of ev_row_floats(maxT)
-    uint32_t* ev_cur = nullptr;      // [2][maxC] K5's operation cursor at the end of a segment, by segment parity
+    uint32_t* ev_cur = nullptr;      // [3][maxC] K5's operation cursor at the end of a segment, by segment parity; [2]: at the end of the run's LAST segment
+    bool fold_pending = false;       // the last EVM fold pass of the latest run (the operations of its last two segments) is still to be made: it rides the next
+                                     // run's first limit-filter replay (which K5 of that run waits for anyway), or is made when somebody asks for m17_diag (flush_fold)
+    bool fold_with_decode = false;   // (inside m17hip_demod_run) ... or the latest run's deferred decode, where that is queued behind the run at once
     EvState* ev_state = nullptr;     // [maxC]
     uint32_t seq_lds_bytes = 0; // tune 14: LDS bytes a workgroup of the sequential kernel asks for (0 = SEQ_LDS_BYTES_4 for four waves)
     float* llr_edges = nullptr;
@@ -152,7 +178,6 @@ struct m17hip_ctx {
     uint64_t pos = 0;          // samples consumed since reset
     uint32_t lastC = 0, lastT = 0;
     bool have_run = false;     // a run has been made since the last reset (the stream continues)
-    bool recs_valid = false;   // the record slots hold a finished run's records in the layout (rec_cap) they were written with
     bool uploaded = false;
     bool timing = false;
     bool profile = false;      // K5 writes per-channel tick counters (tuning knob 1)
@@ -740,11 +765,12 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->dcd_state, C * sizeof(DcdState));
     ALLOC(c->seq_state, C * sizeof(SeqState));
     ALLOC(c->ev_state, C * sizeof(EvState));
-    ALLOC(c->ev_cur, 2 * C * sizeof(uint32_t));
-    ALLOC(c->recs, C * c->rec_cap * sizeof(FrameRec));
-    ALLOC(c->rec_count, C * sizeof(uint32_t));
+    ALLOC(c->ev_cur, 3 * C * sizeof(uint32_t));
+    ALLOC(c->sets[0].recs, C * c->rec_cap * sizeof(FrameRec));      // (the second set: with the second run, ensure_set)
+    ALLOC(c->sets[0].rec_count, C * sizeof(uint32_t));
     ALLOC(c->rec_offsets, (C + 1) * sizeof(uint64_t));
-    ALLOC(c->overflow, 4 * sizeof(uint32_t));   // [0] record overflow, [1] channels that left the limit-filter replay (m17hip_replay_drops)
+    ALLOC(c->overflow, 8 * sizeof(uint32_t));
+    c->sets[0].ovf = c->overflow; c->sets[1].ovf = c->overflow + 4;
     ALLOC(c->tables, sizeof(DecodeTables));
     ALLOC(c->taps, 160 * sizeof(float));
     ALLOC(c->taps_skew, FS_NBODY * FS_TAB * sizeof(float));
@@ -797,7 +823,9 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
         return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)decode_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (92 + 122 + 16) * 64 * 4) != hipSuccess)
         return fail(M17HIP_EHIP);
-    if (hipMemset(c->overflow, 0, 16) != hipSuccess) return fail(M17HIP_EHIP);
+    if (hipMemset(c->overflow, 0, 32) != hipSuccess) return fail(M17HIP_EHIP);
+    for (hipEvent_t* e : {&c->sets[0].done, &c->sets[1].done, &c->sets[0].chain, &c->sets[1].chain, &c->ev_dst})
+        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     { std::lock_guard<std::mutex> lk(g_runs.mu); c->seen_overlap = g_runs.overlaps; g_runs.ctxs.push_back(c); }   // (a new context has seen no overlap yet)
     *out = c;
     const int r = m17hip_demod_reset(c);
@@ -822,13 +850,15 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     if (c->side2 && !c->foreign_streams[1]) hipStreamDestroy(c->side2);
     if (c->side3 && !c->foreign_streams[2]) hipStreamDestroy(c->side3);
     if (c->copy && !c->foreign_streams[3]) hipStreamDestroy(c->copy);
-    for (hipEvent_t e : {c->ev_copy, c->ev_in_ready, c->ev_end[0], c->ev_end[1], c->ev_mark, c->ev_tail})
+    if (c->ev_dst) hipEventDestroy(c->ev_dst);
+    for (hipEvent_t e : {c->ev_copy, c->ev_in_ready, c->ev_end[0], c->ev_end[1], c->ev_mark, c->ev_tail, c->sets[0].done, c->sets[1].done, c->sets[0].chain, c->sets[1].chain})
         if (e) hipEventDestroy(e);
     for (int q = 0; q < 2; ++q)
         for (auto* v : {&c->ev_fir_[q], &c->ev_dcd_[q], &c->ev_gate_[q], &c->ev_redo_[q], &c->ev_seq_[q]})
             for (auto e : *v) hipEventDestroy(e);
-    void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->recs, c->rec_count, c->rec_offsets,
-                    c->overflow, c->tables, c->taps, c->taps_skew, c->llr_edges, c->level_gain, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs, c->pkt_count, c->diag_log, c->diag_count, c->defer_llr, c->defer_hist,
+    void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->sets[0].recs, c->sets[0].rec_count, c->sets[0].defer_llr,
+                    c->sets[1].recs, c->sets[1].rec_count, c->sets[1].defer_llr, c->rec_offsets,
+                    c->overflow, c->tables, c->taps, c->taps_skew, c->llr_edges, c->level_gain, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs2[0], c->pkt_recs2[1], c->pkt_count2, c->diag_log, c->diag_count, c->defer_hist,
                     c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->bnd, c->ev_ops, c->ev_cur, c->ev_state, c->truth, c->first_needed};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);   // (the context is going away: nothing to report to)
@@ -1189,6 +1219,13 @@ int m17hip_demod_reset(m17hip_ctx* c)
         c->front_pending = false;
         c->gate0_queued = false;
     }
+    // the payload work of the runs before (deferred decode, consumers: their state is reset below) is waited for ON the device
+    // (payload work that was never asked for goes with the stream it belonged to: the consumers' state is reset below)
+    for (auto& rs : c->sets) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, rs.done, 0));   // (never recorded: no wait)
+        rs.pending = false;
+    }
+    c->fold_pending = false;   // (the EVM state it would have updated is reset below)
     hipLaunchKernelGGL(seq_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->dcd_state, c->ev_state, c->maxC);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(zero_prefix_kernel, dim3(c->maxC), dim3(64), 0, c->stream, c->xbuf, c->xpitch, c->ybuf, c->ypitch, c->maxC);
@@ -1199,15 +1236,19 @@ int m17hip_demod_reset(m17hip_ctx* c)
     if (c->pkt_cap) {
         hipLaunchKernelGGL(packet_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, (PacketState*)c->pkt_state, c->maxC);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->pkt_count2, 0, 8, c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(c->rec_count, 0, (size_t)c->maxC * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->overflow, 0, 16, c->stream));
+    for (auto& rs : c->sets) {
+        if (rs.rec_count) HIPCHK(c, hipMemsetAsync(rs.rec_count, 0, (size_t)c->maxC * 4, c->stream));
+        rs.valid = false;
+    }
+    HIPCHK(c, hipMemsetAsync(c->overflow, 0, 32, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));   // the front end of a staged run starts on its own streams: not before this
+    HIPCHK(c, hipStreamWaitEvent(c->pay(), c->ev_mark, 0));   // (nor anything a fetch queues on the payload stream)
     c->pos = 0;
     c->have_run = false;
     c->inplace_after_run = false;
-    c->recs_valid = false;
+    c->sel_back = 0;
     return M17HIP_OK;
 }
 
@@ -1325,8 +1366,13 @@ static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStre
     G.nblk = (C + GT_CPW - 1) / GT_CPW;
     uint32_t fold_blocks = 0;
     if (ahead && k >= 2 && c->defer_evm && c->ev_ops) {   // (K5 of segment k - 2 is through: its EVM operations ride along, sixteen channels per block)
-        G.ev = EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, C, c->ev_cur + (size_t)((k - 2u) & 1u) * c->maxC};
+        G.ev = EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, C, c->ev_cur + (size_t)((k - 2u) & 1u) * c->maxC, 0u};
         fold_blocks = ev_fold_blocks(C);
+    }
+    if (k == 0 && !redo && c->fold_pending && c->ev_ops) {   // the LAST pass of the run before: K5 of this run's first segment waits for this launch anyway
+        G.ev = EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, c->lastC, c->ev_cur + 2 * (size_t)c->maxC, 1u};
+        fold_blocks = ev_fold_blocks(c->lastC);
+        c->fold_pending = false;
     }
     hipLaunchKernelGGL(limit_track_kernel, dim3(G.nblk + fold_blocks), dim3(64), GT_LDS_FLOATS * sizeof(float), st, G);
     HIPCHK(c, hipGetLastError());
@@ -1383,6 +1429,63 @@ static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, b
 }
 
 }  // namespace
+
+// The latest run's last EVM fold pass on the main stream (behind that run), if nothing has taken it along yet.
+static int flush_fold(m17hip_ctx* c)
+{
+    if (!c->fold_pending) return M17HIP_OK;
+    c->fold_pending = false;
+    if (!c->ev_ops) return M17HIP_OK;
+    hipLaunchKernelGGL(evm_deferred_kernel, dim3(ev_fold_blocks(c->lastC)), dim3(64), 0, c->stream,
+                       EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, c->lastC, c->ev_cur + 2 * (size_t)c->maxC, 1u});
+    HIPCHK(c, hipGetLastError());
+    return M17HIP_OK;
+}
+
+// Queue the payload work of the runs whose results nobody has asked for yet, in run order, on the payload stream: the frames K5 left to
+// decode_deferred_kernel (one lane per frame), then the consumers (their state goes from run to run), then `done`.
+// `selected_only`: up to the run the fetch family names (m17hip_frames_select) — a fetch of run k must not queue the work of run k + 1, whose
+// chain may have just begun: everything behind it on the payload stream would wait for that run's end.
+// `older_only`: the run before the latest alone (its record set is about to be written again).
+static int flush_payload(m17hip_ctx* c, bool selected_only = false, bool older_only = false)
+{
+    for (int j = 0; j < 2; ++j) {
+        const int i = j == 0 ? (c->cur ^ 1) : c->cur;   // the older run first
+        if (j == 1 && (older_only || (selected_only && (c->sel_back & 1u)))) break;
+        m17hip_ctx::RecSet& rs = c->sets[i];
+        if (!rs.valid || !rs.pending) continue;
+        const hipStream_t ps = c->pay();
+        HIPCHK(c, hipStreamWaitEvent(ps, c->sets[i ^ 1].done, 0));   // (the run before it, whichever stream did its work; never recorded: no wait)
+        HIPCHK(c, hipStreamWaitEvent(ps, rs.chain, 0));
+        const uint32_t C = rs.C;
+        if (rs.defer_llr && c->defer_hist) {   // (frames are deferred only while both stores exist: m17hip_tune key 15)
+            DeferParams D{};
+            D.recs = rs.recs; D.rec_cap = rs.rec_cap; D.rec_count = rs.rec_count; D.defer = rs.defer_llr; D.hist = c->defer_hist; D.tables = c->tables;
+            D.state = c->seq_state; D.diag_log = c->diag_cap ? c->diag_log : nullptr; D.diag_cap = c->diag_cap; D.diag_count = c->diag_count; D.C = C;
+            D.ev = EvParams{nullptr, 0, nullptr, nullptr, 0, nullptr, C, nullptr, 0u};
+            uint32_t fold_blocks = 0;
+            if (c->fold_with_decode && c->fold_pending && i == c->cur && c->ev_ops) {   // (the latest run's last fold pass, beside its decode on the main stream)
+                D.ev = EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, C, c->ev_cur + 2 * (size_t)c->maxC, 1u};
+                fold_blocks = ev_fold_blocks(C);
+                c->fold_pending = false;
+            }
+            Timed tm(c, KT_DEC, ps);
+            hipLaunchKernelGGL(decode_deferred_kernel, dim3(C + fold_blocks), dim3(64), DEFER_LDS_BYTES, ps, D);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (rs.bert && c->bert_state)   // payload consumer: PRBS9 statistics over this run's BERT records
+            hipLaunchKernelGGL(bert_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, ps, rs.recs, rs.rec_cap, rs.rec_count, (BertState*)c->bert_state, C);
+        if (rs.pkt && c->pkt_cap) {   // payload consumer: packet reassembly over this run's packet records
+            HIPCHK(c, hipMemsetAsync(c->pkt_count2 + i, 0, 4, ps));
+            hipLaunchKernelGGL(packet_asm_kernel, dim3((C + 63) / 64), dim3(64), 0, ps, rs.recs, rs.rec_cap, rs.rec_count, (PacketState*)c->pkt_state, C,
+                               (PacketRec*)c->pkt_recs2[i], c->pkt_cap, c->pkt_count2 + i, c->channel_base);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(rs.done, ps));
+        rs.pending = false;
+    }
+    return M17HIP_OK;
+}
 
 // BASELINE configs[1] as ONE call: matched filter, limit filter and the four correlations of `samples` samples per channel, pipelined in time.
 // The limit filter is one dependent chain per channel over the whole run (12 ns per sample) and is what the call lasts; the matched filter
@@ -1529,10 +1632,23 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         if ((r = gate_mode_for_run(c, sp))) return r;
         if ((r = launch_front_all(c, sp, C, flags))) return r;
     }
-    if (c->defer_decode && !c->defer_llr) {   // the deferred-frame stores exist only where that mode is used (184 B per record slot)
-        HIPCHK(c, hipMalloc((void**)&c->defer_llr, (size_t)c->maxC * c->rec_cap_alloc * 46 * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc((void**)&c->defer_hist, (size_t)c->maxC * DEFER_HIST_WORDS * 64 * sizeof(uint32_t)));
+    // this run's record set: the one the run before the previous one wrote (its payload work is long through; waited for on the device)
+    const int si = (c->sets[0].valid || c->sets[1].valid || c->have_run) ? (c->cur ^ 1) : c->cur;
+    m17hip_ctx::RecSet& rs = c->sets[si];
+    if (!rs.recs) {   // the second set appears with the second run
+        HIPCHK(c, hipMalloc((void**)&rs.recs, (size_t)c->maxC * c->rec_cap_alloc * sizeof(FrameRec)));
+        HIPCHK(c, hipMalloc((void**)&rs.rec_count, (size_t)c->maxC * sizeof(uint32_t)));
+        HIPCHK(c, hipMemsetAsync(rs.rec_count, 0, (size_t)c->maxC * 4, c->stream));
     }
+    if (c->defer_decode && !rs.defer_llr)   // the deferred-frame stores exist only where that mode is used (184 B per record slot)
+        HIPCHK(c, hipMalloc((void**)&rs.defer_llr, (size_t)c->maxC * c->rec_cap_alloc * 46 * sizeof(uint32_t)));
+    if (c->defer_decode && !c->defer_hist)
+        HIPCHK(c, hipMalloc((void**)&c->defer_hist, (size_t)c->maxC * DEFER_HIST_WORDS * 64 * sizeof(uint32_t)));
+    if (rs.valid) {   // the run that wrote it last: its payload work must be through (queued now if nobody asked for it)
+        if (rs.pending && (r = flush_payload(c, false, true))) return r;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, rs.done, 0));
+    }
+    rs.valid = false;
     if (c->defer_evm && !c->ev_ops) {   // the operation rows of the deferred EVM: 4 B per symbol of the longest run
         c->ev_pitch = c->ev_pitch_override ? c->ev_pitch_override : ev_row_floats(c->maxT);
         HIPCHK(c, hipMalloc((void**)&c->ev_ops, (size_t)c->maxC * c->ev_pitch * sizeof(float)));
@@ -1575,20 +1691,21 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         P.dropped = drop_of[k & 1u];
         P.x = c->xbuf + t0; P.xpitch = c->xpitch; P.y = c->ybuf + t0; P.ypitch = c->ypitch;
         P.dcd_table = c->dcd_table; P.ticks_cap = c->ticks_cap; P.state = c->seq_state;
-        P.recs = c->recs; P.rec_cap = c->rec_cap; P.rec_count = c->rec_count; P.overflow = c->overflow;
+        P.recs = rs.recs; P.rec_cap = c->rec_cap; P.rec_count = rs.rec_count; P.overflow = rs.ovf;
         P.tables = c->tables; P.taps = c->taps; P.llr_edges = c->llr_edges;
         P.C = C; P.T = len; P.pos0 = c->pos + t0; P.tick_row0 = c->pos / TICK; P.flags = (flags & 1u) | (t0 ? 2u : 0u) | (std::min(k, 23u) << 8);
         P.kalman_order = c->kalman_order; P.channel_base = c->channel_base;
         P.level_gain = c->level_gain + (size_t)(c->kalman_order & 7u) * core::LEVEL_SCHED_N;
         P.diag_log = c->diag_cap ? c->diag_log : nullptr; P.diag_cap = c->diag_cap; P.diag_count = c->diag_count;
-        P.defer = c->defer_decode ? c->defer_llr : nullptr;
-        if (c->defer_evm) { P.ev_ops = c->ev_ops; P.ev_pitch = c->ev_pitch; P.ev_cursor_out = c->ev_cur + (size_t)(k & 1u) * c->maxC; }
+        P.defer = c->defer_decode ? rs.defer_llr : nullptr;
+        if (c->defer_evm) { P.ev_ops = c->ev_ops; P.ev_pitch = c->ev_pitch; P.ev_cursor_out = c->ev_cur + (size_t)(k + 1u == nseg ? 2u : (k & 1u)) * c->maxC; }
         P.bnd_out = c->bnd + (size_t)((k + 1u) & 1u) * c->maxC;
         P.truth_out = c->truth ? c->truth + (size_t)(k & 1u) * c->maxC : nullptr;
         P.dbg = (c->profile || c->wave_times) ? c->dbg : nullptr;
         return P;
     };
-    HIPCHK(c, hipMemsetAsync(c->overflow + 3, 0, 4, c->stream));   // channel-segments of THIS run that end with the carrier off (K5 counts)
+    HIPCHK(c, hipMemsetAsync(rs.ovf, 0, 4, c->stream));       // record overflow of THIS run
+    HIPCHK(c, hipMemsetAsync(rs.ovf + 3, 0, 4, c->stream));   // channel-segments of THIS run that end with the carrier off (K5 counts)
     for (uint32_t k = 0; k < nseg; ++k) {
         const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
         HIPCHK(c, hipStreamWaitEvent(c->stream, ev_fir[k], 0));
@@ -1646,26 +1763,16 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_tail, c->stream));
     c->gate0_queued = false;
-    if (c->defer_decode) {   // the payload frames K5 did not decode itself, one lane per frame; then the cost tags K5 left are replaced
-        DeferParams D{};
-        D.recs = c->recs; D.rec_cap = c->rec_cap; D.rec_count = c->rec_count; D.defer = c->defer_llr; D.hist = c->defer_hist; D.tables = c->tables;
-        D.state = c->seq_state; D.diag_log = c->diag_cap ? c->diag_log : nullptr; D.diag_cap = c->diag_cap; D.diag_count = c->diag_count; D.C = C;
-        D.ev = EvParams{c->defer_evm ? c->ev_ops : nullptr, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, C, nullptr};
-        Timed tm(c, KT_DEC);
-        hipLaunchKernelGGL(decode_deferred_kernel, dim3(C + (c->defer_evm ? ev_fold_blocks(C) : 0u)), dim3(64), DEFER_LDS_BYTES, c->stream, D);   // (+ the rest of the run's EVM fold)
-        HIPCHK(c, hipGetLastError());
-    } else if (c->defer_evm) {
-        hipLaunchKernelGGL(evm_deferred_kernel, dim3(ev_fold_blocks(C)), dim3(64), 0, c->stream,
-                           EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, C, nullptr});
+    // ---- the end of the run on the MAIN stream: what the next run's chain needs of this one — the one or two deferred costs the state still
+    //      names (settle_tail_kernel).  The rest of the run's EVM fold (the operations of its last two segments: 0.8 ms of one dependent chain
+    //      per channel that nothing in the demodulator reads) is NOT made here: see fold_pending
+    if (c->defer_decode) {
+        SettleParams S{rs.recs, c->rec_cap, rs.defer_llr, c->tables, c->seq_state, C, EvParams{nullptr, 0, nullptr, nullptr, 0, nullptr, C, nullptr, 0u}};
+        hipLaunchKernelGGL(settle_tail_kernel, dim3(C), dim3(64), SETTLE_LDS_BYTES, c->stream, S);
         HIPCHK(c, hipGetLastError());
     }
-    if (c->bert)   // payload consumer: PRBS9 statistics over this run's BERT records
-        hipLaunchKernelGGL(bert_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->recs, c->rec_cap, c->rec_count, (BertState*)c->bert_state, C);
-    if (c->pkt_cap) {   // payload consumer: packet reassembly over this run's packet records
-        HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
-        hipLaunchKernelGGL(packet_asm_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, c->recs, c->rec_cap, c->rec_count, (PacketState*)c->pkt_state, C,
-                           (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count, c->channel_base);
-    }
+    c->fold_pending = c->defer_evm;
+    HIPCHK(c, hipEventRecord(rs.chain, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_end[q], c->stream));
     { std::lock_guard<std::mutex> lk(g_runs.mu); c->last_end = c->ev_end[q]; }
     c->slot_used[q] = true;
@@ -1673,34 +1780,76 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     c->inplace_after_run = false;
     c->lastC = C; c->lastT = T; c->runT = T; c->last_nseg = nseg;
     c->have_run = true;
-    c->recs_valid = true;
+    rs.valid = true; rs.C = C; rs.rec_cap = c->rec_cap; rs.nseg = nseg;
+    rs.pending = true; rs.bert = c->bert; rs.pkt = c->pkt_cap != 0;
+    c->cur = si;
+    c->sel_back = 0;
+    // The run's payload work — the frames K5 did not decode itself, then the consumers — is queued when its results are asked for.  At once
+    // where that costs nothing or is needed: a context that does not stream (the work goes to the main stream, behind the run, as up to round 5),
+    // and with the diagnostic log on (ONE store, which the deferred decode patches: the next run waits for it).
+    if (!c->copy || c->diag_cap) {
+        c->fold_with_decode = c->fold_pending && c->defer_decode && c->pay() == c->stream;   // (beside the decode, as up to round 5)
+        if ((r = flush_payload(c))) return r;
+        c->fold_with_decode = false;
+        if (c->diag_cap) {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, rs.done, 0));
+            if ((r = flush_fold(c))) return r;
+        }
+    }
     return M17HIP_OK;
 }
 
-// Offsets + (optionally) the dense copy in one pass and ONE stream synchronisation.  *count = records the run produced;
+// The record set the fetch family names (m17hip_frames_select): the latest run's, or the run's before it; nullptr when that run's
+// records are not there (no such run since the reset, or the layout was changed under them: m17hip_tune key 8).
+static m17hip_ctx::RecSet* selected_set(m17hip_ctx* c)
+{
+    m17hip_ctx::RecSet& rs = c->sets[c->cur ^ (int)(c->sel_back & 1u)];
+    return rs.valid ? &rs : nullptr;
+}
+
+// Offsets + (optionally) the dense copy in one pass and ONE stream synchronisation — of the PAYLOAD stream: behind the deferred decode
+// and the consumers of the run concerned, beside whatever the main stream has been given since.  *count = records the run produced;
 // at most `cap` of them are written.  M17HIP_EOVERFLOW: a channel outran its record slots during the run;
 // M17HIP_ETRUNC: more records than `cap`.
 static int compact_into(m17hip_ctx* c, FrameRec* dev_out, uint64_t cap, uint64_t* count)
 {
-    const uint32_t C = c->lastC;
+    m17hip_ctx::RecSet* rs = selected_set(c);
+    if (!rs) return M17HIP_ESTATE;
+    if (int fr = flush_payload(c, true)) return fr;
+    const uint32_t C = rs->C;
+    if (dev_out && dev_out != c->compact && c->sel_back == 0 && c->pay() != c->stream) {
+        // a device destination of the caller's: whatever the caller queued on the main stream for it (a fill, its previous consumer) comes first —
+        // for the LATEST run that costs nothing (the payload work waits for that run's end on the main stream anyway); with a newer run queued
+        // (m17hip_frames_select(ctx, 1)) the destination must be ready when the call is made (include/m17hip.h)
+        HIPCHK(c, hipEventRecord(c->ev_dst, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->pay(), c->ev_dst, 0));
+    }
     {
-        Timed tm(c, KT_COMPACT);
-        hipLaunchKernelGGL(rec_offsets_kernel, dim3(1), dim3(256), 0, c->stream, c->rec_count, c->rec_cap, c->rec_offsets, C);
+        Timed tm(c, KT_COMPACT, c->pay());
+        hipLaunchKernelGGL(rec_offsets_kernel, dim3(1), dim3(256), 0, c->pay(), rs->rec_count, rs->rec_cap, c->rec_offsets, C);
         HIPCHK(c, hipGetLastError());
         if (dev_out) {
-            hipLaunchKernelGGL(compact_kernel, dim3(C), dim3(64), 0, c->stream, c->recs, c->rec_cap, c->rec_count, c->rec_offsets, dev_out, cap, C);
+            hipLaunchKernelGGL(compact_kernel, dim3(C), dim3(64), 0, c->pay(), rs->recs, rs->rec_cap, rs->rec_count, c->rec_offsets, dev_out, cap, C);
             HIPCHK(c, hipGetLastError());
         }
     }
     uint64_t total = 0;
     uint32_t ovf[4] = {0, 0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(&total, c->rec_offsets + C, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ovf, c->overflow, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(&total, c->rec_offsets + C, 8, hipMemcpyDeviceToHost, c->pay()));
+    HIPCHK(c, hipMemcpyAsync(ovf, rs->ovf, 16, hipMemcpyDeviceToHost, c->pay()));
+    HIPCHK(c, hipStreamSynchronize(c->pay()));
     if (count) *count = total;
-    c->off_segs_prev = ovf[3]; c->chan_segs_prev = c->lastC * std::max(1u, c->last_nseg);   // (what the next run's gate-aware choice looks at)
+    c->off_segs_prev = ovf[3]; c->chan_segs_prev = rs->C * std::max(1u, rs->nseg);   // (what the next run's gate-aware choice looks at)
     if (ovf[0]) return M17HIP_EOVERFLOW;
     if (dev_out && total > cap) return M17HIP_ETRUNC;
+    return M17HIP_OK;
+}
+
+int m17hip_frames_select(m17hip_ctx* c, uint32_t back)
+{
+    if (!c || back > 1) return M17HIP_EINVAL;
+    if (!c->sets[c->cur ^ (int)back].valid) return M17HIP_ESTATE;
+    c->sel_back = back;
     return M17HIP_OK;
 }
 
@@ -1708,7 +1857,6 @@ int m17hip_frames_count(m17hip_ctx* c, uint64_t* total)
 {
     if (!c || !total) return M17HIP_EINVAL;
     GUARD(c);
-    if (!c->recs_valid) return M17HIP_ESTATE;
     return compact_into(c, nullptr, 0, total);
 }
 
@@ -1716,7 +1864,6 @@ int m17hip_frames_compact_device(m17hip_ctx* c, m17_frame_rec* recs_dev, uint64_
 {
     if (!c || !recs_dev) return M17HIP_EINVAL;
     GUARD(c);
-    if (!c->recs_valid) return M17HIP_ESTATE;
     return compact_into(c, (FrameRec*)recs_dev, capacity, count);
 }
 
@@ -1724,11 +1871,13 @@ int m17hip_frames_fetch(m17hip_ctx* c, m17_frame_rec* recs_host, uint64_t capaci
 {
     if (!c || !recs_host) return M17HIP_EINVAL;
     GUARD(c);
-    if (!c->recs_valid) return M17HIP_ESTATE;
+    const m17hip_ctx::RecSet* rs = selected_set(c);
+    if (!rs) return M17HIP_ESTATE;
     // one compaction into the context's dense buffer; it is sized for the caller's capacity (records beyond it are not
     // wanted anyway), so a second pass is never needed
-    const uint64_t want = std::max<uint64_t>(std::min<uint64_t>(capacity, (uint64_t)c->lastC * c->rec_cap), 1024);
+    const uint64_t want = std::max<uint64_t>(std::min<uint64_t>(capacity, (uint64_t)rs->C * rs->rec_cap), 1024);
     if (want > c->compact_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->pay()));   // (nothing still reads the old one)
         free_dev(c->compact, &c->last_hip); c->compact_cap = 0;
         HIPCHK(c, hipMalloc((void**)&c->compact, (size_t)want * sizeof(FrameRec)));
         c->compact_cap = want;
@@ -1746,27 +1895,33 @@ int m17hip_diag_fetch(m17hip_ctx* c, m17_diag* diag_host, uint32_t C)
 {
     if (!c || !diag_host || C == 0 || C > c->maxC) return M17HIP_EINVAL;
     GUARD(c);
+    if (int fr = flush_fold(c)) return fr;        // m17_diag::evm of the latest run: its last fold pass, if nothing has made it yet
+    if (c->front_pending && c->gate0_queued)      // (... or the replay m17hip_demod_front queued for the next run is making it: wait for that launch)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gate_[c->slot][0], 0));
     HIPCHK(c, hipMemcpy2DAsync(diag_host, sizeof(Diag), &c->seq_state[0].cold.diag, sizeof(SeqState), sizeof(Diag), C, hipMemcpyDeviceToHost,
                                c->stream));
-    uint32_t ovf[4] = {0, 0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(ovf, c->overflow, 16, hipMemcpyDeviceToHost, c->stream));
+    uint32_t ovf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(ovf, c->overflow, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return ovf[2] ? M17HIP_EOVERFLOW : M17HIP_OK;   // (a channel outran its row of deferred EVM operations: every field but `evm` is right)
+    return (ovf[2] | ovf[6]) ? M17HIP_EOVERFLOW : M17HIP_OK;   // (a channel outran its row of deferred EVM operations: every field but `evm` is right)
 }
 
 int m17hip_diag_log_fetch(m17hip_ctx* c, m17_diag* log_host, uint32_t* counts_host, uint32_t C, uint32_t capacity)
 {
     if (!c || !log_host || !counts_host || C == 0 || C > c->maxC || capacity == 0) return M17HIP_EINVAL;
     GUARD(c);
-    if (!c->diag_cap || !c->recs_valid) return M17HIP_ESTATE;
+    if (!c->diag_cap || !c->sets[c->cur].valid) return M17HIP_ESTATE;
+    if (int fr = flush_fold(c)) return fr;
+    if (int fr = flush_payload(c)) return fr;
+    HIPCHK(c, hipStreamSynchronize(c->pay()));   // (the deferred decode has put the costs into the log's entries)
     HIPCHK(c, hipMemcpyAsync(counts_host, c->diag_count, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
     const uint32_t n = std::min(capacity, c->diag_cap);
     HIPCHK(c, hipMemcpy2DAsync(log_host, (size_t)capacity * sizeof(Diag), c->diag_log, (size_t)c->diag_cap * sizeof(Diag), (size_t)n * sizeof(Diag), C,
                                hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint32_t ovf[4] = {0, 0, 0, 0};
-    HIPCHK(c, hipMemcpy(ovf, c->overflow, 16, hipMemcpyDeviceToHost));
-    if (ovf[2]) return M17HIP_EOVERFLOW;   // (deferred EVM operations were dropped: see m17hip_diag_fetch)
+    uint32_t ovf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(c, hipMemcpy(ovf, c->overflow, 32, hipMemcpyDeviceToHost));
+    if (ovf[2] | ovf[6]) return M17HIP_EOVERFLOW;   // (deferred EVM operations were dropped: see m17hip_diag_fetch)
     bool trunc = false;
     for (uint32_t i = 0; i < C; ++i) trunc = trunc || counts_host[i] > n;
     return trunc ? M17HIP_ETRUNC : M17HIP_OK;
@@ -1795,9 +1950,10 @@ int m17hip_bert_stats(m17hip_ctx* c, m17_bert_stat* stats_host, uint32_t C)
     if (!c || !stats_host || C == 0 || C > c->maxC) return M17HIP_EINVAL;
     GUARD(c);
     if (!c->bert) return M17HIP_ESTATE;
+    if (int fr = flush_payload(c)) return fr;
     std::vector<BertState> tmp(C);
-    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->bert_state, (size_t)C * sizeof(BertState), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->bert_state, (size_t)C * sizeof(BertState), hipMemcpyDeviceToHost, c->pay()));   // (behind the consumers of the runs queued so far)
+    HIPCHK(c, hipStreamSynchronize(c->pay()));
     for (uint32_t i = 0; i < C; ++i) {
         stats_host[i].bits = tmp[i].bit_count; stats_host[i].errors = tmp[i].err_count;
         stats_host[i].synced = tmp[i].synced; stats_host[i].frames = tmp[i].frames;
@@ -1810,18 +1966,21 @@ int m17hip_packets_feed(m17hip_ctx* c, const m17_frame_rec* recs_host, const uin
     if (!c || !recs_host || !counts_host || C == 0 || C > c->maxC || pitch == 0) return M17HIP_EINVAL;
     GUARD(c);
     if (!c->pkt_cap) return M17HIP_ESTATE;
+    if (int fr = flush_payload(c)) return fr;
     const size_t rec_b = round_up((size_t)C * pitch * sizeof(FrameRec), 256);
     int r = ensure_scratch(c, rec_b + (size_t)C * 4);
     if (r) return r;
     FrameRec* drec = reinterpret_cast<FrameRec*>(c->scratch);
     uint32_t* dcnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->scratch) + rec_b);
-    HIPCHK(c, hipMemcpyAsync(drec, recs_host, (size_t)C * pitch * sizeof(FrameRec), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dcnt, counts_host, (size_t)C * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
-    hipLaunchKernelGGL(packet_asm_kernel, dim3((C + 63) / 64), dim3(64), 0, c->stream, drec, pitch, dcnt, (PacketState*)c->pkt_state, C,
-                       (PacketRec*)c->pkt_recs, c->pkt_cap, c->pkt_count, c->channel_base);
+    // (the payload stream: where the runs' own packet consumer works on the same reassembly state)
+    HIPCHK(c, hipMemcpyAsync(drec, recs_host, (size_t)C * pitch * sizeof(FrameRec), hipMemcpyHostToDevice, c->pay()));
+    HIPCHK(c, hipMemcpyAsync(dcnt, counts_host, (size_t)C * 4, hipMemcpyHostToDevice, c->pay()));
+    const int ps = c->cur;   // (the store of the latest run's set: what m17hip_packets_fetch names unless m17hip_frames_select says otherwise)
+    HIPCHK(c, hipMemsetAsync(c->pkt_count2 + ps, 0, 4, c->pay()));
+    hipLaunchKernelGGL(packet_asm_kernel, dim3((C + 63) / 64), dim3(64), 0, c->pay(), drec, pitch, dcnt, (PacketState*)c->pkt_state, C,
+                       (PacketRec*)c->pkt_recs2[ps], c->pkt_cap, c->pkt_count2 + ps, c->channel_base);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // the host buffers may go away
+    HIPCHK(c, hipStreamSynchronize(c->pay()));   // the host buffers may go away
     c->pkt_fed = true;
     return M17HIP_OK;
 }
@@ -1832,13 +1991,16 @@ int m17hip_packets_fetch(m17hip_ctx* c, m17_packet_rec* recs_host, uint32_t capa
     GUARD(c);
     static_assert(sizeof(PacketRec) == sizeof(m17_packet_rec) && sizeof(PacketRec) == 864, "m17_packet_rec layout");
     if (!c->pkt_cap || !(c->have_run || c->pkt_fed)) return M17HIP_ESTATE;
+    const int ps = c->cur ^ (int)(c->sel_back & 1u);   // the packets completed by the SELECTED run (m17hip_frames_select)
+    if (c->sel_back && !c->sets[ps].valid) return M17HIP_ESTATE;
+    if (int fr = flush_payload(c, true)) return fr;
     uint32_t total = 0;
-    HIPCHK(c, hipMemcpyAsync(&total, c->pkt_count, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(&total, c->pkt_count2 + ps, 4, hipMemcpyDeviceToHost, c->pay()));
+    HIPCHK(c, hipStreamSynchronize(c->pay()));
     *count = total;
     const uint32_t stored = std::min(total, c->pkt_cap);
     std::vector<PacketRec> tmp(stored);
-    if (stored) HIPCHK(c, hipMemcpy(tmp.data(), c->pkt_recs, (size_t)stored * sizeof(PacketRec), hipMemcpyDeviceToHost));
+    if (stored) HIPCHK(c, hipMemcpy(tmp.data(), c->pkt_recs2[ps], (size_t)stored * sizeof(PacketRec), hipMemcpyDeviceToHost));
     std::sort(tmp.begin(), tmp.end(), [](const PacketRec& a, const PacketRec& b) { return a.channel != b.channel ? a.channel < b.channel : a.seq < b.seq; });
     const uint32_t n = std::min(stored, capacity);
     if (n) std::memcpy(recs_host, tmp.data(), (size_t)n * sizeof(PacketRec));
@@ -1964,14 +2126,14 @@ static void comm_give_up(m17hip_comm* m, int code)
 static int comm_wait(m17hip_ctx* c, m17hip_comm* m)
 {
     if (c->gather_timeout_ms == 0) {
-        const hipError_t e = hipStreamSynchronize(c->stream);
+        const hipError_t e = hipStreamSynchronize(c->pay());
         if (e != hipSuccess) { c->last_hip = (int)e; return M17HIP_EHIP; }
         return M17HIP_OK;
     }
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (uint64_t spins = 0;; ++spins) {
-        const hipError_t e = hipStreamQuery(c->stream);
+        const hipError_t e = hipStreamQuery(c->pay());
         if (e == hipSuccess) return M17HIP_OK;
         if (e != hipErrorNotReady) { c->last_hip = (int)e; return M17HIP_EHIP; }
         (void)hipGetLastError();
@@ -1997,7 +2159,7 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
     auto comm_failed = [&](ncclResult_t q) { comm_give_up(m, (int)q); return M17HIP_ECOMM; };   // a collective call itself failed: nothing more can be agreed on
     // 1. this rank's records, dense and (channel, seq)-ordered, in the context's compaction buffer
     uint64_t mine = 0;
-    int local = c->recs_valid ? M17HIP_OK : M17HIP_ESTATE;
+    int local = selected_set(c) ? M17HIP_OK : M17HIP_ESTATE;
     bool overflow = false;
     if (local == M17HIP_OK) {
         int r = c->gather_fault == 1 ? M17HIP_EHIP : compact_into(c, c->compact, c->compact_cap, &mine);
@@ -2029,11 +2191,11 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
     const size_t words_n = 2 * (size_t)m->nranks;
     int unread = M17HIP_OK;   // this rank could not read exchange 1
     {
-        hipError_t e = hipMemcpyAsync(m->counts_dev + 2 * m->rank, word, 16, hipMemcpyHostToDevice, c->stream);
+        hipError_t e = hipMemcpyAsync(m->counts_dev + 2 * m->rank, word, 16, hipMemcpyHostToDevice, c->pay());
         if (e != hipSuccess && !local) local = hip_code(e);     // (our slot keeps the previous call's word: its serial gives it away)
-        const ncclResult_t q = R.AllGather(m->counts_dev + 2 * m->rank, m->counts_dev, 2, ncclUint64, m->comm, c->stream);
+        const ncclResult_t q = R.AllGather(m->counts_dev + 2 * m->rank, m->counts_dev, 2, ncclUint64, m->comm, c->pay());
         if (q != ncclSuccess) return comm_failed(q);
-        e = c->gather_fault == 4 ? hipErrorUnknown : hipMemcpyAsync(words, m->counts_dev, words_n * 8, hipMemcpyDeviceToHost, c->stream);
+        e = c->gather_fault == 4 ? hipErrorUnknown : hipMemcpyAsync(words, m->counts_dev, words_n * 8, hipMemcpyDeviceToHost, c->pay());
         if (e != hipSuccess) unread = hip_code(e);
         const int w = comm_wait(c, m);
         if (w == M17HIP_ECOMM) return w;     // not in time: the communicator is given up
@@ -2066,11 +2228,11 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
     constexpr uint64_t PHASE2 = 0xA5ull << 56;
     {
         word[0] = PHASE2 | (serial << 40) | (uint64_t)(uint8_t)(-rc);
-        const hipError_t ew = c->gather_fault == 3 ? hipErrorUnknown : hipMemcpyAsync(m->counts_dev + 2 * m->rank, word, 8, hipMemcpyHostToDevice, c->stream);
+        const hipError_t ew = c->gather_fault == 3 ? hipErrorUnknown : hipMemcpyAsync(m->counts_dev + 2 * m->rank, word, 8, hipMemcpyHostToDevice, c->pay());
         if (ew != hipSuccess && !rc) rc = hip_code(ew);          // (our slot keeps a word of exchange 1: no tag — every rank sees that)
-        const ncclResult_t q = R.AllGather(m->counts_dev + 2 * m->rank, m->counts_dev, 2, ncclUint64, m->comm, c->stream);
+        const ncclResult_t q = R.AllGather(m->counts_dev + 2 * m->rank, m->counts_dev, 2, ncclUint64, m->comm, c->pay());
         if (q != ncclSuccess) return comm_failed(q);
-        hipError_t e = c->gather_fault == 5 ? hipErrorUnknown : hipMemcpyAsync(words, m->counts_dev, words_n * 8, hipMemcpyDeviceToHost, c->stream);
+        hipError_t e = c->gather_fault == 5 ? hipErrorUnknown : hipMemcpyAsync(words, m->counts_dev, words_n * 8, hipMemcpyDeviceToHost, c->pay());
         const int w = comm_wait(c, m);
         if (w == M17HIP_ECOMM) return w;
         // this rank cannot read what was agreed on: it cannot know whether the records travel, so it takes no part in exchange 3.  If they
@@ -2093,7 +2255,7 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
         ncclResult_t q = R.GroupStart();
         uint64_t off = 0;
         for (int k = 0; k < m->nranks && q == ncclSuccess; ++k) {
-            if (k != root && counts[k]) q = R.Recv(m->gathered + off, (size_t)counts[k] * sizeof(FrameRec), ncclUint8, k, m->comm, c->stream);
+            if (k != root && counts[k]) q = R.Recv(m->gathered + off, (size_t)counts[k] * sizeof(FrameRec), ncclUint8, k, m->comm, c->pay());
             off += counts[k];
         }
         const ncclResult_t qe = R.GroupEnd();   // the group is closed whatever happened inside it
@@ -2102,7 +2264,7 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
         off = 0;
         hipError_t he = hipSuccess;
         for (int k = 0; k < m->nranks; ++k) {   // the root's own share: a plain copy, outside the group
-            if (k == root && mine) he = hipMemcpyAsync(m->gathered + off, c->compact, (size_t)mine * sizeof(FrameRec), hipMemcpyDeviceToDevice, c->stream);
+            if (k == root && mine) he = hipMemcpyAsync(m->gathered + off, c->compact, (size_t)mine * sizeof(FrameRec), hipMemcpyDeviceToDevice, c->pay());
             off += counts[k];
         }
         if (he != hipSuccess) return hip_code(he);
@@ -2111,15 +2273,19 @@ static int gather_frames_impl(m17hip_ctx* c, m17hip_comm* m, int root, m17_frame
         // never leaves a copy into the caller's memory behind
         const uint64_t n = std::min(total, capacity);
         if (n) {
-            HIPCHK(c, hipMemcpyAsync(recs_host, m->gathered, (size_t)n * sizeof(FrameRec), dest_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (dest_is_device && c->sel_back == 0 && c->pay() != c->stream) {   // (a device destination: behind the caller's main-stream work on it, as in compact_into)
+                HIPCHK(c, hipEventRecord(c->ev_dst, c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->pay(), c->ev_dst, 0));
+            }
+            HIPCHK(c, hipMemcpyAsync(recs_host, m->gathered, (size_t)n * sizeof(FrameRec), dest_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->pay()));
+            HIPCHK(c, hipStreamSynchronize(c->pay()));
         }
         if (overflow) return M17HIP_EOVERFLOW;
         return total > capacity ? M17HIP_ETRUNC : M17HIP_OK;
     }
     if (mine) {
         ncclResult_t q = R.GroupStart();
-        if (q == ncclSuccess) q = R.Send(c->compact, (size_t)mine * sizeof(FrameRec), ncclUint8, root, m->comm, c->stream);
+        if (q == ncclSuccess) q = R.Send(c->compact, (size_t)mine * sizeof(FrameRec), ncclUint8, root, m->comm, c->pay());
         const ncclResult_t qe = R.GroupEnd();
         if (q == ncclSuccess) q = qe;
         if (q != ncclSuccess) return comm_failed(q);
@@ -2161,33 +2327,38 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
         c->seg_len = (uint32_t)value;
         return M17HIP_OK;
-    case 6:  // BERT statistics (m17hip_bert_stats) on/off
+    case 6:  // BERT statistics (m17hip_bert_stats) on/off (the runs made so far keep the setting they were made with)
         c->bert = value != 0;
         return M17HIP_OK;
     case 7: {  // packet reassembly (m17hip_packets_fetch): room for `value` completed packets per run, 0 = off
         if (value < 0 || value > (1 << 24)) return M17HIP_EINVAL;
+        if (int fr = flush_payload(c)) return fr;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        free_dev(c->pkt_recs, &c->last_hip); c->pkt_cap = 0; c->pkt_fed = false;
+        HIPCHK(c, hipStreamSynchronize(c->pay()));
+        free_dev(c->pkt_recs2[0], &c->last_hip); free_dev(c->pkt_recs2[1], &c->last_hip); c->pkt_cap = 0; c->pkt_fed = false;
         if (value == 0) return M17HIP_OK;
         if (!c->pkt_state) {
             HIPCHK(c, hipMalloc(&c->pkt_state, (size_t)c->maxC * sizeof(PacketState)));
-            HIPCHK(c, hipMalloc((void**)&c->pkt_count, 4));
+            HIPCHK(c, hipMalloc((void**)&c->pkt_count2, 8));
         }
-        HIPCHK(c, hipMalloc(&c->pkt_recs, (size_t)value * sizeof(PacketRec)));
+        HIPCHK(c, hipMalloc(&c->pkt_recs2[0], (size_t)value * sizeof(PacketRec)));
+        HIPCHK(c, hipMalloc(&c->pkt_recs2[1], (size_t)value * sizeof(PacketRec)));
         c->pkt_cap = (uint32_t)value;
         hipLaunchKernelGGL(packet_reset_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, (PacketState*)c->pkt_state, c->maxC);
-        HIPCHK(c, hipMemsetAsync(c->pkt_count, 0, 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->pkt_count2, 0, 8, c->stream));
         HIPCHK(c, hipGetLastError());
         return M17HIP_OK;
     }
     case 8:  // record slots per channel and run actually used (0 = all that were allocated): exercises M17HIP_EOVERFLOW
         if (value < 0 || value > (int64_t)c->rec_cap_alloc) return M17HIP_EINVAL;
-        c->rec_cap = value ? (uint32_t)value : c->rec_cap_alloc;
-        c->recs_valid = false;   // the slots of the last run were written with the old stride: nothing to fetch until the next run
+        c->rec_cap = value ? (uint32_t)value : c->rec_cap_alloc;   // (the sets keep the layout they were written with: a finished run's records stay fetchable)
         return M17HIP_OK;
     case 9: {  // diagnostic log: room for `value` diagnostic callbacks per channel and run, 0 = off (m17hip_diag_log_fetch)
         if (value < 0 || value > (1 << 20)) return M17HIP_EINVAL;
+        if (int fr = flush_fold(c)) return fr;
+        if (int fr = flush_payload(c)) return fr;
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->pay()));
         free_dev(c->diag_log, &c->last_hip); c->diag_cap = 0;
         if (value == 0) return M17HIP_OK;
         if (!c->diag_count) HIPCHK(c, hipMalloc((void**)&c->diag_count, (size_t)c->maxC * 4));
@@ -2206,6 +2377,7 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         return M17HIP_OK;
     case 17:  // RunningStandardDeviation (the EVM of the diagnostic callback) folded outside K5, one lane per channel (1, default), or inside K5 (0)
         if ((value != 0) != c->defer_evm) {
+            if (int fr = flush_fold(c)) return fr;
             HIPCHK(c, hipStreamSynchronize(c->stream));
             c->defer_evm = value != 0;
             hipLaunchKernelGGL(ev_move_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->ev_state, c->maxC, c->defer_evm ? 1 : 0);
@@ -2215,15 +2387,19 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         return M17HIP_OK;
     case 18:  // (tests) floats per channel row of deferred EVM operations, 0 = what a run of max_samples can produce: a smaller value makes the overflow flag reachable
         if (value < 0 || value > (1 << 28) || (value & 3)) return M17HIP_EINVAL;
+        if (int fr = flush_fold(c)) return fr;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         free_dev(c->ev_ops, &c->last_hip);
         c->ev_pitch_override = (uint32_t)value;
         return M17HIP_OK;
     case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1, default), or in K5 (0)
         c->defer_decode = value != 0;
-        if (!c->defer_decode && c->defer_llr) {   // give the stores back (a run in flight may still use them: wait for it)
+        if (!c->defer_decode && c->defer_hist) {   // give the stores back (a run in flight may still use them: wait for it)
+            if (int fr = flush_payload(c)) return fr;
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            free_dev(c->defer_llr, &c->last_hip); free_dev(c->defer_hist, &c->last_hip);
+            HIPCHK(c, hipStreamSynchronize(c->pay()));
+            for (auto& rs_ : c->sets) free_dev(rs_.defer_llr, &c->last_hip);
+            free_dev(c->defer_hist, &c->last_hip);
         }
         return M17HIP_OK;
     case 30:  // fault injection for m17hip_gather_frames (tests): 0 = none, 1 = this rank's compaction fails, 2 = the root's staging allocation fails,

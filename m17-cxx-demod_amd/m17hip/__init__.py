@@ -39,7 +39,7 @@ EXPORTS = [
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_packets_fetch", "m17hip_packets_feed", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
     "m17hip_set_kalman_order", "m17hip_kalman_trace", "m17hip_set_channel_base", "m17hip_upload_wait", "m17hip_comm_get_id", "m17hip_comm_create",
     "m17hip_comm_destroy", "m17hip_comm_last_error", "m17hip_gather_frames", "m17hip_gather_frames_device", "m17hip_diag_log_fetch",
-    "m17hip_upload_i16_device_async", "m17hip_input_alternate", "m17hip_demod_front", "m17hip_advice", "m17hip_replay_drops",
+    "m17hip_upload_i16_device_async", "m17hip_input_alternate", "m17hip_demod_front", "m17hip_advice", "m17hip_replay_drops", "m17hip_frames_select",
 ]
 ETRUNC = -6
 COMM_ID_BYTES = 128
@@ -294,6 +294,11 @@ class Context:
 
     def run(self, flags=0, channels=None, samples=None):
         self._chk(self.lib.m17hip_demod_run(self.h, C.c_uint32(channels or self.C), C.c_uint32(samples or self.T), C.c_uint32(flags)))
+
+    def frames_select(self, back):
+        """Which run's records frames_count / frames / frames_compact_device / gather_frames name: 0 = the latest run (every run() selects it
+        again), 1 = the run before it (a live feed collects run k after it has queued run k + 1)."""
+        self._chk(self.lib.m17hip_frames_select(self.h, C.c_uint32(back)))
 
     def frames_count(self):
         n = C.c_uint64(0)

@@ -42,8 +42,15 @@ def ctx(request):
     c.close()
 
 
-def _pipelined(ctx, Cn, lengths, stage):
-    """The call sequence of a live feed: stage(k + 1), front(k + 1), fetch run k, run(k + 1)."""
+@pytest.fixture(params=["fetch_then_run", "run_then_fetch"])
+def order(request):
+    """The two call sequences of a live feed (include/m17hip.h): run k's records collected BEFORE run k + 1's state-machine half is queued
+    (up to round 5 the only one), or AFTER it (m17hip_frames_select(1): nothing of run k + 1 waits for run k's payload work)."""
+    return request.param
+
+
+def _pipelined(ctx, Cn, lengths, stage, order="fetch_then_run"):
+    """The call sequence of a live feed: stage(k + 1), front(k + 1), then fetch run k and run(k + 1) in either order."""
     ctx.reset()
     stage(0)
     ctx.run(channels=Cn, samples=lengths[0])
@@ -52,8 +59,12 @@ def _pipelined(ctx, Cn, lengths, stage):
         if k + 1 < len(lengths):
             stage(k + 1)
             ctx.front(channels=Cn, samples=lengths[k + 1])
-        parts.append(ctx.frames().copy())          # still run k's records: the front end touches none of them
-        if k + 1 < len(lengths):
+            if order == "run_then_fetch":
+                ctx.run(channels=Cn, samples=lengths[k + 1])
+                ctx.frames_select(1)               # run k's records, with run k + 1 queued behind it
+        parts.append(ctx.frames().copy())          # still run k's records: neither the front end nor the next run touches them
+        ctx.frames_select(0)                       # (the selection stays until the next run or until it is changed)
+        if k + 1 < len(lengths) and order != "run_then_fetch":
             ctx.run(channels=Cn, samples=lengths[k + 1])
     return _sorted(parts)
 
@@ -64,18 +75,18 @@ def _check_diag(ctx, Cn, diags):
         assert np.array_equal(d[f], diags[f], equal_nan=True), f
 
 
-def test_pipelined_runs_from_pinned_host_memory(ctx):
+def test_pipelined_runs_from_pinned_host_memory(ctx, order):
     import torch
     Cn, T, n = 64, 24000, 5
     x = _signals(Cn, n * T, seed=101, sigma=600.0)
     exp, diags = _oracle(x)
     pinned = [torch.from_numpy(np.ascontiguousarray(x[:, k * T:(k + 1) * T])).pin_memory() for k in range(n)]
-    got = _pipelined(ctx, Cn, [T] * n, lambda k: ctx.upload_async(pinned[k].data_ptr(), Cn, T))
+    got = _pipelined(ctx, Cn, [T] * n, lambda k: ctx.upload_async(pinned[k].data_ptr(), Cn, T), order)
     assert got.tobytes() == exp.tobytes() and got.size > 3 * Cn
     _check_diag(ctx, Cn, diags)
 
 
-def test_pipelined_runs_from_device_memory(ctx):
+def test_pipelined_runs_from_device_memory(ctx, order):
     """m17hip_upload_i16_device_async: the chunks are handed over by a producer on the GPU (pitch > samples: a view into its buffer)."""
     import torch
     Cn, T, n = 48, 19200, 6
@@ -84,13 +95,13 @@ def test_pipelined_runs_from_device_memory(ctx):
     dev = torch.from_numpy(x).cuda()               # [Cn][n * T]: chunk k = columns [k T, (k + 1) T), row pitch n * T
     torch.cuda.synchronize()                       # the producer's buffer is COMPLETE before it is handed over: a copy from pageable memory may still be in
                                                    # flight when .cuda() returns, and the context's copy stream does not wait for torch's (seen once in ~15 full runs)
-    got = _pipelined(ctx, Cn, [T] * n, lambda k: ctx.upload_device_async(dev.data_ptr() + 2 * k * T, Cn, T, pitch=n * T))
+    got = _pipelined(ctx, Cn, [T] * n, lambda k: ctx.upload_device_async(dev.data_ptr() + 2 * k * T, Cn, T, pitch=n * T), order)
     ctx.upload_wait()
     assert got.tobytes() == exp.tobytes() and got.size > 3 * Cn
     _check_diag(ctx, Cn, diags)
 
 
-def test_two_resident_slabs_alternate_without_copies(ctx):
+def test_two_resident_slabs_alternate_without_copies(ctx, order):
     """m17hip_input_alternate: slab A, slab B, A, B, ... — the regime of bench.py's single-stream leg.  The stream the channels see
     is A B A B A B; the oracle demodulates exactly that."""
     import torch
@@ -117,8 +128,12 @@ def test_two_resident_slabs_alternate_without_copies(ctx):
         if k + 1 < 6:
             stage(k + 1)
             ctx.front(channels=Cn, samples=T)
+            if order == "run_then_fetch":
+                ctx.run(channels=Cn, samples=T)
+                ctx.frames_select(1)
         parts.append(ctx.frames().copy())
-        if k + 1 < 6:
+        ctx.frames_select(0)
+        if k + 1 < 6 and order != "run_then_fetch":
             ctx.run(channels=Cn, samples=T)
     got = _sorted(parts)
     assert got.tobytes() == exp.tobytes() and got.size > 6 * Cn
@@ -180,7 +195,7 @@ def test_pipelined_ragged_chunks_and_mixed_staging(ctx):
     _check_diag(ctx, Cn, diags)
 
 
-def test_pipelined_lost_sync_across_run_boundaries(ctx):
+def test_pipelined_lost_sync_across_run_boundaries(ctx, order):
     """Bursts followed by loud noise: sync is lost, dcd.unlock() is forced (K2's speculation is dropped), the gated FIR restarts —
     with run boundaries falling anywhere in that."""
     import torch
@@ -188,7 +203,7 @@ def test_pipelined_lost_sync_across_run_boundaries(ctx):
     x = _signals(Cn, n * T, seed=106, sigma=500.0, n_frames=14, tail_sigma=3000.0)
     exp, diags = _oracle(x)
     pinned = [torch.from_numpy(np.ascontiguousarray(x[:, k * T:(k + 1) * T])).pin_memory() for k in range(n)]
-    got = _pipelined(ctx, Cn, [T] * n, lambda k: ctx.upload_async(pinned[k].data_ptr(), Cn, T))
+    got = _pipelined(ctx, Cn, [T] * n, lambda k: ctx.upload_async(pinned[k].data_ptr(), Cn, T), order)
     assert got.tobytes() == exp.tobytes() and got.size > Cn
     _check_diag(ctx, Cn, diags)
 
@@ -288,3 +303,91 @@ def test_the_evm_fold_can_move_between_runs_of_a_stream():
     assert _sorted(parts).tobytes() == exp.tobytes()
     _check_diag(c, Cn, diags)
     c.close()
+
+
+def test_records_and_consumers_of_run_k_are_collected_after_run_k_plus_1_was_queued():
+    """the deferred decode, the payload consumers, the compaction and the host's wait for them are off the chain of a continued
+    stream — a run ends on the main stream with its state settled (settle_tail_kernel), everything else works on the payload stream on the
+    record set of its own run, and the fetch family names the run before the latest after m17hip_frames_select(ctx, 1).  Six runs of
+    BERT / voice / packet channels with the BERT and packet consumers on: records, PRBS9 statistics, reassembled packets and m17_diag
+    equal the oracle's over the whole stream, with every run's records fetched only after the NEXT run was queued."""
+    import torch
+    Cn, T, n = 48, 28800, 6
+    xs = [_signals(16, n * T, seed=141, sigma=600.0, kind=0), _signals(16, n * T, seed=142, sigma=600.0, kind=1),
+          _signals(16, n * T, seed=143, sigma=500.0, kind=4, n_frames=20)]
+    x = np.concatenate(xs)
+    exp, diags = _oracle(x)
+    c = m17hip.Context(Cn, T)
+    c.tune(6, 1); c.tune(7, 256)
+    assert c.lib.m17hip_frames_select(c.h, C.c_uint32(1)) == ESTATE      # no run yet
+    assert c.lib.m17hip_frames_select(c.h, C.c_uint32(2)) == EINVAL
+    pins = [torch.from_numpy(np.ascontiguousarray(x[:, k * T:(k + 1) * T])).pin_memory() for k in range(n)]
+    c.reset()
+    c.upload_async(pins[0].data_ptr(), Cn, T)
+    c.run(channels=Cn, samples=T)
+    assert c.lib.m17hip_frames_select(c.h, C.c_uint32(1)) == ESTATE      # one run: there is no run before it
+    parts, counts, pkts = [], [], []
+    for k in range(n):
+        if k + 1 < n:
+            c.upload_async(pins[k + 1].data_ptr(), Cn, T)
+            c.front(channels=Cn, samples=T)
+            c.run(channels=Cn, samples=T)
+            assert c.frames_count() >= 0                                  # (run k + 1's own count: selected by default)
+            latest = c.frames_count()
+            c.frames_select(1)
+        counts.append(c.frames_count())
+        parts.append(c.frames().copy())
+        pkts.append(c.packets().copy())                                   # the packets run k completed (the selected run's store)
+        assert parts[-1].size == counts[-1]
+        if k + 1 < n:
+            c.frames_select(0)
+            assert c.frames_count() == latest
+    c.upload_wait()
+    got = _sorted(parts)
+    assert got.tobytes() == exp.tobytes() and got.size > 4 * Cn
+    _check_diag(c, Cn, diags)
+    # the packets, run by run, are those of the same runs made strictly one after the other in a second context
+    d = m17hip.Context(Cn, T)
+    d.tune(7, 256)
+    d.reset()
+    npk = 0
+    for k in range(n):
+        d.upload(x[:, k * T:(k + 1) * T]); d.run()
+        one = d.packets()
+        assert one.tobytes() == pkts[k].tobytes(), k
+        npk += one.size
+    assert npk >= 16      # every packet channel completed its packet somewhere in the stream
+    d.close()
+    # the consumers worked run by run on their own run's records: PRBS9 statistics == the oracle's receiver over the oracle's BERT frames
+    st = c.bert_stats(Cn)
+    for ch in range(16):
+        r = exp[exp["channel"] == ch]
+        bert = r[r["frame_type"] == 5]
+        bits, errs, sync = ol.bert_count(bert["payload"][:, :25]) if bert.size else (0, 0, False)
+        assert (int(st["bits"][ch]), int(st["errors"][ch]), bool(st["synced"][ch]), int(st["frames"][ch])) == (bits, errs, sync, bert.size), ch
+    # after a reset nothing of the old stream can be selected
+    c.reset()
+    assert c.lib.m17hip_frames_select(c.h, C.c_uint32(0)) == ESTATE and c.lib.m17hip_frames_select(c.h, C.c_uint32(1)) == ESTATE
+    got0 = C.c_uint64(0)
+    assert c.lib.m17hip_frames_count(c.h, C.byref(got0)) == ESTATE
+    c.close()
+
+
+def test_gather_names_the_selected_run():
+    """m17hip_gather_frames after m17hip_frames_select(ctx, 1): the records of the run BEFORE the latest travel (one-rank communicator)."""
+    Cn, T = 12, 24000
+    x = _signals(Cn, 2 * T, seed=151)
+    c = m17hip.Context(Cn, T)
+    comm = m17hip.Comm(c, m17hip.comm_get_id(), 0, 1)
+    c.reset()
+    c.upload(x[:, :T]); c.run()
+    first = c.frames().copy()
+    c.upload(x[:, T:]); c.run()
+    second = c.frames().copy()
+    assert first.size and second.size and first.tobytes() != second.tobytes()
+    recs, counts = c.gather_frames(comm, root=0)
+    assert recs.tobytes() == second.tobytes()
+    c.frames_select(1)
+    recs, counts = c.gather_frames(comm, root=0)
+    assert recs.tobytes() == first.tobytes() and counts.tolist() == [first.size]
+    comm.close(); c.close()

@@ -3,12 +3,13 @@ in front of every context (argv[1], default 0) — for rocprofv3 traces of the g
     rocprofv3 --kernel-trace -d out -o t -- python3 tools/stream_only.py 3;  python3 tools/rocpd_step.py out/t_results.db"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch
 sys.path.insert(0, os.path.join(ROOT, 'm17-cxx-demod_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import m17hip, oracle_lib as ol
 m17hip.Context._warned = True
 nph = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ORDER = os.environ.get('ORDER', 'new')
 pre = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # streams created before anything else (shifts every later index)
 torch.zeros(1, device='cuda')
 hip = ctypes.CDLL([l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l][0])
@@ -29,9 +30,13 @@ def stream(n):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(n):
         for c in gs: c.input_alternate(Cg, T); c.front()
-        for c in gs: c.frames_count(); c.run()
+        if ORDER == 'new':     # run k + 1's chain queued before run k's records are collected (m17hip_frames_select)
+            for c in gs: c.run()
+            for c in gs: c.frames_select(1); c.frames_count(); c.frames_select(0)
+        else:
+            for c in gs: c.frames_count(); c.run()
     for c in gs: c.frames_count()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) * 1e3 / n
 stream(8)
-print('placeholders %d pre %d: single-stream ms/step %.2f %.2f' % (nph, pre, stream(12), stream(12)), flush=True)
+print('placeholders %d pre %d order %s: single-stream ms/step %.2f %.2f' % (nph, pre, ORDER, stream(12), stream(12)), flush=True)
