@@ -161,7 +161,11 @@ struct m17hip_ctx {
     bool defer_decode = true;
     // the running EVM folded outside K5, one lane per channel (m17_state.hpp, evm_fold_pass; tune 17)
     bool defer_evm = true;
-    float* ev_ops = nullptr;         // [maxC][ev_pitch] operations of the current run (lazily allocated)
+    float* ev_ops2[2] = {nullptr, nullptr};   // [maxC][ev_pitch] operations of a run (lazily allocated); the second one where a run begins while the last fold pass of the run before is still to come
+    int ev_par = 0;                  // the buffer of the current / latest run
+    const float* fold_ops = nullptr; // what the pending last fold pass works on: the run's buffer, its channels, its end-of-run cursors
+    uint32_t fold_C = 0;
+    const uint32_t* fold_end = nullptr;
     uint32_t ev_pitch = 0;
     uint32_t ev_pitch_override = 0;  // tuning knob 18 (tests): floats per operation row instead of ev_row_floats(maxT)
     uint32_t* ev_cur = nullptr;      // [3][maxC] K5's operation cursor at the end of a segment, by segment parity; [2]: at the end of the run's LAST segment
@@ -765,7 +769,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     ALLOC(c->dcd_state, C * sizeof(DcdState));
     ALLOC(c->seq_state, C * sizeof(SeqState));
     ALLOC(c->ev_state, C * sizeof(EvState));
-    ALLOC(c->ev_cur, 3 * C * sizeof(uint32_t));
+    ALLOC(c->ev_cur, 4 * C * sizeof(uint32_t));   // [0], [1]: by segment parity; [2], [3]: at the end of a run, by the run's buffer
     ALLOC(c->sets[0].recs, C * c->rec_cap * sizeof(FrameRec));      // (the second set: with the second run, ensure_set)
     ALLOC(c->sets[0].rec_count, C * sizeof(uint32_t));
     ALLOC(c->rec_offsets, (C + 1) * sizeof(uint64_t));
@@ -859,7 +863,7 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     void* ptrs[] = {c->xbuf, c->ybuf, c->dcd_table, c->dcd_state, c->seq_state, c->sets[0].recs, c->sets[0].rec_count, c->sets[0].defer_llr,
                     c->sets[1].recs, c->sets[1].rec_count, c->sets[1].defer_llr, c->rec_offsets,
                     c->overflow, c->tables, c->taps, c->taps_skew, c->llr_edges, c->level_gain, c->compact, c->scratch, c->dbg, c->hbuf, c->final_h, c->gate_exp, c->dropped, c->bert_state, c->xstage, c->pkt_state, c->pkt_recs2[0], c->pkt_recs2[1], c->pkt_count2, c->diag_log, c->diag_count, c->defer_hist,
-                    c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->bnd, c->ev_ops, c->ev_cur, c->ev_state, c->truth, c->first_needed};
+                    c->yalt, c->halt, c->dcd_alt, c->synth_scratch, c->bnd, c->ev_ops2[0], c->ev_ops2[1], c->ev_cur, c->ev_state, c->truth, c->first_needed};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);   // (the context is going away: nothing to report to)
     delete c;
@@ -1365,13 +1369,15 @@ static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStre
     G.taps = c->taps; G.C = C; G.T = len; G.pos0 = c->pos + t0; G.tick_row0 = c->pos / TICK; G.flags = flags | ((redo && !redo_stores) ? 2u : 0u);
     G.nblk = (C + GT_CPW - 1) / GT_CPW;
     uint32_t fold_blocks = 0;
-    if (ahead && k >= 2 && c->defer_evm && c->ev_ops) {   // (K5 of segment k - 2 is through: its EVM operations ride along, sixteen channels per block)
-        G.ev = EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, C, c->ev_cur + (size_t)((k - 2u) & 1u) * c->maxC, 0u};
+    if (ahead && k >= 2 && c->defer_evm && c->ev_ops2[c->ev_par]) {   // (K5 of segment k - 2 is through: its EVM operations ride along, sixteen channels per block)
+        G.ev = EvParams{c->ev_ops2[c->ev_par], c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, C, c->ev_cur + (size_t)((k - 2u) & 1u) * c->maxC, 0u};
         fold_blocks = ev_fold_blocks(C);
     }
-    if (k == 0 && !redo && c->fold_pending && c->ev_ops) {   // the LAST pass of the run before: K5 of this run's first segment waits for this launch anyway
-        G.ev = EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, c->lastC, c->ev_cur + 2 * (size_t)c->maxC, 1u};
-        fold_blocks = ev_fold_blocks(c->lastC);
+    // The LAST pass of the run before (its buffer is not this run's): beside K5 of this run's first segment, with the replay that runs ahead for the
+    // second one — or, for a run of one segment, with this replay, which K5 waits for (that K5 is the one that moves the end-of-run cursors on)
+    if (!redo && c->fold_pending && c->fold_ops && ((sp.nseg >= 2 && ahead && k == 1) || (sp.nseg < 2 && k == 0))) {
+        G.ev = EvParams{c->fold_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, c->fold_C, c->fold_end, 1u};
+        fold_blocks = ev_fold_blocks(c->fold_C);
         c->fold_pending = false;
     }
     hipLaunchKernelGGL(limit_track_kernel, dim3(G.nblk + fold_blocks), dim3(64), GT_LDS_FLOATS * sizeof(float), st, G);
@@ -1435,9 +1441,9 @@ static int flush_fold(m17hip_ctx* c)
 {
     if (!c->fold_pending) return M17HIP_OK;
     c->fold_pending = false;
-    if (!c->ev_ops) return M17HIP_OK;
-    hipLaunchKernelGGL(evm_deferred_kernel, dim3(ev_fold_blocks(c->lastC)), dim3(64), 0, c->stream,
-                       EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, c->lastC, c->ev_cur + 2 * (size_t)c->maxC, 1u});
+    if (!c->fold_ops) return M17HIP_OK;
+    hipLaunchKernelGGL(evm_deferred_kernel, dim3(ev_fold_blocks(c->fold_C)), dim3(64), 0, c->stream,
+                       EvParams{c->fold_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, c->fold_C, c->fold_end, 1u});
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
@@ -1464,8 +1470,8 @@ static int flush_payload(m17hip_ctx* c, bool selected_only = false, bool older_o
             D.state = c->seq_state; D.diag_log = c->diag_cap ? c->diag_log : nullptr; D.diag_cap = c->diag_cap; D.diag_count = c->diag_count; D.C = C;
             D.ev = EvParams{nullptr, 0, nullptr, nullptr, 0, nullptr, C, nullptr, 0u};
             uint32_t fold_blocks = 0;
-            if (c->fold_with_decode && c->fold_pending && i == c->cur && c->ev_ops) {   // (the latest run's last fold pass, beside its decode on the main stream)
-                D.ev = EvParams{c->ev_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, C, c->ev_cur + 2 * (size_t)c->maxC, 1u};
+            if (c->fold_with_decode && c->fold_pending && i == c->cur && c->fold_ops) {   // (the latest run's last fold pass, beside its decode on the main stream)
+                D.ev = EvParams{c->fold_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, c->fold_C, c->fold_end, 1u};
                 fold_blocks = ev_fold_blocks(C);
                 c->fold_pending = false;
             }
@@ -1649,9 +1655,12 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipStreamWaitEvent(c->stream, rs.done, 0));
     }
     rs.valid = false;
-    if (c->defer_evm && !c->ev_ops) {   // the operation rows of the deferred EVM: 4 B per symbol of the longest run
-        c->ev_pitch = c->ev_pitch_override ? c->ev_pitch_override : ev_row_floats(c->maxT);
-        HIPCHK(c, hipMalloc((void**)&c->ev_ops, (size_t)c->maxC * c->ev_pitch * sizeof(float)));
+    if (c->defer_evm) {   // the operation rows of the deferred EVM: 4 B per symbol of the longest run
+        if (c->fold_pending) c->ev_par ^= 1;   // (the run before still has a fold pass to come: it keeps its rows, this run writes the other buffer)
+        if (!c->ev_ops2[c->ev_par]) {
+            c->ev_pitch = c->ev_pitch_override ? c->ev_pitch_override : ev_row_floats(c->maxT);
+            HIPCHK(c, hipMalloc((void**)&c->ev_ops2[c->ev_par], (size_t)c->maxC * c->ev_pitch * sizeof(float)));
+        }
     }
     c->dbg_waves = (c->profile || c->wave_times) ? C : 0;
     // K2 launches: the whole first segment from K5's state; every later segment AHEAD of K5 from the replay's own end state (replay
@@ -1698,7 +1707,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         P.level_gain = c->level_gain + (size_t)(c->kalman_order & 7u) * core::LEVEL_SCHED_N;
         P.diag_log = c->diag_cap ? c->diag_log : nullptr; P.diag_cap = c->diag_cap; P.diag_count = c->diag_count;
         P.defer = c->defer_decode ? rs.defer_llr : nullptr;
-        if (c->defer_evm) { P.ev_ops = c->ev_ops; P.ev_pitch = c->ev_pitch; P.ev_cursor_out = c->ev_cur + (size_t)(k + 1u == nseg ? 2u : (k & 1u)) * c->maxC; }
+        if (c->defer_evm) { P.ev_ops = c->ev_ops2[c->ev_par]; P.ev_pitch = c->ev_pitch; P.ev_cursor_out = c->ev_cur + (size_t)(k + 1u == nseg ? 2u + (uint32_t)c->ev_par : (k & 1u)) * c->maxC; }
         P.bnd_out = c->bnd + (size_t)((k + 1u) & 1u) * c->maxC;
         P.truth_out = c->truth ? c->truth + (size_t)(k & 1u) * c->maxC : nullptr;
         P.dbg = (c->profile || c->wave_times) ? c->dbg : nullptr;
@@ -1771,7 +1780,9 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         hipLaunchKernelGGL(settle_tail_kernel, dim3(C), dim3(64), SETTLE_LDS_BYTES, c->stream, S);
         HIPCHK(c, hipGetLastError());
     }
+    if (c->fold_pending && (r = flush_fold(c))) return r;   // (the run before: nothing of this run took its last pass along — one segment, no replay ahead)
     c->fold_pending = c->defer_evm;
+    c->fold_ops = c->ev_ops2[c->ev_par]; c->fold_C = C; c->fold_end = c->ev_cur + (2 + (size_t)c->ev_par) * c->maxC;
     HIPCHK(c, hipEventRecord(rs.chain, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_end[q], c->stream));
     { std::lock_guard<std::mutex> lk(g_runs.mu); c->last_end = c->ev_end[q]; }
@@ -2382,14 +2393,14 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
             c->defer_evm = value != 0;
             hipLaunchKernelGGL(ev_move_kernel, dim3((c->maxC + 63) / 64), dim3(64), 0, c->stream, c->seq_state, c->ev_state, c->maxC, c->defer_evm ? 1 : 0);
             HIPCHK(c, hipGetLastError());
-            if (!c->defer_evm && c->ev_ops) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_dev(c->ev_ops, &c->last_hip); }
+            if (!c->defer_evm) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_dev(c->ev_ops2[0], &c->last_hip); free_dev(c->ev_ops2[1], &c->last_hip); c->fold_ops = nullptr; }
         }
         return M17HIP_OK;
     case 18:  // (tests) floats per channel row of deferred EVM operations, 0 = what a run of max_samples can produce: a smaller value makes the overflow flag reachable
         if (value < 0 || value > (1 << 28) || (value & 3)) return M17HIP_EINVAL;
         if (int fr = flush_fold(c)) return fr;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        free_dev(c->ev_ops, &c->last_hip);
+        free_dev(c->ev_ops2[0], &c->last_hip); free_dev(c->ev_ops2[1], &c->last_hip); c->fold_ops = nullptr;
         c->ev_pitch_override = (uint32_t)value;
         return M17HIP_OK;
     case 15:  // payload frames of running stream / BERT transmissions decoded after the run, one lane per frame (1, default), or in K5 (0)
