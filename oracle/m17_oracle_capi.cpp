@@ -299,37 +299,7 @@ int m17o_decode_frame(int sync_type, const int8_t* llr368, uint8_t* state_io, ui
 static size_t run_channel(const int16_t* s, size_t n, int invert, uint32_t channel, m17o_frame_rec* recs, size_t cap,
                           m17o_diag* diag, float* sym_out, size_t sym_cap, size_t* n_sym)
 {
-    std::vector<FrameRecord> out;
-    auto d = std::make_unique<Demodulator>();
-    d->out = &out;
-    size_t ns = 0;
-    if (sym_out) d->on_symbol = [&](uint64_t, float sym, float) { if (ns < sym_cap) sym_out[ns] = sym; ns++; };
-    d->run(s, n, invert != 0);
-    size_t cnt = 0;
-    for (auto& f : out) {
-        if (cnt < cap) {
-            m17o_frame_rec& r = recs[cnt];
-            std::memset(&r, 0, sizeof(r));
-            r.channel = channel; r.seq = (uint32_t)cnt; r.sample_pos = f.sample_pos; r.cost = f.cost;
-            r.frame_type = f.frame_type; r.sync_type = f.sync_type; r.len = f.len;
-            std::memcpy(r.payload, f.data, 30);
-        }
-        cnt++;
-    }
-    if (diag) {
-        std::memset(diag, 0, sizeof(*diag));
-        const Diag& g = d->diag;
-        diag->dcd = g.dcd; diag->evm = g.evm; diag->deviation = g.deviation; diag->offset = g.offset;
-        diag->locked = g.locked; diag->clock = g.clock; diag->sample_index = g.sample_index;
-        diag->sync_index = g.sync_index; diag->clock_index = g.clock_index; diag->viterbi_cost = g.viterbi_cost;
-        diag->dcd_level = g.dcd_level; diag->n_diag = g.n_diag; diag->demod_state = (uint32_t)d->st;
-        diag->n_frames = (uint32_t)cnt;
-        // live counters at the end of the run (debugging aid; the HIP path fills the same words)
-        diag->pad[0] = (uint32_t)d->clock.count;
-        diag->pad[1] = ((uint32_t)d->sync_count & 0xFFFFu) | ((uint32_t)d->missing_sync_count << 16);
-    }
-    if (n_sym) *n_sym = ns;
-    return cnt;
+    return run_channel_t<Demodulator>(s, n, invert, channel, recs, cap, diag, sym_out, sym_cap, n_sym);
 }
 
 size_t m17o_demod(const int16_t* s, size_t n, int invert, m17o_frame_rec* recs, size_t cap, m17o_diag* diag)
@@ -346,24 +316,7 @@ size_t m17o_demod_symbols(const int16_t* s, size_t n, int invert, float* sym_out
 // n_frames at that moment, pad[0] | pad[1] << 32 = the sample that fired it).  Returns the number of callbacks.
 size_t m17o_demod_diag_log(const int16_t* s, size_t n, int invert, m17o_diag* log, size_t cap)
 {
-    std::vector<FrameRecord> out;
-    auto d = std::make_unique<Demodulator>();
-    d->out = &out;
-    size_t cnt = 0;
-    Demodulator* dp = d.get();
-    d->on_diag = [&](uint64_t pos, const Diag& g) {
-        if (cnt < cap) {
-            m17o_diag& o = log[cnt];
-            std::memset(&o, 0, sizeof(o));
-            o.dcd = g.dcd; o.evm = g.evm; o.deviation = g.deviation; o.offset = g.offset; o.locked = g.locked; o.clock = g.clock;
-            o.sample_index = g.sample_index; o.sync_index = g.sync_index; o.clock_index = g.clock_index; o.viterbi_cost = g.viterbi_cost;
-            o.dcd_level = g.dcd_level; o.n_diag = g.n_diag; o.demod_state = (uint32_t)dp->st; o.n_frames = (uint32_t)out.size();
-            o.pad[0] = (uint32_t)pos; o.pad[1] = (uint32_t)(pos >> 32);
-        }
-        ++cnt;
-    };
-    d->run(s, n, invert != 0);
-    return cnt;
+    return diag_log_t<Demodulator>(s, n, invert, log, cap);
 }
 
 // Batch: samples[C][T] (row pitch = pitch samples); recs[C][cap]; counts[C]; diags[C].  `threads` host threads.

@@ -15,6 +15,7 @@
 #include "m17_oracle_fec.hpp"
 
 #include <functional>
+#include <memory>
 #include <vector>
 
 namespace m17o {
@@ -38,25 +39,53 @@ struct Diag {  // arguments of the last diagnostic callback (M17Demodulator.h:68
     uint32_t n_diag;   // number of diagnostic callbacks so far
 };
 
-struct Demodulator {
+// The operators the orchestrator is made of, as a policy: OracleOps = this directory's restatements (the oracle proper).
+// oracle/ref_shim.cpp instantiates the SAME orchestrator over the REFERENCE's own operator classes (BaseFirFilter, Correlator,
+// SyncWord, DataCarrierDetect, SymbolEvm, llr, M17Framer, M17FrameDecoder — compiled from the reference's headers where they lie)
+// to pin their composition: only ClockRecovery / FreqDevEstimator (KalmanFilter.h -> blaze, absent) stay the oracle's there.
+struct OracleOps {
+    using Fir = Fir150;
+    using Carrier = Dcd;
+    using Evm = SymbolEvm;
+    using Corr = Correlator;
+    using Sync = SyncWord;
+    template <typename Sink> using Decoder = FrameDecoder<Sink>;
+    struct Framer {  // llr<float,4> (Util.h:128-145) + M17Framer<368> (M17Framer.h:42-53): the completed frame, or nullptr
+        int8_t buf[368];
+        size_t idx = 0;
+        Framer() { reset(); }
+        void reset() { std::memset(buf, 0, 368); idx = 0; }
+        const int8_t* push(float sample)
+        {
+            int8_t a, b;
+            llr_table().lookup(sample, a, b);
+            buf[idx++] = a;
+            buf[idx++] = b;
+            if (idx == 368) { idx = 0; return buf; }
+            return nullptr;
+        }
+    };
+};
+
+template <typename Ops>
+struct DemodulatorT {
     enum class St : uint8_t { UNLOCKED, LSF_SYNC, STREAM_SYNC, PACKET_SYNC, BERT_SYNC, SYNC_WAIT, FRAME };
     static constexpr size_t STREAM_COST_LIMIT = 80, PACKET_COST_LIMIT = 60;
     static constexpr int MAX_MISSING_SYNC = 10, MIN_SYNC_COUNT = 78, MAX_SYNC_COUNT = 86;
 
-    Fir150 fir;
-    Dcd dcd;
+    typename Ops::Fir fir;
+    typename Ops::Carrier dcd;
     ClockRecovery clock;
-    SymbolEvm evm;
-    Correlator corr;
-    SyncWord preamble_sync{{+3, -3, +3, -3, +3, -3, +3, -3}, 29.f};
-    SyncWord lsf_sync{{+3, +3, +3, +3, -3, -3, +3, -3}, 31.f, -31.f};
-    SyncWord packet_sync{{3, -3, 3, 3, -3, -3, -3, -3}, 31.f, -31.f};
-    SyncWord eot_sync{{+3, +3, +3, +3, +3, +3, -3, +3}, 31.f};
+    typename Ops::Evm evm;
+    typename Ops::Corr corr;
+    typename Ops::Sync preamble_sync{{+3, -3, +3, -3, +3, -3, +3, -3}, 29.f};
+    typename Ops::Sync lsf_sync{{+3, +3, +3, +3, -3, -3, +3, -3}, 31.f, -31.f};
+    typename Ops::Sync packet_sync{{3, -3, 3, 3, -3, -3, -3, -3}, 31.f, -31.f};
+    typename Ops::Sync eot_sync{{+3, +3, +3, +3, +3, +3, -3, +3}, 31.f};
     FreqDevEstimator dev;
     size_t count_ = 0;
     int8_t polarity = 1;
-    int8_t framer[368];
-    size_t framer_idx = 0;
+    typename Ops::Framer framer;
     St st = St::UNLOCKED;
     SyncType sync_word_type = SyncType::LSF;
     uint8_t sample_index = 0;
@@ -72,7 +101,7 @@ struct Demodulator {
     Diag diag{};
 
     struct Sink {
-        Demodulator* d;
+        DemodulatorT* d;
         void operator()(const FrameOut& f) const
         {
             if (!d->out) return;
@@ -83,16 +112,16 @@ struct Demodulator {
             d->out->push_back(r);
         }
     };
-    FrameDecoder<Sink> decoder{Sink{this}};
+    typename Ops::template Decoder<Sink> decoder{Sink{this}};
 
     // optional taps for tests: called with (pos, filtered sample) / per symbol
     std::function<void(uint64_t, float, float)> on_symbol;  // pos, normalised symbol, raw filtered
     std::function<void(uint64_t, const Diag&)> on_diag;     // every diagnostic callback: sample position, arguments
 
-    Demodulator() { std::memset(framer, 0, 368); }
-    Demodulator(const Demodulator&) = delete;
+    DemodulatorT() {}
+    DemodulatorT(const DemodulatorT&) = delete;
 
-    void framer_reset() { std::memset(framer, 0, 368); framer_idx = 0; }
+    void framer_reset() { framer.reset(); }
 
     void update_values(uint8_t index)  // :233-241
     {
@@ -259,15 +288,10 @@ struct Demodulator {
         sample = sample * (float)polarity;
         evm.update(sample);
         if (on_symbol) on_symbol(pos, sample, filtered);
-        int8_t a, b;
-        llr_table().lookup(sample, a, b);
-        framer[framer_idx++] = a;
-        framer[framer_idx++] = b;
-        if (framer_idx == 368) {
-            framer_idx = 0;
+        if (const int8_t* frame = framer.push(sample)) {   // llr<FloatType,4>(sample) + framer(n, &tmp), :617-619
             sync_count = 0;
             int8_t buffer[368];
-            std::memcpy(buffer, framer, 368);
+            std::memcpy(buffer, frame, 368);
             decoder.run(sync_word_type, buffer, viterbi_cost);
             switch (decoder.state()) {
             case DecState::STREAM: st = St::STREAM_SYNC; break;
@@ -333,5 +357,71 @@ struct Demodulator {
         for (size_t i = 0; i < n; ++i) { step(scale_sample(s[i], invert)); pos++; }
     }
 };
+using Demodulator = DemodulatorT<OracleOps>;
+
+// One channel through a demodulator of type D: frame records (Rec: the 64-byte record of the C APIs), the last diagnostic callback
+// (DiagOut: their 64-byte diagnostic record), optionally the normalised symbols.  Shared by oracle/m17_oracle_capi.cpp (D = Demodulator)
+// and oracle/ref_shim.cpp (D = the orchestrator over the reference's operators).
+template <typename D, typename Rec, typename DiagOut>
+inline size_t run_channel_t(const int16_t* s, size_t n, int invert, uint32_t channel, Rec* recs, size_t cap, DiagOut* diag, float* sym_out, size_t sym_cap,
+                            size_t* n_sym)
+{
+    std::vector<FrameRecord> out;
+    auto d = std::make_unique<D>();
+    d->out = &out;
+    size_t ns = 0;
+    if (sym_out) d->on_symbol = [&](uint64_t, float sym, float) { if (ns < sym_cap) sym_out[ns] = sym; ns++; };
+    d->run(s, n, invert != 0);
+    size_t cnt = 0;
+    for (auto& f : out) {
+        if (cnt < cap) {
+            Rec& r = recs[cnt];
+            std::memset(&r, 0, sizeof(r));
+            r.channel = channel; r.seq = (uint32_t)cnt; r.sample_pos = f.sample_pos; r.cost = f.cost;
+            r.frame_type = f.frame_type; r.sync_type = f.sync_type; r.len = f.len;
+            std::memcpy(r.payload, f.data, 30);
+        }
+        cnt++;
+    }
+    if (diag) {
+        std::memset(diag, 0, sizeof(*diag));
+        const Diag& g = d->diag;
+        diag->dcd = g.dcd; diag->evm = g.evm; diag->deviation = g.deviation; diag->offset = g.offset;
+        diag->locked = g.locked; diag->clock = g.clock; diag->sample_index = g.sample_index;
+        diag->sync_index = g.sync_index; diag->clock_index = g.clock_index; diag->viterbi_cost = g.viterbi_cost;
+        diag->dcd_level = g.dcd_level; diag->n_diag = g.n_diag; diag->demod_state = (uint32_t)d->st;
+        diag->n_frames = (uint32_t)cnt;
+        // live counters at the end of the run (debugging aid; the HIP path fills the same words)
+        diag->pad[0] = (uint32_t)d->clock.count;
+        diag->pad[1] = ((uint32_t)d->sync_count & 0xFFFFu) | ((uint32_t)d->missing_sync_count << 16);
+    }
+    if (n_sym) *n_sym = ns;
+    return cnt;
+}
+
+// Every diagnostic callback of one channel, in order (same layout as the log entries of m17hip_diag_log_fetch: demod_state and
+// n_frames at that moment, pad[0] | pad[1] << 32 = the sample that fired it).  Returns the number of callbacks.
+template <typename D, typename DiagOut>
+inline size_t diag_log_t(const int16_t* s, size_t n, int invert, DiagOut* log, size_t cap)
+{
+    std::vector<FrameRecord> out;
+    auto d = std::make_unique<D>();
+    d->out = &out;
+    size_t cnt = 0;
+    D* dp = d.get();
+    d->on_diag = [&](uint64_t pos, const Diag& g) {
+        if (cnt < cap) {
+            DiagOut& o = log[cnt];
+            std::memset(&o, 0, sizeof(o));
+            o.dcd = g.dcd; o.evm = g.evm; o.deviation = g.deviation; o.offset = g.offset; o.locked = g.locked; o.clock = g.clock;
+            o.sample_index = g.sample_index; o.sync_index = g.sync_index; o.clock_index = g.clock_index; o.viterbi_cost = g.viterbi_cost;
+            o.dcd_level = g.dcd_level; o.n_diag = g.n_diag; o.demod_state = (uint32_t)dp->st; o.n_frames = (uint32_t)out.size();
+            o.pad[0] = (uint32_t)pos; o.pad[1] = (uint32_t)(pos >> 32);
+        }
+        ++cnt;
+    };
+    d->run(s, n, invert != 0);
+    return cnt;
+}
 
 }  // namespace m17o

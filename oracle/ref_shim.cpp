@@ -36,6 +36,9 @@
 #include <type_traits>
 #include <vector>
 
+// the oracle's orchestrator (namespace m17o), for ref_hybrid_demod below: its state machine over THIS file's reference operators
+#include "m17_oracle_demod.hpp"
+
 bool display_lsf = false;  // M17FrameDecoder.h:19 declares it extern
 
 static_assert(std::is_same<decltype(abs(1.0f)), float>::value, "abs(float) must be the float overload (Q5)");
@@ -293,6 +296,147 @@ int ref_decode_frame(int sync_type, const int8_t* llr368, uint8_t* state_io, uin
     int n = 0;
     for (auto& r : outs) recs[n++] = r;
     return n;
+}
+
+}  // extern "C"
+
+// ---- the composition pin ------------------------------------------------------------------------------------------------
+// M17Demodulator.h cannot be compiled here (it includes KalmanFilter.h -> blaze, absent), so what vouches for the orchestrator is
+// reading.  What CAN be pinned is everything the orchestrator is made of and how the pieces are wired: the oracle's state machine
+// (m17o::DemodulatorT) instantiated over the REFERENCE's own operator objects — BaseFirFilter<float,150>, Correlator<float>,
+// SyncWord<Correlator<float>>, DataCarrierDetect<float,48000,400>{2400, 3600, 0.1, 4.0}, SymbolEvm<float>, llr<float,4>,
+// M17Framer<368>, M17FrameDecoder (M17Demodulator.h:148-164), each placement-new'ed into zero-filled storage (Q4) — with only
+// ClockRecovery and FreqDevEstimator (the two blaze users) from the oracle.  tests/test_oracle_vs_ref.py: hybrid == pure oracle,
+// record for record and diagnostic for diagnostic.  What then remains unpinned is the state machine's own 330 lines and the
+// 2 x 2 Kalman arithmetic.
+namespace {
+
+std::array<float, 150> g_hybrid_taps;   // (set by the entry points before an orchestrator is constructed: detail::Taps lives in M17Demodulator.h)
+
+struct RefOps {
+    struct Fir {
+        Zeroed<BaseFirFilter<float, 150>> z;
+        BaseFirFilter<float, 150>* f;
+        Fir() : f(&z.make(g_hybrid_taps)) {}
+        float step(float x) { return (*f)(x); }
+    };
+    struct Carrier {
+        using T = DataCarrierDetect<float, 48000, 400>;
+        Zeroed<T> z;
+        T* p;
+        Carrier() : p(&z.make(2400, 3600, 0.1, 4.0)) {}
+        void step(float s) { (*p)(s); }
+        bool dcd() const { return p->dcd(); }
+        float level() const { return p->level(); }
+        void update() { p->update(); }
+        void unlock() { p->unlock(); }
+    };
+    struct Evm {
+        Zeroed<SymbolEvm<float>> z;
+        SymbolEvm<float>* p;
+        Evm() : p(&z.make()) {}
+        void reset() { p->reset(); }
+        void update(float s) { p->update(s); }
+        float evm() const { return p->evm(); }
+    };
+    struct Corr {
+        Zeroed<Correlator<float>> z;
+        Correlator<float>* p;
+        Corr() : p(&z.make()) {}
+        void sample(float v) { p->sample(v); }
+        size_t index() const { return p->index(); }
+        float limit() const { return p->limit(); }
+        void outer_symbol_levels(size_t si, float& mn, float& mx) const
+        {
+            auto r = p->outer_symbol_levels(si);
+            mn = std::get<0>(r); mx = std::get<1>(r);
+        }
+    };
+    struct Sync {
+        using T = SyncWord<Correlator<float>>;
+        Zeroed<T> z;
+        T* p;
+        Sync(std::initializer_list<int> w, float m1, float m2 = std::numeric_limits<float>::lowest())
+        {
+            T::buffer_t b;
+            int i = 0;
+            for (int v : w) b[i++] = (int8_t)v;
+            p = &z.make(std::move(b), m1, m2);
+        }
+        float triggered(const Corr& c) { return p->triggered(*c.p); }
+        size_t step(const Corr& c) { return (*p)(*c.p); }
+        int8_t updated() { return p->updated(); }
+    };
+    struct Framer {
+        Zeroed<M17Framer<368>> z;
+        M17Framer<368>* p;
+        Framer() : p(&z.make()) {}
+        void reset() { p->reset(); }
+        const int8_t* push(float sample)
+        {
+            auto n = llr<float, 4>(sample);
+            int8_t* tmp = nullptr;
+            const size_t len = (*p)(n, &tmp);
+            return len ? tmp : nullptr;
+        }
+    };
+    template <typename Sink>
+    struct Decoder {
+        Zeroed<M17FrameDecoder> z;
+        M17FrameDecoder* p;
+        Sink sink;
+        explicit Decoder(Sink s) : sink(s)
+        {
+            p = &z.make([this](const M17FrameDecoder::output_buffer_t& ob, int cost) {
+                m17o::FrameOut f;
+                std::memset(&f, 0, sizeof(f));
+                f.cost = cost; f.type = (m17o::FrameType)ob.type;
+                switch (ob.type) {
+                case M17FrameDecoder::FrameType::LSF: f.len = 30; std::memcpy(f.data, ob.lsf.data(), 30); break;
+                case M17FrameDecoder::FrameType::LICH: f.len = 6; std::memcpy(f.data, ob.lich.data(), 6); break;
+                case M17FrameDecoder::FrameType::STREAM: f.len = 18; std::memcpy(f.data, ob.stream.data(), 18); break;
+                case M17FrameDecoder::FrameType::BERT: f.len = 25; std::memcpy(f.data, ob.bert.data(), 25); break;
+                default: f.len = 26; std::memcpy(f.data, ob.packet.data(), 26); break;
+                }
+                sink(f);
+                return true;
+            });
+        }
+        void reset() { p->reset(); }
+        m17o::DecState state() const { return (m17o::DecState)p->state(); }
+        void run(m17o::SyncType t, int8_t* buffer, size_t& cost)
+        {
+            M17FrameDecoder::input_buffer_t b;
+            std::memcpy(b.data(), buffer, 368);
+            (*p)((M17FrameDecoder::SyncWordType)t, b, cost);
+        }
+    };
+};
+static_assert((int)M17FrameDecoder::State::BERT == (int)m17o::DecState::BERT && (int)M17FrameDecoder::SyncWordType::BERT == (int)m17o::SyncType::BERT &&
+              (int)M17FrameDecoder::FrameType::BERT == (int)m17o::FrameType::BERT, "enumerations in the reference's order");
+
+using HybridDemodulator = m17o::DemodulatorT<RefOps>;
+
+struct ref_diag {   // (= m17_diag / m17o_diag)
+    int32_t dcd; float evm, deviation, offset; int32_t locked; float clock; int32_t sample_index, sync_index, clock_index, viterbi_cost;
+    float dcd_level; uint32_t n_diag, demod_state, n_frames, pad[2];
+};
+static_assert(sizeof(ref_diag) == 64 && sizeof(ref_frame_rec) == 64, "record layouts");
+
+}  // namespace
+
+extern "C" {
+
+size_t ref_hybrid_demod(const float* taps150, const int16_t* s, size_t n, int invert, ref_frame_rec* recs, size_t cap, ref_diag* diag)
+{
+    std::memcpy(g_hybrid_taps.data(), taps150, sizeof(float) * 150);
+    return m17o::run_channel_t<HybridDemodulator>(s, n, invert, 0u, recs, cap, diag, (float*)nullptr, (size_t)0, (size_t*)nullptr);
+}
+
+size_t ref_hybrid_diag_log(const float* taps150, const int16_t* s, size_t n, int invert, ref_diag* log, size_t cap)
+{
+    std::memcpy(g_hybrid_taps.data(), taps150, sizeof(float) * 150);
+    return m17o::diag_log_t<HybridDemodulator>(s, n, invert, log, cap);
 }
 
 }  // extern "C"

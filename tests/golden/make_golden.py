@@ -6,6 +6,9 @@ code produced for them, plus the known-answer vectors held by the reference's un
 
   ref_vectors.npz   inputs -> outputs of the reference operators (via oracle/_ref)
   kat_vectors.json  literal vectors from reference tests/ViterbiTest.cpp, tests/UtilTest.cpp
+  hybrid_vectors.npz  what the reference's OWN operator objects deliver under the oracle's orchestrator (oracle/ref_shim.cpp,
+                    ref_hybrid_demod) for 48 scenarios of oracle_lib.random_scenario: frame records, last diagnostic callback, and a
+                    checksum of each input (`make_golden.py hybrid` writes this file alone)
 
 The input signals come from the repository's own synthetic generator (oracle/m17_oracle_gen.hpp).
 """
@@ -163,5 +166,27 @@ def main():
           os.path.getsize(os.path.join(HERE, "kat_vectors.json")), "bytes json")
 
 
+def hybrid():
+    """The composition pin, frozen: tests/test_oracle_kat.py compares the pure oracle with these wherever oracle/_ref is absent."""
+    import zlib
+    assert ol.ref() is not None, "oracle/_ref not built"
+    out = {"seeds": np.arange(48, dtype=np.int64), "total": np.int64(48000)}
+    recs, diags, sums, counts = [], [], [], []
+    for seed in out["seeds"]:
+        x = ol.random_scenario(int(seed), total=48000)
+        r, d = ol.hybrid_demod(x, invert=int(seed) & 1, taps150=ref_taps())
+        recs.append(r); diags.append(d); counts.append(r.size); sums.append(zlib.crc32(x.tobytes()))
+    out["records"] = np.concatenate(recs).view(np.uint8).reshape(-1, 64)
+    out["counts"] = np.array(counts, dtype=np.int64)
+    out["diags"] = np.array(diags).view(np.uint8).reshape(-1, 64)
+    out["input_crc32"] = np.array(sums, dtype=np.uint32)
+    np.savez_compressed(os.path.join(HERE, "hybrid_vectors.npz"), **out)
+    print("wrote hybrid_vectors.npz:", int(out["counts"].sum()), "records of", len(counts), "scenarios,", os.path.getsize(os.path.join(HERE, "hybrid_vectors.npz")), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "hybrid":
+        hybrid()
+    else:
+        main()
+        hybrid()

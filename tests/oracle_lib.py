@@ -168,6 +168,50 @@ def demod(samples, invert=0, cap=4096):
     return recs[:n].copy(), diag[0].copy()
 
 
+def hybrid_demod(samples, invert=0, cap=4096, taps150=None):
+    """The oracle's ORCHESTRATOR over the REFERENCE's own operator objects (oracle/ref_shim.cpp, ref_hybrid_demod): records and the last
+    diagnostic callback of one channel, laid out like demod()'s.  Needs oracle/_ref (the build container)."""
+    lib = ref()
+    lib.ref_hybrid_demod.restype = C.c_size_t
+    s = np.ascontiguousarray(samples, dtype=np.int16)
+    t = np.ascontiguousarray(taps() if taps150 is None else taps150, dtype=np.float32)
+    recs = np.zeros(cap, dtype=FRAME_REC)
+    diag = np.zeros(1, dtype=DIAG)
+    n = lib.ref_hybrid_demod(_p(t), _p(s), C.c_size_t(s.size), C.c_int(invert), _p(recs), C.c_size_t(cap), _p(diag))
+    assert n <= cap
+    return recs[:n].copy(), diag[0].copy()
+
+
+def hybrid_diag_log(samples, invert=0, cap=4096, taps150=None):
+    lib = ref()
+    lib.ref_hybrid_diag_log.restype = C.c_size_t
+    s = np.ascontiguousarray(samples, dtype=np.int16)
+    t = np.ascontiguousarray(taps() if taps150 is None else taps150, dtype=np.float32)
+    log = np.zeros(cap, dtype=DIAG)
+    n = lib.ref_hybrid_diag_log(_p(t), _p(s), C.c_size_t(s.size), C.c_int(invert), _p(log), C.c_size_t(cap))
+    assert n <= cap
+    return log[:n].copy()
+
+
+def random_scenario(seed, total=96000, kinds=(0, 1, 2, 3, 4)):
+    """One channel of tools/parity_sweep.py's scenario generator: bursts of random kind (BERT, voice-like stream, RAW packet, noise only, packet
+    closed by an FCS), length, lead-in, noise, DC offset, gain and symbol phase, back to back — lost sync, forced carrier-detect unlocks,
+    restarts of the gated matched filter, and (a silent stretch) the carrier detect's 0 / 0."""
+    rng = np.random.default_rng(seed)
+    x = np.zeros(total, dtype=np.int16)
+    pos = 0
+    while pos < total - 8000:
+        n = min(int(rng.integers(6000, 40000)), total - pos)
+        p = gen_params(seed=int(rng.integers(1, 1 << 30)), kind=int(rng.choice(kinds)), n_frames=int(rng.integers(1, 16)),
+                       lead_in=int(rng.integers(0, 5000)), lead_sigma=float(rng.choice([0.0, 100.0, 1000.0, 10000.0, 40000.0])),
+                       noise_sigma=float(rng.choice([0.0, 100.0, 500.0, 1200.0, 2500.0])), tail_sigma=float(rng.choice([0.0, 100.0, 1000.0, 5000.0])),
+                       dc_offset=float(rng.choice([0.0, 0.0, 300.0, -2000.0, 6000.0])), gain=float(rng.choice([1.0, 0.3, 0.7, 1.6])),
+                       phase=int(rng.integers(-1, 10)), invert=0, total=n)
+        x[pos:pos + n] = generate(p)[:n]
+        pos += n
+    return x
+
+
 def demod_batch(samples2d, invert=0, cap=600, threads=8):
     lib = oracle()
     s = np.ascontiguousarray(samples2d, dtype=np.int16)

@@ -468,3 +468,23 @@ def test_packet_with_fcs_end_to_end():
         assert out[0]["size"] == sent.size and out[0]["checksum"] == 0x0F47 and out[0]["frames"] == nf and out[0]["seq_errors"] == 0
         assert bytes(out[0]["data"][:sent.size]) == sent.tobytes()
     assert sent.size > 800
+
+
+def test_oracle_equals_the_frozen_output_of_the_references_operators_under_the_orchestrator():
+    """tests/golden/hybrid_vectors.npz (tests/golden/make_golden.py hybrid, build container): the frame records and the last diagnostic
+    callback that the REFERENCE's own operator objects deliver under the oracle's orchestrator (oracle/ref_shim.cpp ref_hybrid_demod) for
+    48 random scenarios.  The pure oracle must deliver the same — the frozen form of tests/test_oracle_vs_ref.py's live comparison, for
+    boxes without oracle/_ref."""
+    import os
+    import zlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hybrid_vectors.npz"))
+    off = 0
+    for i, seed in enumerate(g["seeds"]):
+        x = ol.random_scenario(int(seed), total=int(g["total"]))
+        assert zlib.crc32(x.tobytes()) == int(g["input_crc32"][i]), "the scenario generator changed: regenerate the fixture"
+        r, d = ol.demod(x, invert=int(seed) & 1)
+        n = int(g["counts"][i])
+        assert r.size == n and r.tobytes() == g["records"][off:off + n].tobytes(), seed
+        assert d.tobytes() == g["diags"][i].tobytes(), seed
+        off += n
+    assert off == g["records"].shape[0] and off > 200

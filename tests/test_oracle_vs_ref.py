@@ -116,3 +116,37 @@ def test_callsign_vs_reference():
         assert ol.decode_callsign(e) == ol.decode_callsign(e, lib=R, prefix="ref_")
     for call in ("N0CALL", "WX9O", "IU2KWO", "A", "AB1CDE-9", "K1/P.Q", "lower", ""):
         assert ol.encode_callsign(call) == ol.encode_callsign(call, lib=R, prefix="ref_")
+
+
+def test_the_orchestrator_over_the_references_own_operators_equals_the_oracle():
+    """M17Demodulator.h cannot be compiled here (blaze), but everything it is MADE of can — oracle/ref_shim.cpp instantiates the
+    oracle's state machine over the reference's BaseFirFilter, Correlator, SyncWord, DataCarrierDetect, SymbolEvm, llr, M17Framer and
+    M17FrameDecoder objects (zero-filled storage, only ClockRecovery / FreqDevEstimator from the oracle).  On 240 scenarios of the parity
+    sweep's generator (all five frame kinds back to back, lost sync, forced unlocks, either polarity) the hybrid and the pure oracle deliver the
+    same frame callbacks (3004 of them) and the same diagnostic callbacks, record for record and field for field — the composition is pinned; what reading
+    alone vouches for is the state machine's own 330 lines and the 2 x 2 Kalman arithmetic."""
+    frames = kinds = 0
+    for seed in range(240):
+        x = ol.random_scenario(seed)
+        inv = seed & 1
+        ro, do = ol.demod(x, invert=inv)
+        rh, dh = ol.hybrid_demod(x, invert=inv)
+        assert ro.tobytes() == rh.tobytes(), seed
+        assert do.tobytes() == dh.tobytes(), seed
+        if seed % 8 == 0:       # every diagnostic callback, in order
+            assert ol.demod_diag_log(x, invert=inv).tobytes() == ol.hybrid_diag_log(x, invert=inv).tobytes(), seed
+        frames += ro.size
+        kinds |= int(np.bitwise_or.reduce(1 << ro["frame_type"].astype(np.int64))) if ro.size else 0
+    assert frames > 2500, frames
+    assert kinds == 0b101111, bin(kinds)     # LSF, LICH, STREAM, BASIC packet and BERT callbacks all occurred (the generator makes no FULL packets)
+
+
+def test_the_hybrid_follows_the_carrier_detects_nan():
+    """SURVEY Q1 through the whole chain: silence first (0 / 0 in DataCarrierDetect::update: the level is NaN for ever), then a transmission —
+    the reference's own DataCarrierDetect under the orchestrator and the oracle agree that nothing is ever decoded."""
+    p = ol.gen_params(seed=5, kind=1, n_frames=6, lead_in=3072, noise_sigma=300.0, tail_sigma=300.0, lead_sigma=40000.0, total=30000)
+    x = np.concatenate([np.zeros(4000, np.int16), ol.generate(p)[:30000]])
+    ro, do = ol.demod(x)
+    rh, dh = ol.hybrid_demod(x)
+    assert ro.tobytes() == rh.tobytes() and do.tobytes() == dh.tobytes()
+    assert ro.size == 0 and np.isnan(do["dcd_level"])
