@@ -174,8 +174,8 @@ struct DeferParams {
     uint32_t C;
     EvParams ev;                  // the run's deferred EVM (m17_state.hpp): folded by the blocks behind the first C of the launch (ops == nullptr: none)
 };
-constexpr int DEFER_HIST_WORDS = 101;                                   // 201 trellis steps (BERT), two per word
-constexpr int DEFER_LDS_BYTES = (46 + 8) * 64 * 4 + 4 * 488 * 2;        // LLR nibbles, output bytes, source maps: 17.7 KB
+constexpr int DEFER_HIST_WORDS = 201;                                   // 201 trellis steps (BERT), one decision word per step
+constexpr int DEFER_LDS_BYTES = (46 + 8) * 64 * 4 + 4 * 488 * 2 + 512 * 2;   // LLR nibbles, output bytes, source maps, the list of deferred slots: 18.7 KB
 __global__ __launch_bounds__(64) void decode_deferred_kernel(DeferParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -187,6 +187,7 @@ __global__ __launch_bounds__(64) void decode_deferred_kernel(DeferParams P)
     L.llr = lds;                // [46][64] nibbles
     L.outb = lds + 46 * 64;     // [8][64]
     uint16_t* maps = reinterpret_cast<uint16_t*>(L.outb + 8 * 64);   // [4][488] source maps (every trellis step reads two entries)
+    uint16_t* list = maps + 4 * 488;    // [<= 512] the slots whose frames are deferred, in order
     L.lsf = nullptr;
     L.stride = 64;
     L.prof = nullptr;
@@ -201,15 +202,33 @@ __global__ __launch_bounds__(64) void decode_deferred_kernel(DeferParams P)
     if (c >= P.C) return;
     FrameRec* recs = P.recs + (size_t)c * P.rec_cap;
     const uint32_t n = min(P.rec_count[c], P.rec_cap);
-    for (uint32_t slot = lane; slot < n; slot += 64) {
-        uint32_t* w = reinterpret_cast<uint32_t*>(recs + slot);
-        if (!cost_is_deferred(w[4]) || w[15] != DEFER_MARK) continue;
-        const uint32_t* src = P.defer + ((size_t)c * P.rec_cap + slot) * 46;
-        for (int k = 0; k < 46; ++k) as_lds(L.llr)[k * 64 + lane] = src[k];
-        const int kind = kind_of_frame_type(w[5] & 0xFFu);
-        int stale = (int)w[14];
-        const uint32_t cost = viterbi_decode<true, true>(P.tables, L, lane, kind, stale);
-        complete_record(w, cost, L.outb, 64, lane, len_of_kind(kind));
+    for (uint32_t s0 = 0; s0 < n; s0 += 512) {   // (512 slots at a time: the list's room; a 10 s run has 508)
+        // the deferred slots as a dense list: a stream's records alternate LICH / payload — with a lane per SLOT half the lanes idled
+        const uint32_t s1 = min(n, s0 + 512u);
+        uint32_t nd = 0;
+        __syncthreads();
+        for (uint32_t base = s0; base < s1; base += 64) {
+            const uint32_t slot = base + lane;
+            bool d = false;
+            if (slot < s1) {
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(recs + slot);
+                d = cost_is_deferred(w[4]) && w[15] == DEFER_MARK;
+            }
+            const unsigned long long mask = __ballot(d);
+            if (d) list[nd + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)(slot - s0);
+            nd += (uint32_t)__popcll(mask);
+        }
+        __syncthreads();
+        for (uint32_t k0 = lane; k0 < nd; k0 += 64) {
+            const uint32_t slot = s0 + as_lds(list)[k0];
+            uint32_t* w = reinterpret_cast<uint32_t*>(recs + slot);
+            const uint32_t* src = P.defer + ((size_t)c * P.rec_cap + slot) * 46;
+            for (int k = 0; k < 46; ++k) as_lds(L.llr)[k * 64 + lane] = src[k];
+            const int kind = kind_of_frame_type(w[5] & 0xFFu);
+            int stale = (int)w[14];
+            const uint32_t cost = viterbi_decode_pk(L, lane, kind, stale);
+            complete_record(w, cost, L.outb, 64, lane, len_of_kind(kind));
+        }
     }
     __threadfence_block();
     __syncthreads();
