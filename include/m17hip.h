@@ -29,6 +29,7 @@ extern "C" {
 #define M17HIP_EOVERFLOW (-5) /* a per-channel frame-record buffer overflowed */
 #define M17HIP_ETRUNC (-6)   /* more results than the caller's capacity: *count says how many exist, `capacity` were written */
 #define M17HIP_ECOMM (-7)    /* an RCCL call failed (m17hip_gather_*) */
+#define M17HIP_ECONFIG (-8)  /* m17hip_ctx_create: the process runs with fewer than 8 hardware queues (GPU_MAX_HW_QUEUES; see m17hip_advice) */
 /* (-8 was M17HIP_ETIMEOUT of ABI 301's persistent kernel form, removed in ABI 400) */
 
 /* Frame-type / sync-type codes = the reference enums M17FrameDecoder.h:52-55. */
@@ -81,12 +82,17 @@ int m17hip_version(void);
 #define M17HIP_MAX_SAMPLES_PER_RUN 33553152u
 int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out);
 void m17hip_ctx_destroy(m17hip_ctx* ctx);
-/* Deployment advice (bit set; 0 = nothing to say).  Bit 0 (M17HIP_ADVICE_HW_QUEUES): the process runs with fewer than 8 hardware
- * queues (environment variable GPU_MAX_HW_QUEUES, read by the HIP runtime when it initialises; its default is 4).  A context uses
- * five streams (main, matched filter, carrier detect, limit-filter replay, copy); with streams sharing a hardware queue a kernel
- * queued behind another stream's event wait waits with it, and the overlap the streams exist for is lost (measured: two contexts
- * 42 instead of 26 ms per step).  Export GPU_MAX_HW_QUEUES=16 before the first HIP call of the process. */
+/* Hardware queues.  A context uses five streams (main, matched filter, carrier detect, limit-filter replay, copy); with streams
+ * sharing a hardware queue a kernel queued behind another stream's event wait waits with it, and the overlap the streams exist for
+ * is lost (measured: two contexts 42 instead of 26 ms per step).  The HIP runtime reads GPU_MAX_HW_QUEUES when it initialises (its
+ * default is 4): export GPU_MAX_HW_QUEUES=16 before the first HIP call of the process (the Python binding and the C++ host classes
+ * set it at load time when it is unset — effective when that is before the process's first contact with the GPU).
+ * The slow state is never entered silently: with the variable unset or below 8 m17hip_ctx_create returns M17HIP_ECONFIG, unless the
+ * host says it accepts that (environment variable M17HIP_FEW_HW_QUEUES_OK=1).
+ * m17hip_advice (bit set; 0 = nothing to say): bit 0 (M17HIP_ADVICE_HW_QUEUES) fewer than 8 queues were asked for, bit 1
+ * (M17HIP_ADVICE_HW_QUEUES_16) fewer than 16 — enough for one context, not for two batches in flight or a stream in two groups. */
 #define M17HIP_ADVICE_HW_QUEUES 1
+#define M17HIP_ADVICE_HW_QUEUES_16 2
 int m17hip_advice(const m17hip_ctx* ctx);
 /* Operational statistic: how many times since the last m17hip_demod_reset a channel left the limit-filter replay (the demodulator
  * forced dcd.unlock() after losing sync, M17Demodulator.h:396-404, 470-478: the one gate event the replay cannot foresee) and computed
@@ -352,7 +358,13 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  *        from it (a closed gate reopens only when an update finds level > 4.0: a function of the table and the off state alone) and K1 follows
  *        K5 of segment k - 2 instead of running ahead — on input that is idle most of the time 1.35 x the throughput, on always-on input 5 %
  *        less (K1 on the chain); 0 = never; -1 (default) = per run: on when more than a quarter of the channel-segments of the last FETCHED run
- *        ended with the carrier off.  Same results either way.
+ *        ended with the carrier off.  Same results either way.  NOTE: -1 consults the context's HISTORY (what the last fetched run looked like):
+ *        the schedule of a run, and with it its latency, depends on the runs before — never a result.  A host that needs the same latency
+ *        whatever came before pins 0 or 1.
+ * key 33: a RAMP of segment lengths at the start of a run: value, 2 x value, 4 x value, ... samples until key 3's length is reached (0, default:
+ *        none).  A channel that leaves the limit-filter replay in a segment carries the filter itself to the end of the NEXT one, and channels leave
+ *        it mostly while sync is being acquired: short first segments bound what that costs the launches concerned.  One batch at a time
+ *        24.6 -> 23.5 ms per 4096 x 480 000 with 9600; with batches in flight or a continued stream the extra launches cost as much (NOTES 6.4).
  * key 20: what happens after a forced dcd.unlock() took a channel off the limit-filter replay: 0 (default) = the replay's state is re-derived
  *        beside the sequential kernel and the channel computes its own filter history through the next segment (the sequential kernel never
  *        waits: best wherever its chain of launches is what a step lasts — a continued stream, one batch at a time); 1 = the replay of the next

@@ -112,6 +112,7 @@ struct m17hip_ctx {
     hipEvent_t last_end = nullptr;    // ev_end of the run queued last
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     uint32_t seg0_len = 0;            // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others; measured neutral)
+    uint32_t seg_ramp = 0;            // tuning knob 33: first segment of a ramp r, 2 r, 4 r, ... up to seg_len (0 = none)
     float* dcd_table = nullptr;
     DcdState* dcd_state = nullptr;
     SeqState* seq_state = nullptr;
@@ -716,21 +717,33 @@ const char* m17hip_strerror(int code)
     case M17HIP_EOVERFLOW: return "frame record buffer overflow";
     case M17HIP_ETRUNC: return "output truncated to the caller's capacity";
     case M17HIP_ECOMM: return "RCCL communication error";
+    case M17HIP_ECONFIG: return "GPU_MAX_HW_QUEUES is unset or below 8: a context's streams would share hardware queues and serialise (export GPU_MAX_HW_QUEUES=16 before the process's first HIP call, or M17HIP_FEW_HW_QUEUES_OK=1 to go on regardless)";
     default: return "unknown error";
     }
 }
 int m17hip_last_hip_error(const m17hip_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+static int hw_queues_env()   // what the process asked the HIP runtime for (the runtime's default is 4)
+{
+    const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+    return q ? std::atoi(q) : 4;
+}
 int m17hip_advice(const m17hip_ctx* ctx)
 {
     if (!ctx) return 0;
-    const char* q = std::getenv("GPU_MAX_HW_QUEUES");
-    return (!q || std::atoi(q) < 8) ? M17HIP_ADVICE_HW_QUEUES : 0;
+    const int n = hw_queues_env();
+    return (n < 8 ? M17HIP_ADVICE_HW_QUEUES : 0) | (n < 16 ? M17HIP_ADVICE_HW_QUEUES_16 : 0);
 }
 int m17hip_version(void) { return 600; }
 
 int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out)
 {
     if (!out || max_channels == 0 || max_samples == 0 || max_samples > M17HIP_MAX_SAMPLES_PER_RUN) return M17HIP_EINVAL;   // (argument checks: before any HIP call)
+    // The slow state is not entered silently: with the runtime's default of four hardware queues the five streams of a context share queues,
+    // a kernel queued behind another stream's event wait waits with it, and a step takes 1.4-1.6 x as long (NOTES 4.14, 5.3).
+    if (hw_queues_env() < 8) {
+        const char* ok = std::getenv("M17HIP_FEW_HW_QUEUES_OK");
+        if (!ok || std::atoi(ok) == 0) return M17HIP_ECONFIG;
+    }
     m17hip_ctx* c = new (std::nothrow) m17hip_ctx();
     if (!c) return M17HIP_ENOMEM;
     c->device = device;
@@ -1258,17 +1271,30 @@ int m17hip_demod_reset(m17hip_ctx* c)
 
 namespace {
 
-// How a run of T samples is cut into segments (tuning knobs 3, 4): segment k covers [t0(k), t0(k + 1)): a short first one (its front
-// end and K2 are all K5 has to wait for), then equal ones.
+// How a run of T samples is cut into segments (tuning knobs 3, 4, 33): segment k covers [t0(k), t0(k + 1)).  Equal ones of seg_len samples;
+// optionally a short first one (key 4), or a RAMP (key 33): segments of r, 2 r, 4 r, ... samples until seg_len is reached.  The ramp is for
+// where channels leave the limit-filter replay — at the start of a transmission, while sync is being acquired: a channel that leaves it in
+// segment k carries the filter itself to the end of segment k + 1, so what a drop costs the launches it falls into is twice the segment's length.
 struct SegPlan {
-    uint32_t T, seg_len, seg0, nseg;
+    uint32_t T, seg_len, nseg;
+    std::vector<uint32_t> b;   // b[k] = first sample of segment k; b[nseg] = T
     SegPlan(const m17hip_ctx* c, uint32_t T_) : T(T_)
     {
         seg_len = (!c->profile && c->seg_len) ? c->seg_len : T;
-        seg0 = (seg_len < T && c->seg0_len && c->seg0_len < seg_len) ? c->seg0_len : seg_len;
-        nseg = T <= seg0 ? 1u : 1u + (T - seg0 + seg_len - 1) / seg_len;
+        b.push_back(0);
+        uint32_t pos = 0;
+        if (seg_len < T && !c->profile) {
+            if (c->seg_ramp && c->seg_ramp < seg_len) {
+                for (uint32_t len = c->seg_ramp; len < seg_len && pos + len < T; len *= 2) { pos += len; b.push_back(pos); }
+            } else if (c->seg0_len && c->seg0_len < seg_len) {
+                pos = c->seg0_len; b.push_back(pos);
+            }
+        }
+        while (pos + seg_len < T) { pos += seg_len; b.push_back(pos); }
+        b.push_back(T);
+        nseg = (uint32_t)b.size() - 1u;
     }
-    uint32_t t0(uint32_t k) const { return k == 0 ? 0u : std::min(T, seg0 + (k - 1u) * seg_len); }
+    uint32_t t0(uint32_t k) const { return b[std::min<size_t>(k, nseg)]; }
 };
 
 static int ensure_seg_events(m17hip_ctx* c, int q, uint32_t nseg)
@@ -2430,6 +2456,10 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
     case 26:  // gate-aware front end: 1 = K1 of segment k >= 2 skips what the carrier cannot be on for, 0 = never, -1 (default) = per run from the previous run's share of closed gates
         if (value < -1 || value > 1) return M17HIP_EINVAL;
         c->gate_aware = (int)value;
+        return M17HIP_OK;
+    case 33:  // ramp of segment lengths at the start of a run: value, 2 x value, 4 x value, ... samples, then seg_len (0 = none)
+        if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
+        c->seg_ramp = (uint32_t)value;
         return M17HIP_OK;
     case 13:  // workgroups of K1's bounded grid (0 = default)
         if (value < 0 || value > (1 << 20)) return M17HIP_EINVAL;

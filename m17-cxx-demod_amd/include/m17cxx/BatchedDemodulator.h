@@ -37,7 +37,7 @@ public:
         static bool warned = false;
         if ((m17hip_advice(ctx_) & M17HIP_ADVICE_HW_QUEUES) && !warned) {
             warned = true;
-            std::fprintf(stderr, "m17hip: GPU_MAX_HW_QUEUES is unset or below 8: the context's streams will share hardware queues and serialise; "
+            std::fprintf(stderr, "m17hip: GPU_MAX_HW_QUEUES is below 8 (M17HIP_FEW_HW_QUEUES_OK was given): the context's streams will share hardware queues and serialise; "
                                  "export GPU_MAX_HW_QUEUES=16 before the process touches the GPU (include/m17hip.h)\n");
         }
     }

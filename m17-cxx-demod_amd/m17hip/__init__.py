@@ -9,6 +9,11 @@ import os
 
 import numpy as np
 
+# The HIP runtime reads GPU_MAX_HW_QUEUES when it initialises (a context's five streams must not share hardware queues: include/m17hip.h,
+# m17hip_advice): ask for 16 unless the host has decided otherwise.  Effective when this import comes before the process's first contact with
+# the GPU; m17hip_ctx_create refuses (M17HIP_ECONFIG) when fewer than 8 were asked for.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M17HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libm17hip.so")   # (M17HIP_LIB: an experiment build of the same library)
 
@@ -106,10 +111,10 @@ class Context:
         self._chk(self.lib.m17hip_ctx_create(C.c_int(device), C.c_uint32(max_channels), C.c_uint32(max_samples), C.byref(self.h)))
         if stream is not None:
             self.set_stream(stream)
-        if not Context._warned and self.lib.m17hip_advice(self.h) & 1:
+        if not Context._warned and self.lib.m17hip_advice(self.h) & 3:
             Context._warned = True
             import warnings
-            warnings.warn("m17hip: GPU_MAX_HW_QUEUES is unset or below 8 — the streams of a context (and of several contexts) will share "
+            warnings.warn("m17hip: fewer than 16 hardware queues were asked for (GPU_MAX_HW_QUEUES) — with several contexts the streams will share "
                           "hardware queues and serialise; export GPU_MAX_HW_QUEUES=16 before the process touches the GPU (include/m17hip.h)")
 
     def _chk(self, code):

@@ -79,3 +79,24 @@ def test_fake_rccl_exports_what_the_product_binds():
         for f in files:
             if f.endswith((".py", ".hip", ".hpp", ".h", "Makefile")):
                 assert "fake_rccl" not in open(os.path.join(dirpath, f), errors="ignore").read(), f
+
+
+def test_ctx_create_refuses_the_slow_state_unless_the_host_accepts_it():
+    """VERDICT r5 #7a: with the HIP runtime's default of four hardware queues a context's five streams share queues and a step takes 1.4-1.6 x as
+    long.  That state is not entered silently: m17hip_ctx_create returns M17HIP_ECONFIG (before any HIP call: no GPU needed here) unless
+    GPU_MAX_HW_QUEUES >= 8 or the host says M17HIP_FEW_HW_QUEUES_OK=1.  (A child process: the variable is this process's too.)"""
+    import subprocess, sys
+    code = r"""
+import ctypes as C, os, sys
+lib = C.CDLL(sys.argv[1])
+lib.m17hip_strerror.restype = C.c_char_p
+h = C.c_void_p()
+os.environ.pop("GPU_MAX_HW_QUEUES", None); os.environ.pop("M17HIP_FEW_HW_QUEUES_OK", None)
+r1 = lib.m17hip_ctx_create(C.c_int(0), C.c_uint32(4), C.c_uint32(1000), C.byref(h))
+os.environ["GPU_MAX_HW_QUEUES"] = "4"
+r2 = lib.m17hip_ctx_create(C.c_int(0), C.c_uint32(4), C.c_uint32(1000), C.byref(h))
+print(r1, r2, b"GPU_MAX_HW_QUEUES" in lib.m17hip_strerror(C.c_int(-8)))
+"""
+    import m17hip as m
+    r = subprocess.run([sys.executable, "-c", code, m.LIB_PATH], capture_output=True, text=True, timeout=120)
+    assert r.stdout.split() == ["-8", "-8", "True"], r.stdout + r.stderr
