@@ -384,7 +384,7 @@ class Bench:
                 total = self.finish(k - 1)
             return self.finish(n_steps - 1)
         for k0 in range(0, n_steps, F):   # groups of F steps queued together and waited for together: the batches go through the same
-            ks = range(k0, min(k0 + F, n_steps))   # phases side by side (round 2: 6 % faster than half a step apart, tools/regime_bench.py; round 5: 1.1-1.8 % slower, NOTES 5.12)
+            ks = range(k0, min(k0 + F, n_steps))   # phases side by side (round 2: 6 % faster than half a step apart; round 5: 1.1-1.8 % slower, NOTES 5.12)
             for k in ks:
                 self.launch(k)
             for k in ks:
