@@ -52,6 +52,7 @@ try:   # the two-batch regime of the default command with the probe beside it: t
     pts = [tuple(float(x) for x in l.split()) for l in lines if l and l[0] != '#' and len(l.split()) == 2]
     m = re.search(r'timed region: epoch ([0-9.]+) \.\. ([0-9.]+)', open(f'{d}/clock_probe_default.err').read())
     a, b = float(m.group(1)) - e0, float(m.group(2)) - e0          # the timed region on the probe's time axis (s)
+    pts = [(t, c) for t, c in pts if 300.0 < c < 4000.0]            # (a window in which the probe's wave was descheduled or a counter wrapped is not a clock)
     busy = [c for t, c in pts if a + 0.05 <= t / 1e3 <= b - 0.05]
     idle = [c for t, c in pts if t / 1e3 < a - 3.0]
     j['clock_in_mix'] = {'idle_mhz': sum(idle) / len(idle) if idle else None, 'busy_windows': len(busy), 'busy_mean_mhz': sum(busy) / len(busy) if busy else None,
