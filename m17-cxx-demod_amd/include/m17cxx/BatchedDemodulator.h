@@ -72,8 +72,12 @@ public:
         last_frames_ = got;
         return out;
     }
+    // Which run's records frames() / packets() name: 0 = the latest run (every run() selects it again), 1 = the run before it — what a live
+    // feed asks for after it has queued the next run (m17hip_frames_select).
+    void select(uint32_t back) { check(m17hip_frames_select(ctx_, back), "m17hip_frames_select"); }
     // Streaming (include/m17hip.h, m17hip_demod_front): stage the next run's input from pinned host memory while the current run
-    // computes, start its front end beside the current run's state-machine half, collect the current run's frames(), then run().
+    // computes, start its front end beside the current run's state-machine half, queue its run() behind the current one, then select(1) and
+    // collect the current run's frames() (or, as up to round 5: frames() first, then run()).
     void stage(const int16_t* pinned_host, uint32_t channels, uint32_t samples, size_t pitch)
     {
         check(m17hip_upload_i16_async(ctx_, pinned_host, channels, samples, pitch), "m17hip_upload_i16_async");
