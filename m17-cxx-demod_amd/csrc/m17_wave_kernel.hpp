@@ -73,72 +73,54 @@ typedef float m17_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ Hist3 nf_serve_limit(const float* yr, float* hr, M17_LDS float* B, uint32_t from, uint32_t to, float h0, float h1, float h2)
 {
     const uint32_t l = threadIdx.x & 63u;
-    // Both rows through buffer descriptors that end at `to`: a load beyond it returns 0, a store beyond it is dropped — four loads and four
+    // Both rows through buffer descriptors that end at `to`: a load beyond it returns 0, a store beyond it is dropped — three loads and three
     // stores per block on EVERY path, so that the wait for a block's samples can leave the previous block's stores in flight (with the
-    // bounds as branches the wait-count insertion could only wait for everything: a store round trip per 256 samples).
+    // bounds as branches the wait-count insertion could only wait for everything: a store round trip per block).
     const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc((void*)yr, 0, (int)(to * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t hdst = __builtin_amdgcn_make_buffer_rsrc((void*)hr, 0, (int)(to * 4u), 0x00020000);
-    float nx[4];
+    constexpr uint32_t BLK = TICK;   // one block = what iir_tick_in_place runs over (192 samples; B holds them + 16 bytes of padding + 32 readable)
+    float nx[3];
     auto load = [&](uint32_t b) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) nx[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ysrc, (int)((b + l + 64u * j) * 4u), 0, 0));
+        for (int j = 0; j < 3; ++j) nx[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ysrc, (int)((b + l + 64u * j) * 4u), 0, 0));
     };
     load(from);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(0, hdst, 0x7FFF0000 + 256 * j, 0, 0);   // (four dropped stores: the first block's wait sees what every later one sees)
-    for (uint32_t b = from; b < to; b += 256u) {
-        const uint32_t n = min(256u, to - b);
+    for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_buffer_store_b32(0, hdst, 0x7FFF0000 + 256 * j, 0, 0);   // (three dropped stores: the first block's wait sees what every later one sees)
+    for (uint32_t b = from; b < to; b += BLK) {
+        const uint32_t n = min(BLK, to - b);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) B[l + 64u * j] = nx[j];
+        for (int j = 0; j < 3; ++j) B[l + 64u * j] = nx[j];
         wave_lds_sync();
-        load(b + 256u);   // (beyond `to`: zeros, not used)
-        if (l < 16u) {   // the recurrence is one value per sample for the whole wave: sixteen lanes (uniform16, m17_state.hpp)
-            // (eight samples per pass, the next pass's two LDS reads issued before the recurrence: a wave that serves itself is what its
-            // launch waits for, and a read per four samples waited for on the spot was most of the loop.  The packed multiply (a1 h, a2 h)
-            // takes h from the lower or upper half of the register pair the outputs are collected in: written as `{h, h} * {a1, a2}` the
-            // compiler uses whatever register follows h's as the unused half — a register of the global loads in flight, whose latency
-            // the wait-count insertion then puts into the chain once per block.)
-            const M17_LDS m17_v4f* B4 = reinterpret_cast<const M17_LDS m17_v4f*>(B);
-            M17_LDS m17_v4f* O4 = reinterpret_cast<M17_LDS m17_v4f*>(B);
-            const iir_v2f coef = {IirCoef::a1, IirCoef::a2};
-            float m2 = IirCoef::a2 * h1;
-            iir_v2f p0 = {h2, h2}, p1 = {h1, h0};   // the last four history values; p1.y = the newest
-            auto lo = [&](iir_v2f p) { iir_v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(p), "s"(coef)); return r; };
-            auto hi = [&](iir_v2f p) { iir_v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(p), "s"(coef)); return r; };
-            auto four = [&](const m17_v4f v) {
-                iir_v2f r;
-                r = hi(p1); p0.x = (fabsf(v.x) - r.x) - m2; m2 = r.y;
-                r = lo(p0); p0.y = (fabsf(v.y) - r.x) - m2; m2 = r.y;
-                r = hi(p0); p1.x = (fabsf(v.z) - r.x) - m2; m2 = r.y;
-                r = lo(p1); p1.y = (fabsf(v.w) - r.x) - m2; m2 = r.y;
-                return m17_v4f{p0.x, p0.y, p1.x, p1.y};
-            };
-            m17_v4f c0 = B4[0], c1 = B4[1];
-            uint32_t i = 0;
-            for (; i + 8 <= n; i += 8) {
-                const m17_v4f v0 = c0, v1 = c1;
-                c0 = B4[min(i / 4u + 2u, 62u)];
-                c1 = B4[min(i / 4u + 3u, 63u)];
-                __builtin_amdgcn_sched_barrier(0);
-                O4[i / 4u] = four(v0);
-                O4[i / 4u + 1u] = four(v1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (i) { h0 = p1.y; h1 = p1.x; h2 = p0.y; }
-            for (; i < n; ++i) {
-                const float hn = iir_advance_pk(fabsf(B[i]), h0, m2);
-                h2 = h1; h1 = h0; h0 = hn;
-                B[i] = hn;
+        load(b + BLK);   // (beyond `to`: zeros, not used)
+        if (l == 0u) {
+            // The recurrence is one value per sample for the whole wave: ONE lane runs it.  A whole block as K2's tick does (m17_frontend_kernels.hpp,
+            // iir_tick_in_place: one asm statement, three instructions per sample, the samples replaced by their history values in their registers, the
+            // LDS reads two groups ahead, the writes left in flight) — a wave that serves itself is what its launch waits for (up to 2.2 ms of a launch
+            // whose median wave needs 0.45: gpurun_out/r6/wave_times_*.txt), and the compiler's form of this loop (eight samples per pass, waits for its
+            // own LDS writes) ran at 16 ns per sample alone and 33 in the crowd.
+            if (n == BLK) {
+                iir_tick_in_place((uint32_t)(uintptr_t)B, h0, h1, h2);
+            } else {
+                float m2 = IirCoef::a2 * h1;
+                for (uint32_t i = 0; i < n; ++i) {
+                    const float hn = iir_advance_pk(fabsf(B[i]), h0, m2);
+                    h2 = h1; h1 = h0; h0 = hn;
+                    B[i] = hn;
+                }
             }
         }
         wave_lds_sync();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, B[l + 64u * j]), hdst, (int)((b + l + 64u * j) * 4u), 0, 0);
+        for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, B[l + 64u * j]), hdst, (int)((b + l + 64u * j) * 4u), 0, 0);
         wave_lds_sync();
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the history values are read back by this wave (other lanes, later loads)
-    return Hist3{h0, h1, h2};
+    // (lane 0 holds the history: the caller's scalar registers take the first lane's values)
+    return Hist3{__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, h0))),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, h1))),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, h2)))};
 }
 
 // PROF: compile the 100 MHz section timers and counters in (diagnostics, tools/seq_ablate.py); the production
