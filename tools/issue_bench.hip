@@ -36,6 +36,9 @@
 #define WR64(V0, V1, OFF) "ds_write_b64 v41, v[" #V0 ":" #V0 "+1] offset:" #OFF "\n ds_write_b64 v41, v[" #V1 "-1:" #V1 "] offset:" #OFF "+8\n"
 #define WR2(V0, V1, OFF) "ds_write2_b64 v41, v[" #V0 ":" #V0 "+1], v[" #V1 "-1:" #V1 "] offset0:" #OFF "/8 offset1:" #OFF "/8+1\n"
 #define WAIT4 "s_waitcnt lgkmcnt(4)\n"
+// the outputs straight to GLOBAL memory from the chain's lanes (v44 = the lane's byte offset into the buffer at s[24:25]) instead of through LDS
+#define WRG(V0, V1, OFF) "global_store_dwordx4 v44, v[" #V0 ":" #V1 "], s[24:25] offset:" #OFF "\n"
+#define WAIT0 "s_waitcnt lgkmcnt(0)\n"
 #define NO_R(V0, V1, OFF) ""
 #define NO_W(V0, V1, OFF) ""
 #define CH_TILE(R, W, WT, EXTRA, MOV) \
@@ -52,16 +55,24 @@
     CH_16D(32, 48, 64, 80, 0, 16, 32, 48, R, W, WT, EXTRA, MOV) CH_16D(96, 112, 128, 144, 64, 80, 96, 112, R, W, WT, EXTRA, MOV) \
     "v_add_u32_e32 v40, 128, v40\n v_add_u32_e32 v41, 128, v41\n s_sub_u32 s22, s22, 1\n s_cmp_lg_u32 s22, 0\n s_cbranch_scc1 1b\n" \
     "s_waitcnt lgkmcnt(0)\n"
-#define CLOB "v40", "v41", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
+#define CH_TILEG(R, W, WT, EXTRA, MOV) \
+    "s_mov_b32 s20, 0xbffda16a\n s_mov_b32 s21, 0x3f7b4df5\n s_mov_b32 s22, 8\n" \
+    "ds_read_b128 v[48:51], v40\n ds_read_b128 v[52:55], v40 offset:16\n" \
+    "1:\n" \
+    CH_16(32, 48, 64, 80, 16, 32, 48, 64, R, W, WT, EXTRA, MOV) CH_16(96, 112, 128, 144, 80, 96, 112, 128, R, W, WT, EXTRA, MOV) \
+    "v_add_u32_e32 v40, 128, v40\n v_add_u32_e32 v44, 128, v44\n s_sub_u32 s22, s22, 1\n s_cmp_lg_u32 s22, 0\n s_cbranch_scc1 1b\n" \
+    "s_waitcnt lgkmcnt(0)\n"
+#define CLOB "v44", "s24", "s25", "v40", "v41", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
     "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v86", "v87", "v88", "s20", "s21", "s22", "scc", "memory"
 
 template <int V, int LANES>
-__global__ __launch_bounds__(64) void chain_kernel(float* out, uint32_t ntiles)
+__global__ __launch_bounds__(256) void chain_kernel(float* out, uint32_t ntiles)
 {
+    float* gbuf = out + (1 << 16);   // (V = 12, 13: every tile writes the same 1 KB per lane: 16 lanes x 1100 floats per block)
     __shared__ __attribute__((aligned(16))) float yrow[16][260 + 64];
     __shared__ __attribute__((aligned(16))) float hrow[16][264 + 64];
-    const uint32_t l = threadIdx.x;
-    for (int j = 0; j < 16; ++j) for (uint32_t i = l; i < 324; i += 64) yrow[j][i] = 0.001f * (float)((i * 7 + j) % 97);
+    const uint32_t l = threadIdx.x & 63u;   // (blocks of 256 threads: four waves, each running the chain on its own lanes, the rows shared)
+    for (int j = 0; j < 16; ++j) for (uint32_t i = threadIdx.x; i < 324; i += blockDim.x) yrow[j][i] = 0.001f * (float)((i * 7 + j) % 97);
     __syncthreads();
     if (l < (uint32_t)LANES) {
         const uint32_t ya = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)&yrow[l & 15][0];
@@ -81,6 +92,8 @@ __global__ __launch_bounds__(64) void chain_kernel(float* out, uint32_t ntiles)
             if (V == 8) asm volatile("v_mov_b32 v40, %0\n v_mov_b32 v41, %1\n" CH_TILE(RD, WR64, WAIT4, NONE, NONE) :: "v"(ya), "v"(ha) : CLOB);
             if (V == 9) asm volatile("v_mov_b32 v40, %0\n v_mov_b32 v41, %1\n" CH_TILED(RD, WR64, WAIT4, NONE, NONE) :: "v"(ya), "v"(ha) : CLOB);
             if (V == 10) asm volatile("v_mov_b32 v40, %0\n v_mov_b32 v41, %1\n" CH_TILED(RD, WR2, WAIT, NONE, NONE) :: "v"(ya), "v"(ha) : CLOB);
+            if (V == 12) asm volatile("v_mov_b32 v40, %0\n v_mov_b32 v44, %2\n s_mov_b32 s24, %3\n s_mov_b32 s25, %4\n" CH_TILEG(RD, WRG, WAIT0, NONE, NONE) :: "v"(ya), "v"(ha), "v"((uint32_t)((blockIdx.x * 16 + (l & 15)) * 1100 * 4)), "s"((uint32_t)(uintptr_t)gbuf), "s"((uint32_t)((uintptr_t)gbuf >> 32)) : CLOB);
+            if (V == 13) asm volatile("v_mov_b32 v40, %0\n v_mov_b32 v44, %2\n s_mov_b32 s24, %3\n s_mov_b32 s25, %4\n" CH_TILEG(NO_R, WRG, NONE, NONE, NONE) :: "v"(ya), "v"(ha), "v"((uint32_t)((blockIdx.x * 16 + (l & 15)) * 1100 * 4)), "s"((uint32_t)(uintptr_t)gbuf), "s"((uint32_t)((uintptr_t)gbuf >> 32)) : CLOB);
             if (V == 11) asm volatile("v_mov_b32 v40, %0\n v_mov_b32 v41, %1\n" CH_TILED(NO_R, WR, NONE, NONE, NONE) :: "v"(ya), "v"(ha) : CLOB);
         }
         float r;
@@ -89,6 +102,18 @@ __global__ __launch_bounds__(64) void chain_kernel(float* out, uint32_t ntiles)
     }
 }
 
+template <typename K> void run4(const char* name, K k, float* f)   // the same wave counts as blocks of FOUR waves
+{
+    const uint32_t ntiles = 400;
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    printf("%-46s", name);
+    for (int blocks : {16, 256}) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) { (void)hipEventRecord(a); hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, f, ntiles); (void)hipEventRecord(b); (void)hipEventSynchronize(b); float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms; }
+        printf("  %4d waves (x4 per block): %5.2f ns/sample", 4 * blocks, best * 1e6 / (ntiles * 256.0));
+    }
+    printf("\n");
+}
 template <typename K> void run(const char* name, K k, float* f)
 {
     const uint32_t ntiles = 400;   // x 256 samples
@@ -103,7 +128,7 @@ template <typename K> void run(const char* name, K k, float* f)
 }
 int main()
 {
-    float* f; (void)hipMalloc(&f, 1 << 22); (void)hipMemset(f, 0, 1 << 22);
+    float* f; (void)hipMalloc(&f, 1 << 27); (void)hipMemset(f, 0, 1 << 27);
     run("bare chain, 16 lanes", chain_kernel<0, 16>, f);
     run("bare chain, 64 lanes", chain_kernel<0, 64>, f);
     run("bare chain, 1 lane", chain_kernel<0, 1>, f);
@@ -120,5 +145,11 @@ int main()
     run("reads + 2 x b64 writes one block late, 16 lanes", chain_kernel<9, 16>, f);
     run("reads + write2_b64 one block late, 16 lanes", chain_kernel<10, 16>, f);
     run("b128 writes one block late only, 16 lanes", chain_kernel<11, 16>, f);
+    run("LDS reads + GLOBAL 16-byte stores, 16 lanes", chain_kernel<12, 16>, f);
+    run("LDS reads + GLOBAL 16-byte stores, 1 lane", chain_kernel<12, 1>, f);
+    run("GLOBAL 16-byte stores only, 16 lanes", chain_kernel<13, 16>, f);
+    run("LDS reads + writes, 1 lane", chain_kernel<5, 1>, f);
+    run4("bare chain, 16 lanes, 4 waves per block", chain_kernel<0, 16>, f);
+    run4("LDS reads + writes, 16 lanes, 4 waves per block", chain_kernel<5, 16>, f);
     return 0;
 }
