@@ -180,7 +180,10 @@ struct EvParams {
     SeqState* state;      // cold.ev_cursor = operations of the run; cold.diag.evm = EVM_PENDING where the last callback waits for its value
     uint32_t C;
     const uint32_t* upto; // [C] fold the operations below this cursor (K5's at the end of a segment)
-    uint32_t last;        // the last pass of a run (upto = K5's cursor at the end of its last segment): the next run's operations start at 0, m17_diag is settled
+    uint32_t last;        // != 0: the last pass of a run (upto = K5's cursor at the end of its last segment): the next run's operations start at 0.  1: m17_diag is
+                          // settled as well (the pass runs behind the run, nothing else at work on the state); 2: it is not — the pass rides a launch of the NEXT
+                          // run, whose K5 has the state in its hands (it would put this run's value over a mark of the next run's): the value stays in
+                          // EvState::last, and the pass that does settle (m17hip_diag_fetch's, or the last of a stream) finds it there
 };
 constexpr int EV_CPB = 16;                        // channels per workgroup (one wave) of a fold pass
 constexpr int EV_TILE_FLOATS = EV_CPB * 68;       // its LDS: 16 channels x 64 operations, rows of 68 words
@@ -255,7 +258,7 @@ __device__ __forceinline__ void evm_fold_pass(const EvParams& E, uint32_t blk, f
     if (valid) {
         e.pos = E.last ? 0u : upto;   // (the last pass of a run: the next run's operations start at 0)
         E.es[c] = e;
-        if (E.last) {
+        if (E.last == 1u) {
             uint32_t* w = reinterpret_cast<uint32_t*>(&E.state[c].cold.diag.evm);
             if (*w == EVM_PENDING) *w = __float_as_uint(e.last);
         }

@@ -1291,6 +1291,10 @@ struct SegPlan {
             }
         }
         while (pos + seg_len < T) { pos += seg_len; b.push_back(pos); }
+        // Segment starts are multiples of eight samples: the matched filter loads its input sixteen bytes at a time and stores float4s from a
+        // segment's first sample on (an odd start made those accesses misaligned — the hardware splits them, C++ calls it undefined)
+        for (size_t k = 1; k < b.size(); ++k) b[k] &= ~7u;
+        b.erase(std::unique(b.begin(), b.end()), b.end());
         b.push_back(T);
         nseg = (uint32_t)b.size() - 1u;
     }
@@ -1402,7 +1406,10 @@ static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStre
     // The LAST pass of the run before (its buffer is not this run's): beside K5 of this run's first segment, with the replay that runs ahead for the
     // second one — or, for a run of one segment, with this replay, which K5 waits for (that K5 is the one that moves the end-of-run cursors on)
     if (!redo && c->fold_pending && c->fold_ops && ((sp.nseg >= 2 && ahead && k == 1) || (sp.nseg < 2 && k == 0))) {
-        G.ev = EvParams{c->fold_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, c->fold_C, c->fold_end, 1u};
+        // (beside the replay, last = 2: m17_diag is NOT settled by this pass — K5 of this run's first segment has the state in its hands meanwhile; found by the
+        //  sweep: a run whose last segment fires no callback kept the value this pass had put over the first segment's mark.  In front of segment 0, which K5
+        //  waits for, it is settled as always)
+        G.ev = EvParams{c->fold_ops, c->ev_pitch, c->ev_state, c->diag_cap ? c->diag_log : nullptr, c->diag_cap, c->seq_state, c->fold_C, c->fold_end, k == 0 ? 1u : 2u};
         fold_blocks = ev_fold_blocks(c->fold_C);
         c->fold_pending = false;
     }

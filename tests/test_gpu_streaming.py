@@ -305,6 +305,42 @@ def test_the_evm_fold_can_move_between_runs_of_a_stream():
     c.close()
 
 
+def test_a_runs_last_evm_fold_pass_beside_the_next_runs_first_segment_leaves_its_marks_alone():
+    """Found by tools/parity_sweep.py (seed 6082, round 6; the signals and cuts below are that configuration's): with the fold deferred (key 17)
+    the last pass of run k rides the replay launch of run k + 1 and works BESIDE K5 of that run's first segment.  When it settled m17_diag.evm
+    there, it could put run k's value over the mark that segment had just written — and a run whose last segment is too short to fire another
+    callback (706 samples behind a 4800-sample segment) kept it: 4-5 of the 64 channels ended with a stale evm, records equal."""
+    import torch
+    Cn, T = 64, 96000
+    rng = np.random.default_rng(6082)
+    x = np.zeros((Cn, T), dtype=np.int16)
+    for c in range(Cn):                                          # bursts of every kind and level with gaps, as the sweep makes them
+        pos = 0
+        while pos < T - 8000:
+            n = min(int(rng.integers(6000, 40000)), T - pos)
+            p = ol.gen_params(seed=int(rng.integers(1, 1 << 30)), kind=int(rng.choice([0, 1, 2, 4])), n_frames=int(rng.integers(1, 16)),
+                              lead_in=int(rng.integers(0, 5000)), lead_sigma=float(rng.choice([0.0, 100.0, 1000.0, 10000.0, 40000.0])),
+                              noise_sigma=float(rng.choice([0.0, 100.0, 500.0, 1200.0, 2500.0])), tail_sigma=float(rng.choice([0.0, 100.0, 1000.0, 5000.0])),
+                              dc_offset=float(rng.choice([0.0, 0.0, 300.0, -2000.0, 6000.0])), gain=float(rng.choice([1.0, 0.3, 0.7, 1.6])),
+                              phase=int(rng.integers(-1, 10)), invert=0, total=n)
+            x[c, pos:pos + n] = ol.generate(p)[:n]; pos += n
+    cuts = [0] + sorted(int(v) for v in rng.integers(1, T, size=2)) + [T]
+    assert cuts == [0, 43854, 90494, 96000]
+    lengths = [b - a for a, b in zip(cuts[:-1], cuts[1:])]
+    exp, diags = _oracle(x)
+    pinned = [torch.from_numpy(np.ascontiguousarray(x[:, a:b])).pin_memory() for a, b in zip(cuts[:-1], cuts[1:])]
+    for order in ("fetch_then_run", "run_then_fetch"):
+        c = m17hip.Context(Cn, T)
+        for k, v in {15: 1, 3: 4800, 33: 0, 20: 0, 17: 1, 26: 1}.items():
+            c.tune(k, v)
+        for _ in range(3):                                       # (a race: more than one throw)
+            got = _pipelined(c, Cn, lengths, lambda k: c.upload_async(pinned[k].data_ptr(), Cn, lengths[k]), order)
+            c.upload_wait()
+            assert got.tobytes() == exp.tobytes() and got.size > 4 * Cn
+            _check_diag(c, Cn, diags)
+        c.close()
+
+
 def test_records_and_consumers_of_run_k_are_collected_after_run_k_plus_1_was_queued():
     """the deferred decode, the payload consumers, the compaction and the host's wait for them are off the chain of a continued
     stream — a run ends on the main stream with its state settled (settle_tail_kernel), everything else works on the payload stream on the

@@ -1,5 +1,5 @@
 """Randomised parity sweep on the GPU box: the scenario generator of tests/test_gpu_parity.py::test_full_chain_random_scenarios over
-many seeds, both decode placements, several segment lengths, run boundaries at random samples, pipelined runs; prints the channels whose records or diagnostics differ from the oracle.
+many seeds, both decode placements, several segment lengths (with and without a ramp), run boundaries at random samples, pipelined runs in both call orders; prints the channels whose records or diagnostics differ from the oracle.
 Usage: parity_sweep.py <first seed> <n seeds>"""
 import sys, os, numpy as np
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
@@ -33,9 +33,12 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     cuts = sorted(int(v) for v in rng.integers(1, T, size=2))
     rseg = int(rng.integers(3000, 30000))
     # (payload frames decoded after the run [m17hip_tune 15], segment length, run boundaries, staged + m17hip_demod_front; the redo policy [20] and the EVM fold's place [17] alternate)
+    # piped: 1 = the front end of each run queued before the previous run's records are fetched, then the run (the order of rounds 3-5);
+    #        2 = front, RUN, then the previous run's records (m17hip_frames_select(1): round 6)
     for spec, seg, pieces, piped in ((1, 19200, None, 0), (1, rseg, None, 0), (0, rseg, None, 0), (1, 0, None, 0), (1, 19200, [0] + cuts + [T], 0),
-                                     (1, 19200, [0] + cuts + [T], 1), (0, rseg, [0] + cuts + [T], 1), (1, 4800, [0] + cuts + [T], 1)):
-        ctx.tune(15, spec); ctx.tune(3, seg); ctx.tune(20, (seed + spec + piped) & 1); ctx.tune(17, (seed + piped + (seg & 1)) & 1); ctx.tune(26, (seed + spec + (seg >> 2)) & 1); ctx.reset()
+                                     (1, 19200, [0] + cuts + [T], 1), (0, rseg, [0] + cuts + [T], 1), (1, 4800, [0] + cuts + [T], 1),
+                                     (1, 19200, [0] + cuts + [T], 2), (1, rseg, [0] + cuts + [T], 2), (0, 4800, [0] + cuts + [T], 2)):
+        ctx.tune(15, spec); ctx.tune(3, seg); ctx.tune(33, 2400 if (seed + piped) % 3 == 0 else 0); ctx.tune(20, (seed + spec + piped) & 1); ctx.tune(17, (seed + piped + (seg & 1)) & 1); ctx.tune(26, (seed + spec + (seg >> 2)) & 1); ctx.reset()
         if pieces is None:
             ctx.upload(x); ctx.run(flags=inv); got = ctx.frames()
         elif not piped:   # the same stream as three runs (state, filter history and DCD sums carried between them)
@@ -54,8 +57,11 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
                 if i + 1 < len(spans):
                     n1 = spans[i + 1][1] - spans[i + 1][0]
                     ctx.upload_async(pins[i + 1].data_ptr(), C, n1); ctx.front(flags=inv, channels=C, samples=n1)
+                    if piped == 2:
+                        ctx.run(flags=inv, channels=C, samples=n1); ctx.frames_select(1)
                 parts.append(ctx.frames().copy())
-                if i + 1 < len(spans):
+                ctx.frames_select(0)
+                if i + 1 < len(spans) and piped != 2:
                     ctx.run(flags=inv, channels=C, samples=n1)
             ctx.upload_wait()
             got = np.concatenate(parts); got = got[np.lexsort((got['seq'], got['channel']))]
