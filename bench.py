@@ -261,9 +261,8 @@ class Bench:
             c_ = self.m17hip.Context(C, T, device=self.local_rank)
             c_.set_channel_base(self.rank * C)     # records carry GLOBAL channel ids: the gathered set is the record set of one big run
             self.apply_tune(c_)
-            if self.F > 1:
-                self.streams.append(self.torch.cuda.Stream(device=self.dev))
-                c_.set_stream(self.streams[-1].cuda_stream)
+            # (every context works on the library's own main stream, created with its other streams in a fixed role order: include/m17hip.h,
+            #  m17hip_get_stream — a host stream handed in per context made the layout depend on the process's history, NOTES 6.6)
             self.ctxs.append(c_)
         self.ctx = self.ctxs[0]
         for c_ in self.ctxs:
@@ -463,8 +462,6 @@ class Bench:
             c_ = m17hip.Context(Cg, T, device=self.local_rank)
             c_.set_channel_base(rank * C + g * Cg)
             self.apply_tune(c_)
-            sstreams.append(self.torch.cuda.Stream(device=self.dev))
-            c_.set_stream(sstreams[-1].cuda_stream)
             c_.synth(self.p, Cg, T, chan0=rank * C + g * Cg)
             c_.tune(16, 1)
             c_.synth(self.p, Cg, T, chan0=rank * C + g * Cg)   # the same synthetic slab into the context's second input slab (staged)

@@ -98,7 +98,17 @@ int m17hip_advice(const m17hip_ctx* ctx);
  * forced dcd.unlock() after losing sync, M17Demodulator.h:396-404, 470-478: the one gate event the replay cannot foresee) and computed
  * its own limit-filter history up to the end of the next segment — the slow path of the sequential kernel.  Waits for the queued work. */
 int m17hip_replay_drops(m17hip_ctx* ctx, uint64_t* count);
-/* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = the default stream). */
+/* The context's main stream (a hipStream_t).  From round 6 on the library creates it — together with the context's other streams, in one go and in a
+ * fixed role order; a destroyed context's streams are parked as a set and handed to the next context of that device — because which streams share a
+ * hardware pipe decides 10-40 % of a continued stream's step time and the runtime maps streams to pipes in creation order: a process that creates and
+ * destroys contexts around a host's own main streams walks through the slow layouts (24 -> 26 -> 32 ms per step over three create / use / destroy
+ * cycles, tools/stream_history.py; 22.1-22.5 ms in every cycle with the library's own).  It is a NON-BLOCKING stream: it does not synchronise with the
+ * default stream.  A host that produces input on, or consumes device-side results from, a stream of its own orders the two with events (or, in
+ * PyTorch, wraps this one: torch.cuda.ExternalStream(handle)); results fetched into host memory are complete when the fetch returns, as ever. */
+int m17hip_get_stream(m17hip_ctx* ctx, void** hip_stream);
+/* For hosts that insist: launch all work of this context on `hip_stream` instead (a hipStream_t; NULL = the default stream — what a context ran on
+ * up to round 5 when this was not called).  The library's main stream stays with the context, idle.  M17HIP_STREAM_SETS=0 in the environment restores
+ * the older behaviour altogether (streams per context, destroyed with it, main = the default stream): a diagnostic, not a deployment mode. */
 int m17hip_set_stream(m17hip_ctx* ctx, void* hip_stream);
 
 /* Input: [C][T] int16, row pitch in samples.  Replaces the stdin read loop apps/m17-demod.cpp:484-488. */

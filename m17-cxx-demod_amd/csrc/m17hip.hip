@@ -38,6 +38,8 @@ struct m17hip_ctx {
     int device = 0;
     int last_hip = 0;
     hipStream_t stream = nullptr;
+    hipStream_t own_main = nullptr;   // the main stream the library created with the others (StreamSet); `stream` is this one until m17hip_set_stream names another
+    int set_mode = 0;
     hipStream_t side = nullptr;        // K3 runs here, concurrently with K1 (side2) and with K2/K5 of earlier segments (stream)
     hipStream_t side2 = nullptr;       // K1 of the segments of a run
     hipStream_t side3 = nullptr;       // K2 of segment k+1 while K5 works on segment k
@@ -139,7 +141,8 @@ struct m17hip_ctx {
     // 24 to 27-37 ms whatever its place in the creation order (which streams share a hardware pipe: NOTES 4.14, 6.3).  The copy stream also
     // carries the next run's staged input and prefix copies, which must never wait for a FUTURE event: so a run's payload work is queued
     // when somebody asks for its results (or needs its record set back), not when the run is queued — flush_payload.
-    hipStream_t pay() const { return copy ? copy : stream; }
+    bool streams() const { return copy && xstage; }   // input has been staged (stage_prepare): the copy stream is at work (a parked set may bring one along — that alone changes nothing)
+    hipStream_t pay() const { return streams() ? copy : stream; }
     hipEvent_t ev_dst = nullptr;      // the caller's main-stream work on a device destination is done (a fetch of the LATEST run orders itself behind it)
     uint32_t* overflow = nullptr;     // [8]: four words per record set
     uint64_t* rec_offsets = nullptr;  // exclusive prefix of rec_count (+ total at [C]): scratch of a compaction (payload stream)
@@ -722,6 +725,20 @@ const char* m17hip_strerror(int code)
     }
 }
 int m17hip_last_hip_error(const m17hip_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+// The streams of a context — main, carrier-detect (K3), matched filter (K1), replay (K2 ahead / redo), and the copy / payload stream once something is staged —
+// are created by the library in ONE go in a fixed role order, and when a context goes they are parked as a SET: the next context of that device gets the same
+// streams in the same roles.  Which role streams share a hardware pipe decides 10-40 % of a continued stream's step time (NOTES 4.14, 5.3, 5.10), the runtime maps
+// streams to pipes in creation order, and a process that creates and destroys contexts beside a host's own streams walks through the bad layouts
+// (tools/stream_history.py: 24.3 -> 26.2 -> 31.8 ms per step over three cycles with per-context streams and a host main stream; 22.1-22.5 in every cycle this way).
+// M17HIP_STREAM_SETS=0 in the environment restores per-context streams on the default stream (tools/stream_history.py's A/B).
+struct StreamSet { hipStream_t main, side, side2, side3, copy; int device; };
+static struct { std::mutex mu; std::vector<StreamSet> parked; } g_sets;
+static int stream_set_mode()
+{
+    const char* e = getenv("M17HIP_STREAM_SETS");
+    return (e && atoi(e) == 0) ? 0 : 1;
+}
+
 static int hw_queues_env()   // what the process asked the HIP runtime for (the runtime's default is 4)
 {
     const char* q = std::getenv("GPU_MAX_HW_QUEUES");
@@ -733,7 +750,7 @@ int m17hip_advice(const m17hip_ctx* ctx)
     const int n = hw_queues_env();
     return (n < 8 ? M17HIP_ADVICE_HW_QUEUES : 0) | (n < 16 ? M17HIP_ADVICE_HW_QUEUES_16 : 0);
 }
-int m17hip_version(void) { return 600; }
+int m17hip_version(void) { return 601; }
 
 int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m17hip_ctx** out)
 {
@@ -819,15 +836,33 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
         if (hipMemcpy(c->level_gain, sched.data(), sched.size() * sizeof(core::Kalman2Gain), hipMemcpyHostToDevice) != hipSuccess) return fail(M17HIP_EHIP);
     }
     c->coef = build_coef();
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
-    if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
-    {   // the replay stream outranks the others: its few workgroups must not queue behind K5's thousand.  (K1's stream at the LOWEST priority
-        // was tried: a continued stream of 2 x 2048 channels 24.6 -> 22.8 ms in a process with history, but 2 x 1024 channels 11.5 -> 16.1 ms —
-        // K1 starves behind the other group's kernels: NOTES 5.10.)
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return fail(M17HIP_EHIP);
-        if (hipStreamCreateWithPriority(&c->side3, hipStreamNonBlocking, greatest) != hipSuccess) return fail(M17HIP_EHIP);
+    c->set_mode = stream_set_mode();
+    bool parked = false;
+    if (c->set_mode) {
+        std::lock_guard<std::mutex> lk(g_sets.mu);
+        for (size_t i = 0; i < g_sets.parked.size(); ++i)
+            if (g_sets.parked[i].device == device) {
+                const StreamSet& ss = g_sets.parked[i];
+                c->own_main = ss.main; c->side = ss.side; c->side2 = ss.side2; c->side3 = ss.side3; c->copy = ss.copy;
+                g_sets.parked.erase(g_sets.parked.begin() + (long)i);
+                parked = true;
+                break;
+            }
     }
+    if (!parked) {
+        // (the copy stream joins the set when something is staged — stage_prepare: created here with the others, two batches measured 21.5 against 21.1 ms)
+        if (c->set_mode && hipStreamCreateWithFlags(&c->own_main, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
+        if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
+        {   // the replay stream outranks the others: its few workgroups must not queue behind K5's thousand.  (K1's stream at the LOWEST priority
+            // was tried: a continued stream of 2 x 2048 channels 24.6 -> 22.8 ms in a process with history, but 2 x 1024 channels 11.5 -> 16.1 ms —
+            // K1 starves behind the other group's kernels: NOTES 5.10.)
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return fail(M17HIP_EHIP);
+            if (hipStreamCreateWithPriority(&c->side3, hipStreamNonBlocking, greatest) != hipSuccess) return fail(M17HIP_EHIP);
+        }
+    }
+    if (c->own_main) c->stream = c->own_main;
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     if (hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
@@ -863,10 +898,20 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     for (auto e : c->pool) hipEventDestroy(e);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
-    if (c->side && !c->foreign_streams[0]) hipStreamDestroy(c->side);
-    if (c->side2 && !c->foreign_streams[1]) hipStreamDestroy(c->side2);
-    if (c->side3 && !c->foreign_streams[2]) hipStreamDestroy(c->side3);
-    if (c->copy && !c->foreign_streams[3]) hipStreamDestroy(c->copy);
+    const bool any_foreign = c->foreign_streams[0] || c->foreign_streams[1] || c->foreign_streams[2] || c->foreign_streams[3];
+    if (c->set_mode && !any_foreign && c->own_main && c->side && c->side2 && c->side3) {
+        // the set is parked as a SET: the next context of this device gets the same five streams in the same roles
+        for (hipStream_t st : {c->own_main, c->side, c->side2, c->side3, c->copy})
+            if (st) (void)hipStreamSynchronize(st);
+        std::lock_guard<std::mutex> lk(g_sets.mu);
+        g_sets.parked.push_back(StreamSet{c->own_main, c->side, c->side2, c->side3, c->copy, c->device});
+    } else {
+        if (c->own_main) hipStreamDestroy(c->own_main);
+        if (c->side && !c->foreign_streams[0]) hipStreamDestroy(c->side);
+        if (c->side2 && !c->foreign_streams[1]) hipStreamDestroy(c->side2);
+        if (c->side3 && !c->foreign_streams[2]) hipStreamDestroy(c->side3);
+        if (c->copy && !c->foreign_streams[3]) hipStreamDestroy(c->copy);
+    }
     if (c->ev_dst) hipEventDestroy(c->ev_dst);
     for (hipEvent_t e : {c->ev_copy, c->ev_in_ready, c->ev_end[0], c->ev_end[1], c->ev_mark, c->ev_tail, c->sets[0].done, c->sets[1].done, c->sets[0].chain, c->sets[1].chain})
         if (e) hipEventDestroy(e);
@@ -880,6 +925,13 @@ void m17hip_ctx_destroy(m17hip_ctx* c)
     for (void* p : ptrs)
         if (p) (void)hipFree(p);   // (the context is going away: nothing to report to)
     delete c;
+}
+
+int m17hip_get_stream(m17hip_ctx* c, void** hip_stream)
+{
+    if (!c || !hip_stream) return M17HIP_EINVAL;
+    *hip_stream = (void*)c->stream;
+    return M17HIP_OK;
 }
 
 int m17hip_set_stream(m17hip_ctx* c, void* hip_stream)
@@ -1831,7 +1883,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     // The run's payload work — the frames K5 did not decode itself, then the consumers — is queued when its results are asked for.  At once
     // where that costs nothing or is needed: a context that does not stream (the work goes to the main stream, behind the run, as up to round 5),
     // and with the diagnostic log on (ONE store, which the deferred decode patches: the next run waits for it).
-    if (!c->copy || c->diag_cap) {
+    if (!c->streams() || c->diag_cap) {
         c->fold_with_decode = c->fold_pending && c->defer_decode && c->pay() == c->stream;   // (beside the decode, as up to round 5)
         if ((r = flush_payload(c))) return r;
         c->fold_with_decode = false;

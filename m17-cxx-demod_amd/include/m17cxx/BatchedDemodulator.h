@@ -46,6 +46,8 @@ public:
     BatchedDemodulator& operator=(const BatchedDemodulator&) = delete;
 
     m17hip_ctx* handle() const { return ctx_; }
+    // the context's main stream (a hipStream_t; the library's own, non-blocking): what a host orders its own device work against
+    void* stream() const { void* s = nullptr; check(m17hip_get_stream(ctx_, &s), "m17hip_get_stream"); return s; }
 
     // [channels][samples] int16, row pitch in samples
     void upload(const int16_t* host, uint32_t channels, uint32_t samples, size_t pitch)

@@ -38,7 +38,7 @@ assert PACKET_REC.itemsize == 864
 VITERBI_SHAPES = {0: (488, 240), 1: (296, 144), 2: (420, 206), 3: (402, 197)}
 
 EXPORTS = [
-    "m17hip_strerror", "m17hip_last_hip_error", "m17hip_version", "m17hip_ctx_create", "m17hip_ctx_destroy", "m17hip_set_stream",
+    "m17hip_strerror", "m17hip_last_hip_error", "m17hip_version", "m17hip_ctx_create", "m17hip_ctx_destroy", "m17hip_set_stream", "m17hip_get_stream",
     "m17hip_upload_i16", "m17hip_upload_i16_device", "m17hip_upload_i16_async", "m17hip_synth_i16", "m17hip_download_i16", "m17hip_fir_rrc150", "m17hip_correlator", "m17hip_fir_correlator", "m17hip_dcd", "m17hip_viterbi",
     "m17hip_slice_llr", "m17hip_decode_frames", "m17hip_demod_reset", "m17hip_demod_run", "m17hip_frames_count", "m17hip_frames_fetch",
     "m17hip_frames_compact_device", "m17hip_diag_fetch", "m17hip_bert_stats", "m17hip_packets_fetch", "m17hip_packets_feed", "m17hip_lsf_info", "m17hip_tune", "m17hip_debug_counters", "m17hip_timing_enable", "m17hip_timing_get", "m17hip_timing_reset",
@@ -135,6 +135,19 @@ class Context:
 
     def set_stream(self, stream_handle):
         self._chk(self.lib.m17hip_set_stream(self.h, C.c_void_p(int(stream_handle))))
+
+    @property
+    def stream(self):
+        """The context's main stream (a hipStream_t as an int): the library's own unless set_stream named another (m17hip_get_stream)."""
+        h = C.c_void_p()
+        self._chk(self.lib.m17hip_get_stream(self.h, C.byref(h)))
+        return h.value or 0
+
+    def torch_stream(self):
+        """The main stream as a torch.cuda.ExternalStream: `with torch.cuda.stream(ctx.torch_stream()): ...` puts the host's tensor work in order
+        with the context's."""
+        import torch
+        return torch.cuda.ExternalStream(self.stream)
 
     # ---- input -------------------------------------------------------------------------------------------------
     def upload(self, samples):

@@ -190,6 +190,37 @@ def test_two_batches_in_flight_equal_one_after_the_other():
         c.close()
 
 
+def test_the_library_owns_a_contexts_streams_and_hands_them_on_as_a_set():
+    """m17hip_get_stream (include/m17hip.h): a context's main stream is the library's own — non-blocking, distinct per live context — and a
+    destroyed context's streams are parked as a set: the next context gets the same main stream.  m17hip_set_stream stays as the opt-in
+    (NULL = the default stream).  A host orders its tensor work with the context's by wrapping the stream (torch.cuda.ExternalStream):
+    input produced, demodulated, records compacted into a torch buffer and read — no device-wide synchronisation anywhere."""
+    import torch
+    a, b = m17hip.Context(16, 48000), m17hip.Context(16, 48000)
+    sa, sb = a.stream, b.stream
+    assert sa and sb and sa != sb
+    a.close()
+    c = m17hip.Context(32, 96000)
+    assert c.stream == sa                                        # the parked set, whatever the new context's size
+    b.set_stream(0); assert b.stream == 0
+    b.set_stream(sb); assert b.stream == sb
+    b.close()
+    x = _signals(32, 96000, seed=63, sigma=700.0)
+    exp = _oracle_flat(x)
+    host = torch.from_numpy(x).pin_memory()
+    st = c.torch_stream()
+    for rep in range(3):
+        with torch.cuda.stream(st):
+            dev = host.to("cuda", non_blocking=True) + 0         # a producer ON the context's stream: the copy and an elementwise kernel
+            c.upload_device(dev.data_ptr(), 32, 96000)
+            c.reset(); c.run()
+            out = torch.full((exp.size + 8, 64), 0xEE, dtype=torch.uint8, device="cuda")
+            n = c.frames_compact_device(out.data_ptr(), exp.size + 8)
+            got = out[:n].cpu().numpy()                           # (.cpu() waits for THIS stream only)
+        assert n == exp.size and got.tobytes() == exp.tobytes(), rep
+    c.close()
+
+
 def test_performance_knobs_do_not_change_results():
     """m17hip_tune keys that only move work around (segment length, where payload frames are decoded): the same records under every
     setting; keys the production library does not have (the measurement build's) are M17HIP_EINVAL."""

@@ -20,10 +20,9 @@ def test_recreated_contexts_run_as_fast_as_the_first_ones():
     p = ol.gen_params(seed=20260101, kind=-1, n_frames=T // 1920 - 6, lead_in=3072, noise_sigma=600.0, tail_sigma=600.0, lead_sigma=40000.0, total=T)
 
     def pair_ms():
-        ctxs, streams = [], []
+        ctxs = []
         for g in range(G):
-            c = m17hip.Context(Cg, T)
-            streams.append(torch.cuda.Stream()); c.set_stream(streams[-1].cuda_stream)
+            c = m17hip.Context(Cg, T)              # (the library's own main stream, parked with the context's other streams and reused as a set)
             c.synth(p, Cg, T, chan0=g * Cg); c.tune(16, 1); c.synth(p, Cg, T, chan0=g * Cg); c.tune(16, 0)
             c.reset(); c.run(); ctxs.append(c)
 
@@ -49,5 +48,7 @@ def test_recreated_contexts_run_as_fast_as_the_first_ones():
     big.upload(np.full((2 * Cg, T), -21846, dtype=np.int16)); big.reset(); big.run(); big.frames_count(); big.close()
     first = pair_ms()
     later = [pair_ms() for _ in range(3)]
-    # (which streams share a hardware dispatch pipe changes from pair to pair — NOTES 4.14 — and moves a pair by 10-20 %; the bug made the later pairs 1.6-2.1 x slower)
-    assert sorted(later)[1] < 1.3 * first and max(later) < 1.6 * first, (first, later)
+    # (up to round 5 — a host stream handed to every context, role streams created and destroyed with it — which streams shared a hardware dispatch pipe
+    #  changed from pair to pair, NOTES 4.14, and moved a pair by 10-20 %: the bounds were 1.3 / 1.6.  With the library's stream sets every pair has the first
+    #  pair's layout, NOTES 6.6; the bug this test is about made the later pairs 1.6-2.1 x slower)
+    assert sorted(later)[1] < 1.1 * first and max(later) < 1.2 * first, (first, later)
