@@ -371,10 +371,14 @@ int m17hip_gather_frames_device(m17hip_ctx* ctx, m17hip_comm* comm, int root, m1
  *        ended with the carrier off.  Same results either way.  NOTE: -1 consults the context's HISTORY (what the last fetched run looked like):
  *        the schedule of a run, and with it its latency, depends on the runs before — never a result.  A host that needs the same latency
  *        whatever came before pins 0 or 1.
- * key 33: a RAMP of segment lengths at the start of a run: value, 2 x value, 4 x value, ... samples until key 3's length is reached (0, default:
- *        none).  A channel that leaves the limit-filter replay in a segment carries the filter itself to the end of the NEXT one, and channels leave
+ * key 33: a RAMP of segment lengths at the start of a run: value, 2 x value, 4 x value, ... samples until key 3's length is reached (0 = none).
+ *        A channel that leaves the limit-filter replay in a segment carries the filter itself to the end of the NEXT one, and channels leave
  *        it mostly while sync is being acquired: short first segments bound what that costs the launches concerned.  One batch at a time
- *        24.6 -> 23.5 ms per 4096 x 480 000 with 9600; with batches in flight or a continued stream the extra launches cost as much (NOTES 6.4).
+ *        23.65 -> 22.8 ms per 4096 x 480 000 with 9600; with batches in flight or a continued stream the extra launches cost 1-3 % (NOTES 6.5).
+ *        -1 (default) = per run: 9600 when the run is the only thing in flight on the device as far as the library can see (no other context's
+ *        run unfinished when this one is queued, none since this context's previous run — the rule key 10 = -1 uses) and was not staged, else none.
+ *        NOTE: like keys 10 and 26, -1 consults process HISTORY: the schedule of a run, and with it its latency, depends on what was in flight
+ *        before it — never a result.  A host that needs the same latency whatever came before pins a value.
  * key 20: what happens after a forced dcd.unlock() took a channel off the limit-filter replay: 0 (default) = the replay's state is re-derived
  *        beside the sequential kernel and the channel computes its own filter history through the next segment (the sequential kernel never
  *        waits: best wherever its chain of launches is what a step lasts — a continued stream, one batch at a time); 1 = the replay of the next

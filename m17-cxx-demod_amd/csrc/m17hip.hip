@@ -13,6 +13,8 @@
 #include "m17_parity_kernels.hpp"
 #include "m17_gather.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -114,7 +116,8 @@ struct m17hip_ctx {
     hipEvent_t last_end = nullptr;    // ev_end of the run queued last
     uint32_t seg_len = 48000;         // tuning knob 3: samples per K2+K5 segment of a run (0 = the whole run)
     uint32_t seg0_len = 0;            // tuning knob 4: samples of the FIRST segment (a short one starts K5 early; 0 = like the others; measured neutral)
-    uint32_t seg_ramp = 0;            // tuning knob 33: first segment of a ramp r, 2 r, 4 r, ... up to seg_len (0 = none)
+    int64_t seg_ramp = -1;            // tuning knob 33: first segment of a ramp r, 2 r, 4 r, ... up to seg_len (0 = none; -1 = per run: AUTO_RAMP when the run is the only thing in flight)
+    uint32_t ramp_now = 0;            // what the run being queued uses (a staged run: decided when its front end is queued)
     float* dcd_table = nullptr;
     DcdState* dcd_state = nullptr;
     SeqState* seq_state = nullptr;
@@ -324,6 +327,29 @@ struct Timed {  // HIP events on the stream the kernel is launched on; a launch 
         if (!a) return;
         if (hipEventRecord(b, st) == hipSuccess) c->pending.push_back({a, b, which});
         else { c->pool.push_back(a); c->pool.push_back(b); }
+    }
+};
+// One kernel, timed by events BOUND to its launch (hipExtLaunchKernelGGL's start / stop events: the dispatch's own time stamps, what rocprofv3 reports) — nothing
+// is put into the stream around it.  Two recorded events per launch (Timed above) cost a continued stream 0.65 ms of its 21.7 ms step (tools/stream_only.py,
+// TIMING=1): for the five kernels of a run's chain that is the wrong price for being measured.
+struct TimedK {
+    m17hip_ctx* c; int which; hipEvent_t a = nullptr, b = nullptr;
+    TimedK(m17hip_ctx* ctx, int w) : c(ctx), which(w)
+    {
+        if (!c->timing) return;
+        a = get_event(c); b = get_event(c);
+        if (!a || !b) {
+            if (a) c->pool.push_back(a);
+            if (b) c->pool.push_back(b);
+            a = b = nullptr;
+        }
+    }
+    ~TimedK() { if (a) c->pending.push_back({a, b, which}); }
+    template <typename... P, typename... A>
+    void launch(void (*kernel)(P...), dim3 grid, dim3 block, uint32_t lds, hipStream_t st, A... args)
+    {   // (the arguments converted to the kernel's own parameter types: hipExtLaunchKernelGGL copies them as they come)
+        if (a) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, a, b, 0, static_cast<P>(args)...);
+        else hipLaunchKernelGGL(kernel, grid, block, lds, st, static_cast<P>(args)...);
     }
 };
 // Every entry point works on the context's own device whatever the calling thread's current device is (a host that also
@@ -663,11 +689,11 @@ constexpr size_t SEQ_LDS_BYTES_4 = 34816;   // see the K5 launch
 constexpr uint32_t FIR_GRID_PER_CU = 5, FIR_ITEMS_LATENCY = 3, FIR_ITEMS_THROUGHPUT = 8;
 int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0, const uint32_t* first_needed = nullptr)
 {
-    Timed tm(c, KT_FIR, st);
+    TimedK tm(c, KT_FIR);
 #ifdef M17_TOOLS
     if (c->fir_form == 0) {   // round 4's kernel: the measurement build keeps it for same-box comparisons (tools/k1_forms.py, the clk_k1 pass of tools/profile_round.sh)
         dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C);
-        hipLaunchKernelGGL((fir_rrc150_rolled_kernel<FIR_R, 4>), grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
+        tm.launch((fir_rrc150_rolled_kernel<FIR_R, 4>), grid, dim3(FIR_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, flags, c->taps);
     } else
 #endif
     {
@@ -679,27 +705,27 @@ int launch_fir(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_
         const uint32_t cap = c->fir_grid ? c->fir_grid : std::max(FIR_GRID_PER_CU * c->n_cu, (items + per - 1) / per);
         const dim3 grid(std::min(items, cap));
         if (flags & 1u)
-            hipLaunchKernelGGL(fir_rrc150_skew_kernel<true>, grid, dim3(FS_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, c->taps_skew, tiles, items, first_needed);
+            tm.launch(fir_rrc150_skew_kernel<true>, grid, dim3(FS_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, c->taps_skew, tiles, items, first_needed);
         else
-            hipLaunchKernelGGL(fir_rrc150_skew_kernel<false>, grid, dim3(FS_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, c->taps_skew, tiles, items, first_needed);
+            tm.launch(fir_rrc150_skew_kernel<false>, grid, dim3(FS_THREADS), 0, st, c->xbuf + t0, c->xpitch, c->ybuf + t0, c->ypitch, T, c->taps_skew, tiles, items, first_needed);
     }
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
 int launch_dcd(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, hipStream_t st, uint32_t t0 = 0)
 {
-    Timed tm(c, KT_DCD, st);
+    TimedK tm(c, KT_DCD);
     // table rows are numbered from the first tick of the RUN: a later segment continues where the previous one stopped
     const uint64_t row0 = (c->pos + t0) / TICK - c->pos / TICK;
     // (the pipeline needs whole 32-sample blocks that start on a block boundary of the stream: ragged pieces take the one-wave form)
     if (!c->dcd_latency || T % DP_BLK != 0 || (c->pos + t0) % DP_BLK != 0 || t0 % 8 != 0 || T < 4 * DP_BLK)
-        hipLaunchKernelGGL(dcd_kernel, dim3((C + DCD_CPW * DCD_WPB - 1) / (DCD_CPW * DCD_WPB)), dim3(64 * DCD_WPB), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+        tm.launch(dcd_kernel, dim3((C + DCD_CPW * DCD_WPB - 1) / (DCD_CPW * DCD_WPB)), dim3(64 * DCD_WPB), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
                            c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
     else if (flags & 1u)
-        hipLaunchKernelGGL(dcd_pipe_kernel<true>, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+        tm.launch(dcd_pipe_kernel<true>, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
                            c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
     else
-        hipLaunchKernelGGL(dcd_pipe_kernel<false>, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
+        tm.launch(dcd_pipe_kernel<false>, dim3((C + DP_CPB - 1) / DP_CPB), dim3(256), 0, st, c->xbuf + t0, c->xpitch, c->dcd_state,
                            c->dcd_table + row0 * 12, c->ticks_cap, C, T, c->pos + t0, c->coef, flags);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
@@ -1328,6 +1354,7 @@ namespace {
 // optionally a short first one (key 4), or a RAMP (key 33): segments of r, 2 r, 4 r, ... samples until seg_len is reached.  The ramp is for
 // where channels leave the limit-filter replay — at the start of a transmission, while sync is being acquired: a channel that leaves it in
 // segment k carries the filter itself to the end of segment k + 1, so what a drop costs the launches it falls into is twice the segment's length.
+constexpr uint32_t AUTO_RAMP = 9600;   // (2400 ... 24 000 measured: NOTES 6.5)
 struct SegPlan {
     uint32_t T, seg_len, nseg;
     std::vector<uint32_t> b;   // b[k] = first sample of segment k; b[nseg] = T
@@ -1337,8 +1364,8 @@ struct SegPlan {
         b.push_back(0);
         uint32_t pos = 0;
         if (seg_len < T && !c->profile) {
-            if (c->seg_ramp && c->seg_ramp < seg_len) {
-                for (uint32_t len = c->seg_ramp; len < seg_len && pos + len < T; len *= 2) { pos += len; b.push_back(pos); }
+            if (c->ramp_now && c->ramp_now < seg_len) {
+                for (uint32_t len = c->ramp_now; len < seg_len && pos + len < T; len *= 2) { pos += len; b.push_back(pos); }
             } else if (c->seg0_len && c->seg0_len < seg_len) {
                 pos = c->seg0_len; b.push_back(pos);
             }
@@ -1441,7 +1468,7 @@ static int launch_gated_fir(m17hip_ctx* c, const SegPlan& sp, uint32_t k, uint32
 static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStream_t st, bool ahead, bool redo, uint32_t C, uint32_t flags, bool redo_stores = false)
 {
     const uint32_t t0 = sp.t0(k), len = sp.t0(k + 1) - t0;
-    Timed tm(c, KT_GATE, st);
+    TimedK tm(c, KT_GATE);
     GateParams G{};
     G.x = c->xbuf + t0; G.xpitch = c->xpitch; G.y = c->ybuf + t0; G.ypitch = c->ypitch; G.h = c->hbuf + t0;
     G.dcd_table = c->dcd_table; G.ticks_cap = c->ticks_cap; G.state = c->seq_state;
@@ -1466,7 +1493,7 @@ static int launch_gate_seg(m17hip_ctx* c, const SegPlan& sp, uint32_t k, hipStre
         fold_blocks = ev_fold_blocks(c->fold_C);
         c->fold_pending = false;
     }
-    hipLaunchKernelGGL(limit_track_kernel, dim3(G.nblk + fold_blocks), dim3(64), GT_LDS_FLOATS * sizeof(float), st, G);
+    tm.launch(limit_track_kernel, dim3(G.nblk + fold_blocks), dim3(64), GT_LDS_FLOATS * sizeof(float), st, G);
     HIPCHK(c, hipGetLastError());
     return M17HIP_OK;
 }
@@ -1506,6 +1533,7 @@ static int begin_staged(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags, b
         const uint32_t j = std::min(c->front_k1_after, c->last_nseg) - 1u;
         HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_seq_[c->slot ^ 1][j], 0));
     }
+    c->ramp_now = c->seg_ramp > 0 ? (uint32_t)c->seg_ramp : 0u;   // (a continued stream: the extra launches of a ramp cost its chain more than the shorter drops save)
     const SegPlan sp(c, T);
     int r = ensure_seg_events(c, c->slot, sp.nseg);
     if (r) return r;
@@ -1561,8 +1589,8 @@ static int flush_payload(m17hip_ctx* c, bool selected_only = false, bool older_o
                 fold_blocks = ev_fold_blocks(C);
                 c->fold_pending = false;
             }
-            Timed tm(c, KT_DEC, ps);
-            hipLaunchKernelGGL(decode_deferred_kernel, dim3(C + fold_blocks), dim3(64), DEFER_LDS_BYTES, ps, D);
+            TimedK tm(c, KT_DEC);
+            tm.launch(decode_deferred_kernel, dim3(C + fold_blocks), dim3(64), DEFER_LDS_BYTES, ps, D);
             HIPCHK(c, hipGetLastError());
         }
         if (rs.bert && c->bert_state)   // payload consumer: PRBS9 statistics over this run's BERT records
@@ -1694,6 +1722,11 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
     // so the front end of segment k+1 fills the issue slots K5 of segment k leaves idle (its tail above all).
     // Every K2 starts a fresh speculation from K5's own state, so a channel that had to drop it (forced unlock) carries the
     // limit filter itself only until the end of its segment.
+    // Is this run the only thing in flight on the device?  (What a context can know of it: runs_overlap.)  Then a step lasts what its chain of launches lasts:
+    // K3 and K1 take their latency forms, and the run starts with a ramp of short segments (key 33) — one batch at a time 23.65 -> 22.8 ms per
+    // 4096 x 480 000; with batches in flight or a continued stream both cost more than they save.
+    const bool alone = !staged_run && !runs_overlap(c);
+    if (!staged_run) c->ramp_now = c->seg_ramp >= 0 ? (uint32_t)c->seg_ramp : (alone ? AUTO_RAMP : 0u);
     const SegPlan sp(c, T);
     const uint32_t nseg = sp.nseg;
     const int q = c->slot;
@@ -1718,7 +1751,7 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
         HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork, 0));
-        c->dcd_latency = c->dcd_form < 0 ? !runs_overlap(c) : c->dcd_form == 1;
+        c->dcd_latency = c->dcd_form < 0 ? alone : c->dcd_form == 1;
         c->fir_latency = c->dcd_latency;
         c->front_segs = std::min(ahead, nseg);
         if ((r = gate_mode_for_run(c, sp))) return r;
@@ -1835,16 +1868,16 @@ int m17hip_demod_run(m17hip_ctx* c, uint32_t C, uint32_t T, uint32_t flags)
                 HIPCHK(c, hipEventRecord(ev_gate[k + 1], c->side3));
             }
         }
-        Timed tm(c, KT_SEQ);
+        TimedK tm(c, KT_SEQ);
         SeqParams P = seq_params(k, t0, len);
         P.dropped_in = (k > 0 && !redo_front) ? drop_of[(k - 1u) & 1u] : nullptr;   // (redo in front: nobody starts a segment off the replay)
 #ifdef M17_TOOLS
-        if (c->profile) hipLaunchKernelGGL((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P);
-        else if (c->wave_times) hipLaunchKernelGGL((demod_wave_kernel<4, false, true>), grid, block, lds, c->stream, P);
+        if (c->profile) tm.launch((demod_wave_kernel<4, true>), grid, block, lds, c->stream, P);
+        else if (c->wave_times) tm.launch((demod_wave_kernel<4, false, true>), grid, block, lds, c->stream, P);
         else
 #endif
-        if (c->kalman_order == 3u) hipLaunchKernelGGL((demod_wave_kernel<4, false, false, 3>), grid, block, lds, c->stream, P);   // (the default order: no call in the kernel)
-        else hipLaunchKernelGGL(demod_wave_kernel<4>, grid, block, lds, c->stream, P);
+        if (c->kalman_order == 3u) tm.launch((demod_wave_kernel<4, false, false, 3>), grid, block, lds, c->stream, P);   // (the default order: no call in the kernel)
+        else tm.launch(demod_wave_kernel<4>, grid, block, lds, c->stream, P);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(ev_seq[k], c->stream));
         if (k + ahead < nseg && (r = launch_front_seg(c, sp, k + ahead, C, flags))) return r;
@@ -2517,9 +2550,9 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         if (value < -1 || value > 1) return M17HIP_EINVAL;
         c->gate_aware = (int)value;
         return M17HIP_OK;
-    case 33:  // ramp of segment lengths at the start of a run: value, 2 x value, 4 x value, ... samples, then seg_len (0 = none)
-        if (value < 0 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
-        c->seg_ramp = (uint32_t)value;
+    case 33:  // ramp of segment lengths at the start of a run: value, 2 x value, 4 x value, ... samples, then seg_len (0 = none, -1 = per run)
+        if (value < -1 || value > 0x7FFFFFFF) return M17HIP_EINVAL;
+        c->seg_ramp = value;
         return M17HIP_OK;
     case 13:  // workgroups of K1's bounded grid (0 = default)
         if (value < 0 || value > (1 << 20)) return M17HIP_EINVAL;

@@ -23,7 +23,8 @@ p = ol.gen_params(seed=20260101, kind=-1, n_frames=T // 1920 - 6, lead_in=3072, 
 gs, ss = [], []
 for g in range(G):
     for _ in range(nph): hip_stream()
-    c = m17hip.Context(Cg, T); ss.append(torch.cuda.Stream()); c.set_stream(ss[-1].cuda_stream)
+    c = m17hip.Context(Cg, T)
+    if os.environ.get('MAIN') == 'torch': ss.append(torch.cuda.Stream()); c.set_stream(ss[-1].cuda_stream)   # (rounds 2-5: a host stream per context; default now: the library's own)
     c.synth(p, Cg, T, chan0=g * Cg); c.tune(16, 1); c.synth(p, Cg, T, chan0=g * Cg); c.tune(16, 0)
     c.reset(); c.run(); gs.append(c)
 def stream(n):
@@ -39,4 +40,9 @@ def stream(n):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) * 1e3 / n
 stream(8)
+if os.environ.get('TIMING'):
+    for c in gs: c.timing(True); c.timing_reset()
+if os.environ.get('COMPACT'):   # records compacted into a device buffer, as bench.py's leg does
+    bufs = [torch.zeros(Cg * (2 * (T // 1920 + 2) + 4) * 64, dtype=torch.uint8, device='cuda') for _ in gs]
+    for c, b in zip(gs, bufs): c.frames_count = (lambda c=c, b=b: c.frames_compact_device(b.data_ptr(), Cg * (2 * (T // 1920 + 2) + 4)))
 print('placeholders %d pre %d order %s: single-stream ms/step %.2f %.2f' % (nph, pre, ORDER, stream(12), stream(12)), flush=True)
