@@ -1,7 +1,8 @@
 """What a process's HISTORY does to the stream layout (VERDICT r5 #7b): N cycles of create / use / destroy in one process — each cycle the two-batch
 regime (two contexts of 4096 channels) and then the continued-stream regime (two groups of 2048) — with F foreign HIP streams created in front of every
-cycle.  MAIN=torch: the host hands a torch stream to every context (m17hip_set_stream); MAIN=own: the library's own main stream (M17HIP_STREAM_SETS=1).
-    M17HIP_STREAM_SETS=1 MAIN=own python3 tools/stream_history.py 3 2"""
+cycle.  MAIN=own (default): the library's own main stream; MAIN=torch: the host hands a torch stream to every context (m17hip_set_stream) — rounds 2-5, and
+still the slow layouts (23.2 / 32.8 / 22.6 ms over three cycles WITH the role streams parked).  M17HIP_STREAM_SETS=0: per-context role streams as well.
+    python3 tools/stream_history.py 3 2;  MAIN=torch M17HIP_STREAM_SETS=0 python3 tools/stream_history.py 3 2;  TIMING=1: what the per-kernel events cost"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -11,7 +12,7 @@ import m17hip, oracle_lib as ol
 m17hip.Context._warned = True
 cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 foreign = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-MAIN = os.environ.get('MAIN', 'torch')
+MAIN = os.environ.get('MAIN', 'own')
 torch.zeros(1, device='cuda')
 hip = ctypes.CDLL([l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l][0])
 keep = []
@@ -36,6 +37,11 @@ for cyc in range(cycles):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) * 1e3 / n
     groups(16); two = groups(24)
+    if os.environ.get('TIMING'):   # what the library's per-kernel events cost this regime (bench.py's headline leg keeps them inside its timed region)
+        for c in ctxs: c.timing(True); c.timing_reset()
+        two_t = groups(24)
+        for c in ctxs: c.timing(False)
+        print('  two-batch with kernel timers %.2f, without again %.2f' % (two_t, groups(24)), flush=True)
     for c in ctxs: c.close()
     Cg = C // 2
     gs = []
@@ -54,4 +60,4 @@ for cyc in range(cycles):
         return (time.perf_counter() - t0) * 1e3 / n
     stream(8); one = (stream(12), stream(12))
     for c in gs: c.close()
-    print('sets %s main %s foreign %d cycle %d: two-batch %.2f ms/step   single-stream %.2f %.2f' % (os.environ.get('M17HIP_STREAM_SETS', '0'), MAIN, foreign, cyc, two, *one), flush=True)
+    print('sets %s main %s foreign %d cycle %d: two-batch %.2f ms/step   single-stream %.2f %.2f' % (os.environ.get('M17HIP_STREAM_SETS', '1'), MAIN, foreign, cyc, two, *one), flush=True)
