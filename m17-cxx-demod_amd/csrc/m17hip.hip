@@ -1400,6 +1400,10 @@ static int gate_mode_for_run(m17hip_ctx* c, const SegPlan& sp)
 {
     const bool want = c->gate_aware == 1 || (c->gate_aware < 0 && c->chan_segs_prev && 4ull * c->off_segs_prev > (uint64_t)c->chan_segs_prev);
     c->gate_run = want && sp.nseg >= 3u && !c->front_ahead && !c->profile;
+    // A gate-aware run is a run on mostly idle channels: K1 skips most of its work, K5's waves jump from update point to update point — what is left of the step
+    // is K3's chain, which sees every sample whatever the gate does.  Its latency form then (four waves per 32 channels, 1.1-1.9 ms per launch against
+    // 2.2-3.7): the wave slots it takes are free on such input.
+    if (c->gate_run && c->dcd_form < 0) c->dcd_latency = true;
     if (!c->truth) {   // (K5 leaves the gate state and counts the closed gates in every mode: the next run's choice comes from it)
         HIPCHK(c, hipMalloc((void**)&c->truth, 2 * (size_t)c->maxC * sizeof(GateTruth)));
         HIPCHK(c, hipMalloc((void**)&c->first_needed, (size_t)c->maxC * sizeof(uint32_t)));

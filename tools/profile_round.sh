@@ -16,10 +16,12 @@ ARGS="--in-flight 1 --single-stream 0 --one-at-a-time 0 --steps 4 --warmup 1 --p
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -d $OUT/sq -o sq -- python3 $R/bench.py $ARGS > $OUT/sq.log 2>&1
+# (the instruction counts go into profiles/valu.json, which prices the HEADLINE regime — two batches in flight, ten equal segments per run: the ramp of short
+#  segments the library gives a run that is alone in flight, m17hip_tune key 33 = -1, is pinned off for the two counter passes that feed it)
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -d $OUT/sq -o sq -- python3 $R/bench.py $ARGS --tune 33=0 > $OUT/sq.log 2>&1
 # the clock the chip holds: GRBM_GUI_ACTIVE (cycles the GPU was active during a dispatch) / the dispatch's duration, with the VALU-busy counter
 # beside it — per kernel of the chain (dispatches are serialised under counter collection: each kernel ALONE), and for K1 alone in both forms
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace -d $OUT/clk -o clk -- python3 $R/bench.py $ARGS > $OUT/clk.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace -d $OUT/clk -o clk -- python3 $R/bench.py $ARGS --tune 33=0 > $OUT/clk.log 2>&1
 M17HIP_LIB=$R/m17-cxx-demod_amd/libm17hip_tools.so rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace -d $OUT/clk_k1 -o clk_k1 -- python3 $R/tools/k1_only.py > $OUT/clk_k1.log 2>&1
 # ... and in the real mix (no profiler): one wave of another process records shader cycles against the 100 MHz wall clock (tools/clock_probe.hip)
 # while the default command's two-batch regime runs (200 timed steps = 4 s)
