@@ -722,7 +722,9 @@ class Bench:
         dt, kern = self.dt, self.kern
         src = seq_kern if seq_kern else kern
         src_steps = args.one_at_a_time_steps if seq_kern else args.steps
-        dom = max((k for k in src if src[k]["ms_avg"]), key=lambda k: src[k]["ms_per_step"])
+        # (the limit filter's launches are of three kinds — a run's first segment, replays ahead, redos of a few channels: 4 us ... 1.7 ms — so their average is
+        #  no launch's duration, and all but the first run beside K5: K2 is reported in kernel_ms but is not a candidate for the kernel `roofline` is about)
+        dom = max((k for k in src if src[k]["ms_avg"] and k != "limit_track"), key=lambda k: src[k]["ms_per_step"])
         dom_s = src[dom]["ms_avg"] / 1e3                                    # average duration of ONE launch of the dominant kernel
         launches_per_step = src[dom]["launches"] / src_steps
         units = C * T / launches_per_step                                    # samples one launch processes
@@ -731,8 +733,9 @@ class Bench:
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("channels") == C and tj.get("samples") == T and tj.get("launches_per_step") == launches_per_step and dom in tj.get("kernels", {}):
-                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]   # per launch (= per segment), like `achieved`
+            tk = tj.get("kernels", {}).get(dom)
+            if tj.get("channels") == C and tj.get("samples") == T and tk and tk.get("launches_per_step", tj.get("launches_per_step")) == launches_per_step:
+                traffic = tk["hbm_bytes_per_launch"]   # per launch (= per segment), like `achieved`
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "regime": ("one step strictly after the other, %d steps outside the timed regions (launch durations as rocprofv3 reports them)" % src_steps)

@@ -5,7 +5,7 @@ set -euo pipefail
 TAG=${1:?tag of the profile_round.sh run}; R=${2:?round prefix, e.g. r5}
 D=gpurun_out/profiles_$TAG
 python3 tools/make_valu.py $D 4096 480000 5 profiles/valu.json
-python3 tools/make_traffic.py $D 4096 480000 ${LAUNCHES:-12} profiles/traffic.json
+python3 tools/make_traffic.py $D 4096 480000 5 profiles/traffic.json
 cp $D/trace_summary.md profiles/${R}_one_at_a_time_kernel_trace_stats.md
 cp $D/trace_bench_line.json profiles/${R}_one_at_a_time_bench_line_under_rocprof.json
 cp $D/trace_default_summary.md profiles/${R}_default_command_kernel_trace_stats.md

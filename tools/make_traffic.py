@@ -2,23 +2,30 @@
 """profiles/traffic.json from the PMC passes of tools/profile_round.sh: HBM bytes per LAUNCH of each kernel
 = (2 * FETCH_SIZE + WRITE_SIZE) KB — FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of the
 coalesced streaming reads), counters are per-dispatch averages in KB.  A run of the bench is processed in
-segments (a short first one, then equal ones), so a launch covers channels x samples / launches-per-step on average.
-Usage: make_traffic.py <dir with fetch_summary.md, write_summary.md> <channels> <samples> <launches per step> <out.json>"""
+segments, so a launch covers channels x samples / launches-per-step on average; launches per step per kernel = its calls in the pass / the runs of the pass
+(a run that is alone in flight starts with a ramp of short segments: 12 launches of K1 / K3 / K5 per run, 22 of K2 — replays ahead and redos).
+Usage: make_traffic.py <dir with fetch_summary.md, write_summary.md> <channels> <samples> <runs in the pass> <out.json>"""
 import json, re, sys
-d, C, T, lps, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+d, C, T, runs, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 def val(path, kerns, ctr):
     for l in open(path):
         if l.startswith('- ') and any(k in l for k in kerns):
             return float(re.search(ctr + r'=([0-9.e+]+)', l).group(1))
     return None
+def calls(path, kerns):
+    n = 0
+    for l in open(path):
+        if l.startswith('| ') and any(k in l for k in kerns):
+            n += int(l.strip().strip('|').split('|')[1])
+    return n
 # (the carrier-detect kernel in whichever form the profiled regime ran: one wave per 32 channels, or the four-wave latency form)
 K = {'fir_rrc150': ('fir_rrc150_',), 'dcd': ('dcd_kernel', 'dcd_pipe_kernel'), 'limit_track': ('limit_track_kernel',), 'demod_seq': ('demod_wave_kernel',)}
-j = {'channels': C, 'samples': T, 'launches_per_step': lps,
+j = {'channels': C, 'samples': T, 'runs_in_pass': runs,
      'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh); per-dispatch averages in KB; '
                'FETCH_SIZE doubled per MI355X_MICROARCH.md; limit_track averages include the near-empty redo launches', 'kernels': {}}
 for k, n in K.items():
     f, w = val(f'{d}/fetch_summary.md', n, 'FETCH_SIZE'), val(f'{d}/write_summary.md', n, 'WRITE_SIZE')
     if f is None or w is None: continue
-    j['kernels'][k] = {'fetch_size_kb_raw': f, 'write_size_kb_raw': w, 'hbm_bytes_per_launch': int((2 * f + w) * 1024)}
+    j['kernels'][k] = {'fetch_size_kb_raw': f, 'write_size_kb_raw': w, 'hbm_bytes_per_launch': int((2 * f + w) * 1024), 'launches_per_step': calls(f'{d}/fetch_summary.md', n) / runs}
 json.dump(j, open(out, 'w'), indent=1)
 for k, v in j['kernels'].items(): print(k, round(v['hbm_bytes_per_launch'] / 1e9, 3), 'GB per launch')
