@@ -175,28 +175,35 @@ struct DeferParams {
     EvParams ev;                  // the run's deferred EVM (m17_state.hpp): folded by the blocks behind the first C of the launch (ops == nullptr: none)
 };
 constexpr int DEFER_HIST_WORDS = 201;                                   // 201 trellis steps (BERT), one decision word per step
-constexpr int DEFER_LDS_BYTES = (46 + 8) * 64 * 4 + 4 * 488 * 2 + 512 * 2;   // LLR nibbles, output bytes, source maps, the list of deferred slots: 18.7 KB
-__global__ __launch_bounds__(64) void decode_deferred_kernel(DeferParams P)
+// Two channels (waves) per workgroup share the source maps: 31.5 KB per two waves = ten waves per CU instead of eight (LDS is what limits this kernel's waves, and
+// what it lasts is what those waves can issue).
+constexpr int DEFER_CPB = 2;                                            // channels (waves) per workgroup
+constexpr int DEFER_WAVE_WORDS = (46 + 8) * 64 + 512 / 2;               // per wave: LLR nibbles, output bytes, the list of deferred slots
+constexpr int DEFER_LDS_BYTES = DEFER_CPB * DEFER_WAVE_WORDS * 4 + 4 * 488 * 2;   // + the source maps: 33.5 KB
+constexpr uint32_t defer_blocks(uint32_t C) { return (C + DEFER_CPB - 1) / DEFER_CPB; }
+__global__ __launch_bounds__(64 * DEFER_CPB) void decode_deferred_kernel(DeferParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    if (blockIdx.x >= P.C) {    // (a handful of blocks: the EVM fold runs beside the decode instead of in front of or behind it)
-        evm_fold_pass(P.ev, blockIdx.x - P.C, reinterpret_cast<float*>(lds));
+    if (blockIdx.x >= defer_blocks(P.C)) {    // (a handful of blocks: the EVM fold runs beside the decode instead of in front of or behind it)
+        if (threadIdx.x < 64) evm_fold_pass(P.ev, blockIdx.x - defer_blocks(P.C), reinterpret_cast<float*>(lds));
         return;
     }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* wb = lds + wave * DEFER_WAVE_WORDS;
     DecodeLds L;
-    L.llr = lds;                // [46][64] nibbles
-    L.outb = lds + 46 * 64;     // [8][64]
-    uint16_t* maps = reinterpret_cast<uint16_t*>(L.outb + 8 * 64);   // [4][488] source maps (every trellis step reads two entries)
-    uint16_t* list = maps + 4 * 488;    // [<= 512] the slots whose frames are deferred, in order
+    L.llr = wb;                 // [46][64] nibbles
+    L.outb = wb + 46 * 64;      // [8][64]
+    uint16_t* list = reinterpret_cast<uint16_t*>(L.outb + 8 * 64);    // [<= 512] the slots whose frames are deferred, in order
+    uint16_t* maps = reinterpret_cast<uint16_t*>(lds + DEFER_CPB * DEFER_WAVE_WORDS);   // [4][488] source maps (every trellis step reads two entries)
     L.lsf = nullptr;
     L.stride = 64;
     L.prof = nullptr;
     L.soft = nullptr;
-    const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * DEFER_CPB + wave;
     L.hist = P.hist + (size_t)c * DEFER_HIST_WORDS * 64;
-    for (int k = lane; k < 4 * 488; k += 64) maps[k] = P.tables->src[k / 488][k % 488];
-    __syncthreads();
+    for (int k = threadIdx.x; k < 4 * 488; k += 64 * DEFER_CPB) maps[k] = P.tables->src[k / 488][k % 488];
+    __syncthreads();            // the only block-level barrier: the waves of a block are independent from here on
     L.src = maps;
     L.lich_src = P.tables->lich_src;
     if (c >= P.C) return;
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(64) void decode_deferred_kernel(DeferParams P)
         // the deferred slots as a dense list: a stream's records alternate LICH / payload — with a lane per SLOT half the lanes idled
         const uint32_t s1 = min(n, s0 + 512u);
         uint32_t nd = 0;
-        __syncthreads();
+        wave_lds_sync();
         for (uint32_t base = s0; base < s1; base += 64) {
             const uint32_t slot = base + lane;
             bool d = false;
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(64) void decode_deferred_kernel(DeferParams P)
             if (d) list[nd + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)(slot - s0);
             nd += (uint32_t)__popcll(mask);
         }
-        __syncthreads();
+        wave_lds_sync();
         for (uint32_t k0 = lane; k0 < nd; k0 += 64) {
             const uint32_t slot = s0 + as_lds(list)[k0];
             uint32_t* w = reinterpret_cast<uint32_t*>(recs + slot);
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(64) void decode_deferred_kernel(DeferParams P)
         }
     }
     __threadfence_block();
-    __syncthreads();
+    wave_lds_sync();
     auto settle = [&](int32_t& v) {
         const uint32_t u = (uint32_t)v;
         if (cost_is_deferred(u)) v = recs[u & ~DEFER_TAG].cost;

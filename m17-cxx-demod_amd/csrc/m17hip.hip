@@ -1594,7 +1594,7 @@ static int flush_payload(m17hip_ctx* c, bool selected_only = false, bool older_o
                 c->fold_pending = false;
             }
             TimedK tm(c, KT_DEC);
-            tm.launch(decode_deferred_kernel, dim3(C + fold_blocks), dim3(64), DEFER_LDS_BYTES, ps, D);
+            tm.launch(decode_deferred_kernel, dim3(defer_blocks(C) + fold_blocks), dim3(64 * DEFER_CPB), DEFER_LDS_BYTES, ps, D);
             HIPCHK(c, hipGetLastError());
         }
         if (rs.bert && c->bert_state)   // payload consumer: PRBS9 statistics over this run's BERT records

@@ -38,7 +38,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     for spec, seg, pieces, piped in ((1, 19200, None, 0), (1, rseg, None, 0), (0, rseg, None, 0), (1, 0, None, 0), (1, 19200, [0] + cuts + [T], 0),
                                      (1, 19200, [0] + cuts + [T], 1), (0, rseg, [0] + cuts + [T], 1), (1, 4800, [0] + cuts + [T], 1),
                                      (1, 19200, [0] + cuts + [T], 2), (1, rseg, [0] + cuts + [T], 2), (0, 4800, [0] + cuts + [T], 2)):
-        ctx.tune(15, spec); ctx.tune(3, seg); ctx.tune(33, 2400 if (seed + piped) % 3 == 0 else 0); ctx.tune(20, (seed + spec + piped) & 1); ctx.tune(17, (seed + piped + (seg & 1)) & 1); ctx.tune(26, (seed + spec + (seg >> 2)) & 1); ctx.reset()
+        ctx.tune(15, spec); ctx.tune(3, seg); ctx.tune(33, (2400, 0, -1)[(seed + piped) % 3]); ctx.tune(20, (seed + spec + piped) & 1); ctx.tune(17, (seed + piped + (seg & 1)) & 1); ctx.tune(26, (seed + spec + (seg >> 2)) & 1); ctx.reset()
         if pieces is None:
             ctx.upload(x); ctx.run(flags=inv); got = ctx.frames()
         elif not piped:   # the same stream as three runs (state, filter history and DCD sums carried between them)
