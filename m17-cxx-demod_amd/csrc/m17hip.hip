@@ -758,7 +758,10 @@ int m17hip_last_hip_error(const m17hip_ctx* ctx) { return ctx ? ctx->last_hip : 
 // (tools/stream_history.py: 24.3 -> 26.2 -> 31.8 ms per step over three cycles with per-context streams and a host main stream; 22.1-22.5 in every cycle this way).
 // M17HIP_STREAM_SETS=0 in the environment restores per-context streams on the default stream (tools/stream_history.py's A/B).
 struct StreamSet { hipStream_t main, side, side2, side3, copy; int device; };
-static struct { std::mutex mu; std::vector<StreamSet> parked; } g_sets;
+// (heap-allocated once and never destroyed, like the run registry: a context destroyed during static destruction at process exit still finds it)
+struct StreamSets { std::mutex mu; std::vector<StreamSet> parked; };
+static StreamSets& g_sets_ref() { static StreamSets* r = new StreamSets; return *r; }
+#define g_sets (g_sets_ref())
 static int stream_set_mode()
 {
     const char* e = getenv("M17HIP_STREAM_SETS");

@@ -100,3 +100,12 @@ print(r1, r2, b"GPU_MAX_HW_QUEUES" in lib.m17hip_strerror(C.c_int(-8)))
     import m17hip as m
     r = subprocess.run([sys.executable, "-c", code, m.LIB_PATH], capture_output=True, text=True, timeout=120)
     assert r.stdout.split() == ["-8", "-8", "True"], r.stdout + r.stderr
+
+
+def test_get_stream_refuses_null_arguments():
+    """m17hip_get_stream (round 6: the library owns a context's main stream): argument errors need no GPU."""
+    import ctypes as C
+    lib = m17hip.load_library()
+    h = C.c_void_p()
+    assert lib.m17hip_get_stream(C.c_void_p(), C.byref(h)) == -1
+    assert lib.m17hip_set_stream(C.c_void_p(), C.c_void_p()) == -1
