@@ -69,7 +69,8 @@ def test_truncated_fetch_reports_total():
     code = c.lib.m17hip_frames_fetch(c.h, part.ctypes.data_as(C.c_void_p), C.c_uint64(10), C.byref(n))
     assert code == m17hip.ETRUNC and n.value == full.size and part.tobytes() == full[:10].tobytes()
     import torch
-    dev = torch.zeros(7 * 64, dtype=torch.uint8, device="cuda")
+    with torch.cuda.stream(c.torch_stream()):      # the zero fill ON the context's stream: it is non-blocking, the default stream orders nothing with it
+        dev = torch.zeros(7 * 64, dtype=torch.uint8, device="cuda")
     code = c.lib.m17hip_frames_compact_device(c.h, C.c_void_p(dev.data_ptr()), C.c_uint64(7), C.byref(n))
     assert code == m17hip.ETRUNC and n.value == full.size
     assert dev.cpu().numpy().tobytes() == full[:7].tobytes()
@@ -411,9 +412,11 @@ ctx = m17hip.Context(hi - lo, T)
 ctx.set_channel_base(lo)
 ctx.synth(p, hi - lo, T, chan0=lo)            # this shard's channels of the global job, generated on the device
 ctx.reset(); ctx.run()
-buf = torch.zeros((hi - lo) * 64 * 64, dtype=torch.uint8, device="cuda")
-n = ctx.frames_compact_device(buf.data_ptr(), buf.numel() // 64)
-allrecs, counts = mdist.gather_records(buf.cpu(), n)       # gloo: host tensors (two ranks share the one GPU of this box)
+with torch.cuda.stream(ctx.torch_stream()):   # (the fill and the read-back on the context's own, non-blocking stream)
+    buf = torch.zeros((hi - lo) * 64 * 64, dtype=torch.uint8, device="cuda")
+    n = ctx.frames_compact_device(buf.data_ptr(), buf.numel() // 64)
+    host = buf.cpu()
+allrecs, counts = mdist.gather_records(host, n)       # gloo: host tensors (two ranks share the one GPU of this box)
 np.save(os.path.join(sys.argv[4], f"rank{{rank}}.npy"), allrecs.numpy())
 dist.barrier(); dist.destroy_process_group()
 """
