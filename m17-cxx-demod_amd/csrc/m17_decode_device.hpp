@@ -263,12 +263,15 @@ __device__ __forceinline__ uint32_t viterbi_decode(const DecodeTables* tb, const
 
 // The lane-per-frame decoder with the sixteen path metrics as EIGHT packed 16-bit pairs P[k] = (m[2k], m[2k + 1]) — one v_pk_add_u16 /
 // v_pk_min_u16 serves both new states of a butterfly, the predecessor's metric broadcast into both halves by the instruction's op_sel
-// (no move).  Metrics are kept DOUBLED (even); the candidate through the lower predecessor j gets an even branch cost (2 c), the one
-// through the upper predecessor j + 8 an odd one (2 c + 1): their minimum is the survivor — a tie keeps the lower predecessor, as
-// Viterbi.h:143-158's strict `m0 > m2` does — and its lowest bit is the decision.  Unreachable states start at the sentinel 20000: any
-// value that stays above every reachable metric (<= 4 x 28 while a sentinel is still in play: all sixteen states are reachable from step 4
-// on) and below 2^15 - 244 x 28 orders exactly like the reference's INT_MAX / 2 — the same sentinel is on both sides of every comparison it
-// takes part in.  A step's decision word (ONE 32-bit word per step): bit j = new state 2j, bit 16 + j = new state 2j + 1.
+// (no move).  The candidates through the lower predecessor j, x = (m[j] + cost0, m[j] + cost1), and through the upper one, y = (m[j + 8] +
+// cost1, m[j + 8] + cost0): the survivor is their packed minimum, the decision the SIGN of y - x in each half (v_pk_sub_u16: set exactly when
+// y < x — a tie keeps the lower predecessor, as Viterbi.h:143-158's strict `m0 > m2` does; metrics stay below 2^15, so the 16-bit
+// difference cannot wrap), collected by a shift and a masked or.  (Up to the middle of round 6 the metrics were kept doubled with the
+// decision in the survivor's lowest bit: seven instructions per butterfly where this form needs six, and four more per step for the doubled
+// and the odd costs.)  Unreachable states start at the sentinel 20000: any value that stays above every reachable metric (<= 4 x 28 while a
+// sentinel is still in play: all sixteen states are reachable from step 4 on) and below 2^15 - 244 x 28 orders exactly like the reference's
+// INT_MAX / 2 — the same sentinel is on both sides of every comparison it takes part in.  A step's decision word (ONE 32-bit word per step):
+// bit 8 + j = new state 2j, bit 24 + j = new state 2j + 1.
 // LDS frame as nibbles, source maps in LDS, decision words in GLOBAL memory (hist: [steps][stride]).  Same results as viterbi_decode.
 __device__ __forceinline__ uint32_t pk_add_bcast_lo(uint32_t p, uint32_t c)   // (p.lo + c.lo, p.lo + c.hi)
 {
@@ -288,11 +291,17 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b)   // (a.lo - b.lo, a.hi - b.hi), each modulo 2^16
+{
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ uint32_t viterbi_decode_pk(const DecodeLds& L, int lane, int kind, int& stale_io)
 {
     const int IN = DEC_IN[kind & 3], OUT = DEC_OUT[kind & 3];
     const int steps = IN >> 1;
-    constexpr uint32_t SENT = 2u * 20000u;
+    constexpr uint32_t SENT = 20000u;
     uint32_t P[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) P[k] = SENT | (SENT << 16);
@@ -306,34 +315,31 @@ __device__ __forceinline__ uint32_t viterbi_decode_pk(const DecodeLds& L, int la
             ns0 = soft_at<true, true>(L.src, L.llr, L.stride, lane, kind, 2 * h + 2, stale_io);
             ns1 = soft_at<true, true>(L.src, L.llr, L.stride, lane, kind, 2 * h + 3, stale_io);
         }
-        // branch metrics (Viterbi.h:181-200), doubled: |c - s| for c = -7 / +7, 0 for an erased bit
-        const uint32_t a = s0 ? 2u * (uint32_t)abs(-7 - s0) : 0u, b = s0 ? 2u * (uint32_t)abs(7 - s0) : 0u;
-        const uint32_t d = s1 ? 2u * (uint32_t)abs(-7 - s1) : 0u, e = s1 ? 2u * (uint32_t)abs(7 - s1) : 0u;
+        // branch metrics (Viterbi.h:181-200): |c - s| for c = -7 / +7, 0 for an erased bit
+        const uint32_t a = s0 ? (uint32_t)abs(-7 - s0) : 0u, b = s0 ? (uint32_t)abs(7 - s0) : 0u;
+        const uint32_t d = s1 ? (uint32_t)abs(-7 - s1) : 0u, e = s1 ? (uint32_t)abs(7 - s1) : 0u;
         const uint32_t nn = a + d, np = a + e, pn = b + d, pp = b + e;
         // cost_[0..7] = nn np np nn pn pp pp pn (polys 031/027); cost1 of a butterfly is the complement of its cost0.
-        // Per butterfly j: even pair (cost0, cost1) for the lower predecessor, odd pair (cost1 + 1, cost0 + 1) for the upper one — four
-        // distinct pairs of each
+        // Per butterfly j: the pair (cost0, cost1) for the lower predecessor, (cost1, cost0) for the upper one — four distinct pairs in all
         const uint32_t e_nn = nn | (pp << 16), e_np = np | (pn << 16), e_pn = pn | (np << 16), e_pp = pp | (nn << 16);
-        const uint32_t o_nn = e_pp + 0x00010001u, o_np = e_pn + 0x00010001u, o_pn = e_np + 0x00010001u, o_pp = e_nn + 0x00010001u;   // (cost1 + 1, cost0 + 1) of the butterfly whose cost0 is nn / np / pn / pp
         const uint32_t ce[8] = {e_nn, e_np, e_np, e_nn, e_pn, e_pp, e_pp, e_pn};
-        const uint32_t co[8] = {o_nn, o_np, o_np, o_nn, o_pn, o_pp, o_pp, o_pn};
+        const uint32_t co[8] = {e_pp, e_pn, e_pn, e_pp, e_np, e_nn, e_nn, e_np};
         uint32_t N[8];
         uint32_t acc = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            // new states (2j, 2j + 1): through j: (m[j] + cost0, m[j] + cost1); through j + 8: (m[j+8] + cost1 + 1, m[j+8] + cost0 + 1)
+            // new states (2j, 2j + 1): through j: (m[j] + cost0, m[j] + cost1); through j + 8: (m[j+8] + cost1, m[j+8] + cost0)
             const uint32_t x = (j & 1) ? pk_add_bcast_hi(P[j >> 1], ce[j]) : pk_add_bcast_lo(P[j >> 1], ce[j]);
             const uint32_t y = (j & 1) ? pk_add_bcast_hi(P[(j + 8) >> 1], co[j]) : pk_add_bcast_lo(P[(j + 8) >> 1], co[j]);
-            const uint32_t n = pk_min_u16(x, y);
-            acc |= (n & 0x00010001u) << j;
-            N[j] = n & 0xFFFEFFFEu;
+            N[j] = pk_min_u16(x, y);
+            acc = (acc >> 1) | (pk_sub_u16(y, x) & 0x80008000u);   // after the eighth: butterfly j's two decisions at bits 8 + j and 24 + j
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) P[k] = N[k];
         as_global(L.hist)[h * L.stride + lane] = acc;
     }
     // end state: first strict minimum scanning 0 -> 15 (Viterbi.h:211-221)
-    auto metric = [&](int s) { return (int32_t)(((s & 1) ? P[s >> 1] >> 16 : P[s >> 1] & 0xFFFFu) >> 1); };
+    auto metric = [&](int s) { return (int32_t)((s & 1) ? P[s >> 1] >> 16 : P[s >> 1] & 0xFFFFu); };
     int best = 0;
     int32_t best_cost = metric(0);
 #pragma unroll
@@ -353,7 +359,7 @@ __device__ __forceinline__ uint32_t viterbi_decode_pk(const DecodeLds& L, int la
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if (top - 1 - i < 0 || o <= 0) break;
-            const uint32_t v = (hwv[i] >> ((state >> 1) + ((state & 1u) << 4))) & 1u;
+            const uint32_t v = (hwv[i] >> (8u + (state >> 1) + ((state & 1u) << 4))) & 1u;
             if (index-- <= OUT) {
                 --o;
                 const int byte = o >> 3;
