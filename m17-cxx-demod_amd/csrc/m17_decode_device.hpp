@@ -306,15 +306,27 @@ __device__ __forceinline__ uint32_t viterbi_decode_pk(const DecodeLds& L, int la
 #pragma unroll
     for (int k = 0; k < 8; ++k) P[k] = SENT | (SENT << 16);
     P[0] = SENT << 16;   // state 0 sits at 0 before step 0
-    int ns0 = soft_at<true, true>(L.src, L.llr, L.stride, lane, kind, 0, stale_io);
-    int ns1 = soft_at<true, true>(L.src, L.llr, L.stride, lane, kind, 1, stale_io);
+    // The two soft bits of a step: a map entry each (soft_at: where the bit comes from — a position of the frame, negated or not; an erasure; position 401 as the
+    // frame before left it), then the LLR word that holds it.  Two dependent LDS reads per step: in a pipeline of depth two — the entries of step h + 2 and the
+    // words of step h + 1 are requested while step h is computed — so that no step waits for a read it has just issued (the compiler's order of the plain form:
+    // read the entries, wait, read the words, wait, and only then the add-compare-selects).
+    const M17_LDS uint32_t* map2 = as_lds(reinterpret_cast<const uint32_t*>(L.src)) + kind * 244;   // two 16-bit entries per step
+    const M17_LDS uint32_t* frame = as_lds(L.llr);
+    auto ld_e = [&](int h) -> uint32_t { return h < steps ? map2[h] : 0x80008000u; };
+    auto ld_w = [&](uint32_t e16) -> uint32_t { return frame[((e16 & 0x1FFu) >> 3) * L.stride + lane]; };
+    auto mk_s = [&](uint32_t e16, uint32_t w) -> int {
+        const int v = (int)(((w >> (4u * (e16 & 7u))) & 0xFu) ^ 8u) - 8;
+        const int wv = (e16 & 0x200u) ? -v : v;
+        return (e16 & 0x8000u) ? 0 : ((e16 & 0x4000u) ? stale_io : wv);
+    };
+    uint32_t e_cur = ld_e(0), e_nxt = ld_e(1);
+    uint32_t wa = ld_w(e_cur & 0xFFFFu), wb = ld_w(e_cur >> 16);
     for (int h = 0; h < steps; ++h) {
-        const int s0 = ns0, s1 = ns1;
-        if (2 * h == 400 && (kind & 3) != 3) stale_io = s1;  // this layout writes position 401
-        if (h + 1 < steps) {
-            ns0 = soft_at<true, true>(L.src, L.llr, L.stride, lane, kind, 2 * h + 2, stale_io);
-            ns1 = soft_at<true, true>(L.src, L.llr, L.stride, lane, kind, 2 * h + 3, stale_io);
-        }
+        const int s0 = mk_s(e_cur & 0xFFFFu, wa), s1 = mk_s(e_cur >> 16, wb);
+        if (2 * h == 400 && (kind & 3) != 3) stale_io = s1;  // this layout writes position 401 (the steps behind it read the new value: mk_s runs at their turn)
+        const uint32_t e_nn2 = ld_e(h + 2);
+        wa = ld_w(e_nxt & 0xFFFFu); wb = ld_w(e_nxt >> 16);
+        e_cur = e_nxt; e_nxt = e_nn2;
         // branch metrics (Viterbi.h:181-200): |c - s| for c = -7 / +7, 0 for an erased bit
         const uint32_t a = s0 ? (uint32_t)abs(-7 - s0) : 0u, b = s0 ? (uint32_t)abs(7 - s0) : 0u;
         const uint32_t d = s1 ? (uint32_t)abs(-7 - s1) : 0u, e = s1 ? (uint32_t)abs(7 - s1) : 0u;
