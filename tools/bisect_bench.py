@@ -2,7 +2,9 @@
 Every build runs in its own process (M17HIP_LIB), the list is gone through `--rounds` times so that box drift shows.
     python tools/bisect_bench.py [--rounds 2] [--single] _exp/bis/libm17hip_d8d49ef.so m17-cxx-demod_amd/libm17hip.so ...
 M17_BISECT_TUNE=key=value[,key=value] applies m17hip_tune settings to every context of every build.
---single adds the single-stream regime (two groups of 2048 channels, state carried, m17hip_demod_front) where the build has it."""
+--single adds the single-stream regime (two groups of 2048 channels, state carried, m17hip_demod_front) where the build has it — created AFTER the two-batch
+contexts were used and destroyed (a process with history).  M17_BISECT_PLACEHOLDERS=n: n foreign streams in front of every context; M17_BISECT_HOST_STREAMS=1: a host
+stream per context as up to round 5 (builds without m17hip_get_stream always)."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -13,6 +15,8 @@ def worker(single):
     import m17hip, oracle_lib as ol
     m17hip.Context._warned = True
     tunes = [tuple(int(x) for x in kv.split('=')) for kv in os.environ.get('M17_BISECT_TUNE', '').split(',') if kv]
+    # M17_BISECT_HOST_STREAMS=1: a torch stream handed to every context (m17hip_set_stream), as up to round 5; default: the library's own stream sets (round 6)
+    HOST_STREAMS = os.environ.get('M17_BISECT_HOST_STREAMS', '0') == '1' or not hasattr(m17hip.load_library(), 'm17hip_get_stream')
     class Context(m17hip.Context):
         def __init__(self, *a, **k):
             super().__init__(*a, **k)
@@ -32,7 +36,9 @@ def worker(single):
         return h
     for f in range(2):
         placeholders += [hip_stream() for _ in range(nph)]
-        c = m17hip.Context(C, T); streams.append(torch.cuda.Stream(priority=int(os.environ.get("M17_BISECT_PRIO", "0")))); c.set_stream(streams[-1].cuda_stream); c.synth(p, C, T); ctxs.append(c)
+        c = m17hip.Context(C, T)
+        if HOST_STREAMS: streams.append(torch.cuda.Stream(priority=int(os.environ.get("M17_BISECT_PRIO", "0")))); c.set_stream(streams[-1].cuda_stream)
+        c.synth(p, C, T); ctxs.append(c)
     def groups(n):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for k0 in range(0, n, 2):
@@ -51,7 +57,8 @@ def worker(single):
         try:
             for g in range(G):
                 placeholders += [hip_stream() for _ in range(nph)]
-                c = m17hip.Context(Cg, T); ss.append(torch.cuda.Stream(priority=int(os.environ.get("M17_BISECT_PRIO", "0")))); c.set_stream(ss[-1].cuda_stream)
+                c = m17hip.Context(Cg, T)
+                if HOST_STREAMS: ss.append(torch.cuda.Stream(priority=int(os.environ.get("M17_BISECT_PRIO", "0")))); c.set_stream(ss[-1].cuda_stream)
                 c.synth(p, Cg, T, chan0=g * Cg); c.tune(16, 1); c.synth(p, Cg, T, chan0=g * Cg); c.tune(16, 0)
                 c.reset(); c.run(); gs.append(c)
             def stream(n):
