@@ -231,13 +231,14 @@ def test_performance_knobs_do_not_change_results():
     c.upload(x)
     for settings in ({}, {3: 19200}, {3: 0}, {15: 0}, {15: 0, 3: 7001}, {3: 4800}, {3: 1000}, {10: 1}, {10: 1, 3: 7008}, {10: 0}, {20: 1}, {20: 1, 3: 4800}, {20: 0}, {17: 0}, {17: 0, 3: 7001, 15: 0}, {17: 1, 3: 4800},
                      {13: 256}, {13: 7, 3: 7001}, {13: 100000, 3: 4800},   # K1's bounded grid at other sizes
-                     {26: 1}, {26: 1, 3: 7001}, {26: 1, 3: 4800, 15: 0}, {26: 1, 3: 19200, 10: 1}, {26: 0}):   # the gate-aware front end forced on / off
+                     {26: 1}, {26: 1, 3: 7001}, {26: 1, 3: 4800, 15: 0}, {26: 1, 3: 19200, 10: 1}, {26: 0},   # the gate-aware front end forced on / off
+                     {33: 0}, {33: 2400}, {33: 9600, 3: 19200}, {33: 4801, 3: 7001, 15: 0}, {33: 12000, 20: 1}):   # the ramp of short first segments off / explicit (default -1: per run)
         for k, v in settings.items():
             c.tune(k, v)
         c.reset(); c.run()
         assert c.frames().tobytes() == exp.tobytes(), settings
         for k in settings:
-            c.tune(k, {3: 48000, 15: 1, 10: -1, 20: 0, 17: 1, 13: 0, 26: -1}[k])   # back to the defaults
+            c.tune(k, {3: 48000, 15: 1, 10: -1, 20: 0, 17: 1, 13: 0, 26: -1, 33: -1}[k])   # back to the defaults
     import ctypes as C_
     for key in (0, 1, 2, 4, 5, 11, 12, 14, 19, 21, 22, 25):
         assert c.lib.m17hip_tune(c.h, key, C_.c_int64(1)) == -1, key
