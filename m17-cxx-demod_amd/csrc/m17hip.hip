@@ -869,7 +869,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     bool parked = false;
     if (c->set_mode) {
         std::lock_guard<std::mutex> lk(g_sets.mu);
-        for (size_t i = 0; i < g_sets.parked.size(); ++i)
+        for (size_t i = g_sets.parked.size(); i-- > 0;)   // (the set parked last)
             if (g_sets.parked[i].device == device) {
                 const StreamSet& ss = g_sets.parked[i];
                 c->own_main = ss.main; c->side = ss.side; c->side2 = ss.side2; c->side3 = ss.side3; c->copy = ss.copy;
@@ -881,16 +881,24 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
     if (!parked) {
         // (the copy stream joins the set when something is staged — stage_prepare: created here with the others, two batches measured 21.5 against 21.1 ms)
         // (the ORDER of the four inside the set does not matter: all 24 measured, two batches 20.3-20.6, continued stream 21.3-21.7 ms on one box — NOTES 6.6)
-        if (c->set_mode && hipStreamCreateWithFlags(&c->own_main, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
-        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
-        if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) return fail(M17HIP_EHIP);
-        {   // the replay stream outranks the others: its few workgroups must not queue behind K5's thousand.  (K1's stream at the LOWEST priority
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return fail(M17HIP_EHIP);
+        auto make_set = [&](StreamSet& ss) -> bool {
+            ss = StreamSet{nullptr, nullptr, nullptr, nullptr, nullptr, device};
+            if (c->set_mode && hipStreamCreateWithFlags(&ss.main, hipStreamNonBlocking) != hipSuccess) return false;
+            if (hipStreamCreateWithFlags(&ss.side, hipStreamNonBlocking) != hipSuccess) return false;
+            if (hipStreamCreateWithFlags(&ss.side2, hipStreamNonBlocking) != hipSuccess) return false;
+            // the replay stream outranks the others: its few workgroups must not queue behind K5's thousand.  (K1's stream at the LOWEST priority
             // was tried: a continued stream of 2 x 2048 channels 24.6 -> 22.8 ms in a process with history, but 2 x 1024 channels 11.5 -> 16.1 ms —
             // K1 starves behind the other group's kernels: NOTES 5.10.)
-            int least = 0, greatest = 0;
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return fail(M17HIP_EHIP);
-            if (hipStreamCreateWithPriority(&c->side3, hipStreamNonBlocking, greatest) != hipSuccess) return fail(M17HIP_EHIP);
-        }
+            return hipStreamCreateWithPriority(&ss.side3, hipStreamNonBlocking, greatest) == hipSuccess;
+        };
+        StreamSet mine;
+        if (!make_set(mine)) return fail(M17HIP_EHIP);
+        c->own_main = mine.main; c->side = mine.side; c->side2 = mine.side2; c->side3 = mine.side3;
+        // (creating the sets two at a time — a spare right behind every new set, so that the sets of two contexts sit side by side whatever the host creates in
+        //  between — was measured: two batches 20.6-20.9 ms in all four layouts of tools/bisect_bench.py against 20.7 / 21.6 / 20.7 / 21.3; but four more queues per
+        //  process: four rank processes on one GPU, 32 + queues in all, ran tests/test_gpu_gather_ranks.py twice as long.  Not kept: NOTES 6.6)
     }
     if (c->own_main) c->stream = c->own_main;
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
@@ -905,7 +913,7 @@ int m17hip_ctx_create(int device, uint32_t max_channels, uint32_t max_samples, m
         return fail(M17HIP_EHIP);
     if (hipFuncSetAttribute((const void*)decode_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (92 + 122 + 16) * 64 * 4) != hipSuccess)
         return fail(M17HIP_EHIP);
-    if (hipMemset(c->overflow, 0, 32) != hipSuccess) return fail(M17HIP_EHIP);
+    if (hipMemset(c->overflow, 0, 32) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(M17HIP_EHIP);   // (default-stream work of the creation is through before the context's own streams start)
     for (hipEvent_t* e : {&c->sets[0].done, &c->sets[1].done, &c->sets[0].chain, &c->sets[1].chain, &c->ev_dst})
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(M17HIP_EHIP);
     { std::lock_guard<std::mutex> lk(g_runs.mu); c->seen_overlap = g_runs.overlaps; g_runs.ctxs.push_back(c); }   // (a new context has seen no overlap yet)
@@ -2213,7 +2221,11 @@ int m17hip_comm_create(m17hip_ctx* c, const void* id128, int rank, int nranks, m
     const ncclResult_t r = R.CommInitRank(&m->comm, nranks, id, rank);
     if (r != ncclSuccess) { c->last_hip = 0x10000 | (int)r; delete m; return M17HIP_ECOMM; }   // (no communicator to ask: the ncclResult_t is left in m17hip_last_hip_error, | 0x10000)
     hipError_t e = hipMalloc((void**)&m->counts_dev, 2 * (size_t)nranks * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMemset(m->counts_dev, 0xFF, 2 * (size_t)nranks * sizeof(uint64_t));   // (no slot looks like a word of call 1)
+    // (no slot looks like a word of call 1.  ON the stream the gather works on, and waited for: a plain hipMemset runs on the default stream and is not waited
+    //  for — with the library's own non-blocking streams it could land behind the first exchange's words: one first gather in a few hundred then read 0xFF..
+    //  where a peer's word had been and answered ECOMM.  Found by tests/test_gpu_gather_ranks.py, four ranks, 2 of 25 suite runs)
+    if (e == hipSuccess) e = hipMemsetAsync(m->counts_dev, 0xFF, 2 * (size_t)nranks * sizeof(uint64_t), c->pay());
+    if (e == hipSuccess) e = hipStreamSynchronize(c->pay());
     if (e == hipSuccess) e = hipHostMalloc((void**)&m->words_host, (2 + 2 * (size_t)nranks) * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) { c->last_hip = (int)e; free_dev(m->counts_dev); R.CommDestroy(m->comm); delete m; return M17HIP_ENOMEM; }
     *out = m;
@@ -2499,7 +2511,7 @@ int m17hip_tune(m17hip_ctx* c, int key, int64_t value)
         free_dev(c->diag_log, &c->last_hip); c->diag_cap = 0;
         if (value == 0) return M17HIP_OK;
         if (!c->diag_count) HIPCHK(c, hipMalloc((void**)&c->diag_count, (size_t)c->maxC * 4));
-        HIPCHK(c, hipMemset(c->diag_count, 0, (size_t)c->maxC * 4));
+        HIPCHK(c, hipMemsetAsync(c->diag_count, 0, (size_t)c->maxC * 4, c->stream));   // (on the stream the kernels that count into it run on)
         HIPCHK(c, hipMalloc((void**)&c->diag_log, (size_t)c->maxC * (size_t)value * sizeof(Diag)));
         c->diag_cap = (uint32_t)value;
         return M17HIP_OK;

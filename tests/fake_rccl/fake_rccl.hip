@@ -5,7 +5,7 @@
 // processes that share the ONE device of a test box — something the real library refuses ("duplicate GPU").  It implements the
 // symbols the product binds, between processes on one node:
 //   rendezvous            POSIX shared memory keyed by the unique id
-//   ncclAllGather         stream-ordered, host-staged (stream sync -> D2H -> shared memory -> barrier -> H2D -> barrier)
+//   ncclAllGather         stream-ordered, host-staged (stream sync -> D2H -> shared memory -> barrier -> H2D -> barrier; every copy ON the caller's stream)
 //   ncclSend / ncclRecv   one mailbox per (source, destination); the data of a message travels in a shared-memory segment of its own;
 //                         a message whose size differs from what the receiver asked for is an ERROR here (the real library would
 //                         corrupt or hang) — so a protocol whose two sides disagree about a count fails loudly
@@ -75,6 +75,15 @@ __global__ void fake_rccl_wait_kernel(volatile uint32_t* flag)
 {
     const uint64_t t0 = wall_clock64();
     while (!__atomic_load_n(flag, __ATOMIC_RELAXED) && wall_clock64() - t0 < 4000000000ull) __builtin_amdgcn_s_sleep(127);
+}
+
+// Every copy of the double is made ON the caller's stream and waited for there: a plain hipMemcpy works on the default stream, which orders nothing with a
+// non-blocking stream — and a host-to-device copy from pageable memory may return before its last bytes have landed.  (Round 6: the product's streams became
+// non-blocking ones of its own; one gather in a few thousand then read the PREVIOUS all-gather's words behind the double's hipMemcpy and answered ECOMM.)
+hipError_t copy_on(hipStream_t st, void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
+{
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
 }
 
 size_t dtype_bytes(ncclDataType_t t)
@@ -167,7 +176,7 @@ ncclResult_t run_ops(ncclComm* c, std::vector<Op>& ops)
         void* p = mmap(nullptr, o.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         close(fd);
         if (p == MAP_FAILED) return ncclSystemError;
-        const hipError_t e = hipMemcpy(p, o.buf, o.bytes, hipMemcpyDeviceToHost);
+        const hipError_t e = copy_on(o.stream, p, o.buf, o.bytes, hipMemcpyDeviceToHost);
         munmap(p, o.bytes);
         if (e != hipSuccess) return ncclUnhandledCudaError;
         b.bytes.store(o.bytes, std::memory_order_release);
@@ -197,7 +206,7 @@ ncclResult_t run_ops(ncclComm* c, std::vector<Op>& ops)
         void* p = mmap(nullptr, got, PROT_READ, MAP_SHARED, fd, 0);
         close(fd);
         if (p == MAP_FAILED) return ncclSystemError;
-        const hipError_t e = hipMemcpy(o.buf, p, got, hipMemcpyHostToDevice);
+        const hipError_t e = copy_on(o.stream, o.buf, p, got, hipMemcpyHostToDevice);
         munmap(p, got);
         shm_unlink(name.c_str());
         b.taken.store(seq, std::memory_order_release);
@@ -333,10 +342,10 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
     if (!c || !send || !recv || !bytes || bytes > AG_MAX) return ncclInvalidArgument;
     if (c->hung) return ncclSuccess;
     if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
-    if (hipMemcpy(c->sh->ag[c->rank], send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    if (copy_on(st, c->sh->ag[c->rank], send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
     if (!c->barrier()) return c->timed_out("all-gather: not every rank came", st);
     for (int k = 0; k < c->nranks; ++k)
-        if (hipMemcpy((char*)recv + (size_t)k * bytes, c->sh->ag[k], bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+        if (copy_on(st, (char*)recv + (size_t)k * bytes, c->sh->ag[k], bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
     c->say("allgather bytes=%zu", bytes);
     if (!c->barrier()) return c->timed_out("all-gather: not every rank read", st);
     return ncclSuccess;
