@@ -197,7 +197,7 @@ def parse_args():
                     "reset: a live feed; the front end of run k + 1 is queued through m17hip_demod_front while run k's K2/K5 chain drains) -> value_single_stream")
     ap.add_argument("--one-at-a-time", type=int, default=1, help="1 = also run 2 steps strictly one after the other (no overlap of any kind): the per-launch kernel "
                     "durations the roofline object is computed from (the regime in which HIP events and rocprofv3 agree)")
-    ap.add_argument("--one-at-a-time-steps", type=int, default=2)
+    ap.add_argument("--one-at-a-time-steps", type=int, default=4)
     ap.add_argument("--stream-order", choices=("run_then_fetch", "fetch_then_run"), default="run_then_fetch", help="single-stream regime: queue run k + 1's state-machine half "
                     "before run k's records are collected (m17hip_frames_select(1); default) or after (the order of rounds 3-5)")
     ap.add_argument("--stream-groups", type=int, default=2, help="contexts the channels of the single-stream regime are split into (independent chains)")
