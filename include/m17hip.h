@@ -415,7 +415,10 @@ int m17hip_tune(m17hip_ctx* ctx, int key, int64_t value);
 int m17hip_debug_counters(m17hip_ctx* ctx, uint64_t* host, uint32_t max_waves, uint32_t* waves);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */
-/* When enabled, every kernel launch of the context is bracketed by HIP events on the context's stream. */
+/* When enabled, every kernel launch of the context is timed by HIP events: the five kernels of a run's chain (matched filter, carrier detect, limit filter,
+ * sequential kernel, deferred decode) by events BOUND to the launch (hipExtLaunchKernelGGL: the dispatch's own time stamps, what rocprofv3 reports), the others by
+ * a pair recorded around them on the stream they run on.  Not free on a chain of dependent launches: a continued stream 0.45 ms of a 21.7 ms step, two batches in
+ * flight 1.5 % (tools/stream_only.py, tools/stream_history.py: TIMING=1). */
 int m17hip_timing_enable(m17hip_ctx* ctx, int on);
 /* Accumulated device time (ms) and launch count per kernel since the last m17hip_timing_reset:
  * which: 0 = fir_rrc150, 1 = dcd, 2 = demod_seq, 3 = viterbi/decode_frames, 4 = correlator, 5 = compaction,
