@@ -515,7 +515,8 @@ class Bench:
         # Two timed passes of K steps: the first as a deployment runs it, the second with the library's per-kernel HIP events on for `kernel_ms` — the
         # events are not free on a chain of dependent launches (0.45-0.65 ms of a 21.7 ms step, tools/stream_only.py TIMING=1), and the `value` of this
         # leg is what the feed costs, not what measuring it costs.  (The headline leg keeps its events inside its timed region, as the contract asks.)
-        stream_steps(max(2, args.warmup))
+        # (the legs before this one end with seconds of host work — the oracle's parity run: the GPU's clocks have dropped; as in front of the headline leg)
+        stream_steps(max(2, args.warmup) + args.prewarm // 3)
         dts = timed_pass()
         for c_ in sctx:
             c_.timing(True); c_.timing_reset()
@@ -571,7 +572,8 @@ class Bench:
         if not args.one_at_a_time:
             return None, None, None
         rec_buf = self.rec_bufs[0]
-        ctx.reset(); ctx.run(); ctx.frames_count()   # (untimed: the library picks the carrier-detect kernel's form and the redo policy from whether runs overlapped lately — the legs before this one did)
+        for _ in range(1 + args.prewarm // 12):   # (untimed: the library picks the carrier-detect kernel's form, the segment ramp and the redo policy from whether runs
+            ctx.reset(); ctx.run(); ctx.frames_count()   #  overlapped lately — the legs before this one did; and a GPU that has idled needs load before its clocks settle)
         def timed_pass():
             ctx.reset()
             self.torch.cuda.synchronize()
