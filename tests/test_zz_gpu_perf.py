@@ -50,5 +50,5 @@ def test_recreated_contexts_run_as_fast_as_the_first_ones():
     later = [pair_ms() for _ in range(3)]
     # (up to round 5 — a host stream handed to every context, role streams created and destroyed with it — which streams shared a hardware dispatch pipe
     #  changed from pair to pair, NOTES 4.14, and moved a pair by 10-20 %: the bounds were 1.3 / 1.6.  With the library's stream sets every pair has the first
-    #  pair's layout, NOTES 6.6; the bug this test is about made the later pairs 1.6-2.1 x slower)
-    assert sorted(later)[1] < 1.1 * first and max(later) < 1.2 * first, (first, later)
+    #  pair's layout, NOTES 6.6 (measured: within 3 %; the bounds leave room for a box's noise); the bug this test is about made the later pairs 1.6-2.1 x slower)
+    assert sorted(later)[1] < 1.15 * first and max(later) < 1.3 * first, (first, later)
