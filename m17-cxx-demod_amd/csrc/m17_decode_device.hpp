@@ -291,6 +291,12 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c)   // |a - b| + c (unsigned)
+{
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b)   // (a.lo - b.lo, a.hi - b.hi), each modulo 2^16
 {
     uint32_t r;
@@ -327,10 +333,14 @@ __device__ __forceinline__ uint32_t viterbi_decode_pk(const DecodeLds& L, int la
         const uint32_t e_nn2 = ld_e(h + 2);
         wa = ld_w(e_nxt & 0xFFFFu); wb = ld_w(e_nxt >> 16);
         e_cur = e_nxt; e_nxt = e_nn2;
-        // branch metrics (Viterbi.h:181-200): |c - s| for c = -7 / +7, 0 for an erased bit
-        const uint32_t a = s0 ? (uint32_t)abs(-7 - s0) : 0u, b = s0 ? (uint32_t)abs(7 - s0) : 0u;
-        const uint32_t d = s1 ? (uint32_t)abs(-7 - s1) : 0u, e = s1 ? (uint32_t)abs(7 - s1) : 0u;
-        const uint32_t nn = a + d, np = a + e, pn = b + d, pp = b + e;
+        // branch metrics (Viterbi.h:181-200): |c - s| for c = -7 / +7, 0 for an erased bit (s == 0), summed over the step's two bits.  With u = s + 8
+        // (s in [-8, 8]: a sign-extended nibble, possibly negated): |-7 - s| = |u - 1| and |7 - s| = |u - 15| — one v_sad_u32 each, the second bit's
+        // added to the first's by the same instruction; an erased bit compares u with itself (|u - u| = 0).  Fourteen instructions where the
+        // abs / select / add form took twenty-two.
+        const uint32_t u0 = (uint32_t)(s0 + 8), u1 = (uint32_t)(s1 + 8);
+        const uint32_t r0n = s0 ? 1u : u0, r0p = s0 ? 15u : u0, r1n = s1 ? 1u : u1, r1p = s1 ? 15u : u1;
+        const uint32_t a = sad_u32(u0, r0n, 0u), b = sad_u32(u0, r0p, 0u);
+        const uint32_t nn = sad_u32(u1, r1n, a), np = sad_u32(u1, r1p, a), pn = sad_u32(u1, r1n, b), pp = sad_u32(u1, r1p, b);
         // cost_[0..7] = nn np np nn pn pp pp pn (polys 031/027); cost1 of a butterfly is the complement of its cost0.
         // Per butterfly j: the pair (cost0, cost1) for the lower predecessor, (cost1, cost0) for the upper one — four distinct pairs in all
         const uint32_t e_nn = nn | (pp << 16), e_np = np | (pn << 16), e_pn = pn | (np << 16), e_pp = pp | (nn << 16);
