@@ -309,6 +309,40 @@ def test_measurement_build_knobs_do_not_change_results(tmp_path):
     assert r.returncode == 0 and "tools-build knobs ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+_LEGACY_STREAMS_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join({root!r}, "m17-cxx-demod_amd")); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import m17hip, oracle_lib as ol
+T = 96000
+p = ol.gen_params(seed=9, kind=-1, n_frames=T // 1920 - 4, lead_in=3072, noise_sigma=700.0, tail_sigma=700.0, lead_sigma=40000.0, total=T)
+x = ol.generate_batch(p, 24, T, threads=8)
+recs, counts, _ = ol.demod_batch(x, cap=2 * (T // 1920 + 2) + 4, threads=8)
+exp = np.concatenate([recs[c, :counts[c]] for c in range(24)]).tobytes()
+a = m17hip.Context(24, T)
+assert a.stream == 0, a.stream                    # the default stream, as up to round 5
+a.upload(x); a.reset(); a.run()
+assert a.frames().tobytes() == exp
+a.close()
+b = m17hip.Context(24, T)                        # streams per context: created and destroyed with it
+b.upload(x[:, :48000]); b.reset(); b.run(); first = b.frames().copy()
+b.upload(x[:, 48000:]); b.run()
+got = np.concatenate([first, b.frames()]); got = got[np.lexsort((got["seq"], got["channel"]))]
+assert got.tobytes() == exp
+b.close()
+print("legacy streams ok")
+"""
+
+
+def test_per_context_streams_on_the_default_stream_still_work(tmp_path):
+    """M17HIP_STREAM_SETS=0 (include/m17hip.h, m17hip_set_stream): the diagnostic mode that restores rounds 1-5 — main = the default stream, role
+    streams created and destroyed with the context — delivers the same records (a process of its own: the mode is read at context creation)."""
+    script = tmp_path / "w.py"
+    script.write_text(_LEGACY_STREAMS_WORKER.format(root=ROOT))
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, M17HIP_STREAM_SETS="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "legacy streams ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_deferred_evm_row_overflow_is_reported_not_silent():
     """the rows of deferred EVM operations (m17hip_tune key 17) are sized for what a run can produce; should a channel ever
     outrun its row, the operations beyond are dropped — m17hip_diag_fetch must SAY so (M17HIP_EOVERFLOW) instead of handing out a wrong
